@@ -1,0 +1,206 @@
+"""Seeded synthetic inputs for benchmarking and parity tests (no dataset / checkpoint is
+reachable from the build or GPU boxes).
+
+* ``param_spec``      — name -> shape table of the reference ``DLASeg`` state dict
+                        (reference: src/lib/models/networks/pose_dla_dcn.py:227-322, 377-521,
+                        convGRU.py:7-30, GN.py:4-9).  Pinned against the reference's own
+                        ``model.state_dict()`` by tests/golden/state_dict_keys_*.json.
+* ``make_state_dict`` — variance-preserving random weights in the reference checkpoint format.
+                        Each tensor is drawn from its own generator (seed, crc32(name)) and then
+                        multiplied by a per-layer calibration factor from ``synth_scales.json``
+                        (computed once, offline, by oracle/tools/calibrate_synth.py so that
+                        activations stay O(1), DCN offsets are O(1-3 px) and heat-map logits have
+                        std ~2 around the -2.19 bias).
+* ``frames``          — uint8-uniform RGB frames, normalised exactly as the reference's
+                        ``pre_process`` does (base_detector.py:132; mean/std opts.py:436-437).
+"""
+import json
+import math
+import os
+import zlib
+from collections import OrderedDict
+
+import torch
+
+MEAN = [0.408, 0.447, 0.470]
+STD = [0.289, 0.274, 0.278]
+DEFAULT_SEED = 317  # the reference's default --seed (opts.py:56)
+
+HEADS_POSE = OrderedDict([("hm", 1), ("wh", 2), ("hps", 16), ("reg", 2), ("hm_hp", 8),
+                          ("hp_offset", 2), ("scale", 3)])
+HEADS_TRACK = OrderedDict([("hm", 1), ("wh", 2), ("hps", 16), ("hps_uncertainty", 16), ("reg", 2),
+                           ("hm_hp", 8), ("hp_offset", 2), ("scale", 3), ("scale_uncertainty", 3),
+                           ("tracking", 2), ("tracking_hp", 16)])
+
+_SCALES_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "synth_scales.json")
+
+
+def config_key(arch, tracking):
+    return "%s%s" % (arch.split("_")[0], "_track" if tracking else "")
+
+
+def _bn(spec, name, c):
+    spec[name + ".weight"] = (c,)
+    spec[name + ".bias"] = (c,)
+    spec[name + ".running_mean"] = (c,)
+    spec[name + ".running_var"] = (c,)
+    spec[name + ".num_batches_tracked"] = ()
+
+
+def _block(spec, p, cin, cout):
+    spec[p + ".conv1.weight"] = (cout, cin, 3, 3)
+    _bn(spec, p + ".bn1", cout)
+    spec[p + ".conv2.weight"] = (cout, cout, 3, 3)
+    _bn(spec, p + ".bn2", cout)
+
+
+def _tree(spec, p, levels, cin, cout, level_root, root_dim=0):
+    if root_dim == 0:
+        root_dim = 2 * cout
+    if level_root:
+        root_dim += cin
+    if levels == 1:
+        _block(spec, p + ".tree1", cin, cout)
+        _block(spec, p + ".tree2", cout, cout)
+        spec[p + ".root.conv.weight"] = (cout, root_dim, 1, 1)
+        _bn(spec, p + ".root.bn", cout)
+    else:
+        _tree(spec, p + ".tree1", levels - 1, cin, cout, False, 0)
+        _tree(spec, p + ".tree2", levels - 1, cout, cout, False, root_dim + cout)
+    if cin != cout:
+        spec[p + ".project.0.weight"] = (cout, cin, 1, 1)
+        _bn(spec, p + ".project.1", cout)
+
+
+def _deform(spec, p, chi, cho):
+    _bn(spec, p + ".actf.0", cho)
+    spec[p + ".conv.weight"] = (cho, chi, 3, 3)
+    spec[p + ".conv.bias"] = (cho,)
+    spec[p + ".conv.conv_offset_mask.weight"] = (27, chi, 3, 3)
+    spec[p + ".conv.conv_offset_mask.bias"] = (27,)
+
+
+def _ida(spec, p, o, channels, up_f):
+    for i in range(1, len(channels)):
+        f = int(up_f[i])
+        _deform(spec, "%s.proj_%d" % (p, i), channels[i], o)
+        spec["%s.up_%d.weight" % (p, i)] = (o, 1, 2 * f, 2 * f)
+        _deform(spec, "%s.node_%d" % (p, i), o, o)
+
+
+def param_spec(arch="dla_34", heads=None, tracking=False, head_conv=256):
+    """OrderedDict name -> shape of the reference DLASeg state dict for 'dla_34' / 'dlav1_34'."""
+    base_arch = arch.split("_")[0]
+    assert base_arch in ("dla", "dlav1"), arch
+    heads = heads or (HEADS_TRACK if tracking else HEADS_POSE)
+    ch = [16, 32, 64, 128, 256, 512]
+    s = OrderedDict()
+    s["base.base_layer.0.weight"] = (16, 3, 7, 7)
+    _bn(s, "base.base_layer.1", 16)
+    s["base.level0.0.weight"] = (16, 16, 3, 3)
+    _bn(s, "base.level0.1", 16)
+    s["base.level1.0.weight"] = (32, 16, 3, 3)
+    _bn(s, "base.level1.1", 32)
+    _tree(s, "base.level2", 1, ch[1], ch[2], False)
+    _tree(s, "base.level3", 2, ch[2], ch[3], True)
+    _tree(s, "base.level4", 2, ch[3], ch[4], True)
+    _tree(s, "base.level5", 1, ch[4], ch[5], True)
+    if tracking:
+        for nm, cin in (("pre_img_layer", 3), ("pre_hm_layer", 1), ("pre_hm_hp_layer", 8)):
+            s["base.%s.0.weight" % nm] = (16, cin, 7, 7)
+            _bn(s, "base.%s.1" % nm, 16)
+    _ida(s, "dla_up.ida_0", 256, [256, 512], [1, 2])
+    _ida(s, "dla_up.ida_1", 128, [128, 256, 256], [1, 2, 2])
+    _ida(s, "dla_up.ida_2", 64, [64, 128, 128, 128], [1, 2, 2, 2])
+    if base_arch == "dlav1":
+        for g in ("Wir", "Whr", "Wiz", "Whz", "Win", "Whn"):
+            s["convGRU.cell0.%s.weight" % g] = (64, 64, 3, 3)
+            if g[1] == "i":
+                s["convGRU.cell0.%s.bias" % g] = (64,)
+    _ida(s, "ida_up", 64, [64, 128, 256], [1, 2, 4])
+    for h, classes in heads.items():
+        s[h + ".0.weight"] = (head_conv, 64, 3, 3)
+        s[h + ".0.bias"] = (head_conv,)
+        last = 2
+        if base_arch == "dlav1":
+            s[h + ".1.weight"] = (head_conv,)
+            s[h + ".1.bias"] = (head_conv,)
+            last = 3
+        s["%s.%d.weight" % (h, last)] = (classes, head_conv, 1, 1)
+        s["%s.%d.bias" % (h, last)] = (classes,)
+    return s
+
+
+def _gen(seed, name):
+    g = torch.Generator(device="cpu")
+    g.manual_seed((int(seed) * 1000003 + zlib.crc32(name.encode())) % (2 ** 63 - 1))
+    return g
+
+
+def _bilinear_up(shape):
+    """fill_up_weights, pose_dla_dcn.py:365-374"""
+    o, _, k, _ = shape
+    w = torch.zeros(shape)
+    f = math.ceil(k / 2)
+    c = (2 * f - 1 - f % 2) / (2.0 * f)
+    for i in range(k):
+        for j in range(k):
+            w[0, 0, i, j] = (1 - math.fabs(i / f - c)) * (1 - math.fabs(j / f - c))
+    w[1:, 0] = w[0, 0]
+    return w
+
+
+def load_scales(arch, tracking):
+    if not os.path.exists(_SCALES_PATH):
+        return {}
+    with open(_SCALES_PATH) as f:
+        allsc = json.load(f)
+    return allsc.get(config_key(arch, tracking), {})
+
+
+def make_state_dict(arch="dla_34", heads=None, tracking=False, seed=DEFAULT_SEED, scales=None,
+                    head_conv=256):
+    """Random weights in the reference's ``state_dict`` format (float32 CPU tensors)."""
+    spec = param_spec(arch, heads, tracking, head_conv)
+    if scales is None:
+        scales = load_scales(arch, tracking)
+    heads_ = heads or (HEADS_TRACK if tracking else HEADS_POSE)
+    last = 3 if arch.split("_")[0] == "dlav1" else 2
+    final_hm_bias = {"%s.%d.bias" % (h, last) for h in heads_ if "hm" in h}
+    sd = OrderedDict()
+    for name, shape in spec.items():
+        g = _gen(seed, name)
+        leaf = name.rsplit(".", 1)[1]
+        if leaf == "num_batches_tracked":
+            t = torch.zeros((), dtype=torch.long)
+        elif leaf == "running_mean":
+            t = torch.randn(shape, generator=g) * 0.1
+        elif leaf == "running_var":
+            t = torch.rand(shape, generator=g) * 0.4 + 0.8
+        elif len(shape) == 1 and leaf == "weight":  # BN / GN gamma
+            t = torch.rand(shape, generator=g) * 0.4 + 0.8
+        elif len(shape) == 1:  # biases (BN beta, conv bias)
+            if ".up_" in name:
+                raise AssertionError(name)
+            is_final = name in final_hm_bias
+            if is_final:
+                t = torch.full(shape, -2.19)  # pose_dla_dcn.py:509-510
+            else:
+                t = torch.randn(shape, generator=g) * 0.1
+        elif ".up_" in name:
+            t = _bilinear_up(shape) * (torch.rand(shape, generator=g) * 0.2 + 0.9)
+        else:  # conv weight, He-normal on fan_in
+            fan_in = shape[1] * shape[2] * shape[3]
+            t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+        if name in scales:
+            t = t * float(scales[name])
+        sd[name] = t.float() if t.dtype != torch.long else t
+    return sd
+
+
+def frames(batch, seed=DEFAULT_SEED, h=512, w=512, device="cpu"):
+    """[B,3,h,w] float32: uint8 uniform noise, BGR mean/std normalisation (base_detector.py:132)."""
+    g = _gen(seed, "frames")
+    u8 = torch.randint(0, 256, (batch, h, w, 3), generator=g, dtype=torch.uint8)
+    x = (u8.float() / 255.0 - torch.tensor(MEAN)) / torch.tensor(STD)
+    return x.permute(0, 3, 1, 2).contiguous().to(device)
