@@ -1,0 +1,82 @@
+// centerpose_amd — shared declarations for the HIP kernels (gfx950 / CDNA4 only).
+//
+// Activations are float32 NHWC ("pixel-major": all channels of one output pixel are
+// contiguous).  That is the MI355X-first layout choice for this path: the DCNv2 bilinear gather
+// and the implicit-GEMM loaders then read whole channel vectors (16 B per lane, 64-256 B per
+// pixel) instead of the reference's per-channel NCHW planes (dcn_v2_im2col_cuda.cu:125-195
+// touches 4 scattered floats per (channel, tap)).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CP_OK 0
+#define CP_ERR_INVALID (-1)
+#define CP_ERR_LAUNCH (-2)
+#define CP_ERR_ALLOC (-3)
+#define CP_ERR_STATE (-4)
+
+enum CpAct : int {
+    CP_ACT_NONE = 0,
+    CP_ACT_RELU = 1,
+    CP_ACT_SIGMOID = 2,       // all channels
+    CP_ACT_SIGMOID_FROM = 3,  // sigmoid on channels >= act_from (DCN mask logits), identity below
+};
+
+enum CpStore : int {
+    CP_STORE_NHWC = 0,  // out[(pixel) * ldo + coff + c]
+    CP_STORE_NCHW = 1,  // out[((b * Cout_total) + coff + c) * HoWo + p]   (reference head layout)
+};
+
+#define CP_MAX_SRC 4
+
+// One implicit-GEMM convolution:  out[m, n] = act( (sum_k A[m,k] * Wp[k,n]) * scale[n] + shift[n] + res[m,n] )
+//   m = output pixel (b, ho, wo);  k = (tap, ci) with ci fastest;  n = output channel.
+// A is read on the fly from up to CP_MAX_SRC NHWC sources that form a virtual channel concat
+// (Root's torch.cat, pose_dla_dcn.py:162), or — in DCN mode — produced by the modulated bilinear
+// gather of the reference's deformable im2col (dcn_v2_im2col_cuda.cu:125-195) without ever
+// materialising the `columns` buffer.
+struct ConvParams {
+    const float* src[CP_MAX_SRC];
+    int src_c[CP_MAX_SRC];  // channels per source (multiples of 4)
+    int nsrc;
+    int Cin;  // total input channels
+    int B, H, W, Ho, Wo;
+    int KH, KW, stride, pad;
+    int K;     // KH*KW*Cin (un-padded)
+    int Kpad;  // rows of wp (multiple of BK)
+    const float* wp;  // packed weights [Kpad][CoutPad]
+    int Cout, CoutPad;
+    const float* scale;  // [CoutPad] or nullptr (=1)
+    const float* shift;  // [CoutPad] or nullptr (=0)
+    const float* res;    // NHWC [M][res_ld] or nullptr
+    int res_ld;
+    int act;
+    int act_from;
+    float* out;
+    int store;       // CpStore
+    int ldo;         // NHWC: channel stride of out; NCHW: total channels of out tensor
+    int coff;        // channel offset inside out
+    const float* offmask;  // DCN mode: NHWC [B,H,W,32] = 18 offsets (dh,dw interleaved per tap) + 9 masks (already sigmoided) + 5 pad
+};
+
+int cp_launch_conv(const ConvParams& p, hipStream_t stream);
+// Tile N-width the launcher will pick for `cout` (weights must be padded to a multiple of it).
+int cp_conv_tile_n(int cout);
+
+// ---- element-wise / data-movement kernels (ewise.hip) ----
+int cp_launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int Cpad, hipStream_t s);
+int cp_launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, int ldi, hipStream_t s);
+int cp_launch_maxpool2(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
+// depth-wise ConvTranspose2d(k=2f, stride=f, pad=f/2) of `in` [B,H,W,C] plus `add` [B,fH,fW,C] -> out
+int cp_launch_upsample_add(const float* in, const float* w, const float* add, float* out, int B, int H, int W,
+                           int C, int f, hipStream_t s);
+int cp_launch_add_relu_sum(const float* a, const float* b, const float* c, const float* d, float* out, size_t n,
+                           hipStream_t s);
+// ConvGRU gates (convGRU.py:32-39).  x3/h3: [M,192] = (r,z,n) pre-activations, h: [M,64]
+int cp_launch_gru_gate(const float* x3, const float* h3, const float* hprev, float* hout, size_t M, hipStream_t s);
+// GroupNorm(32 groups) over NHWC [B, HW, C]: stats then in-place normalise + affine + ReLU
+int cp_launch_groupnorm_relu(float* x, const float* gamma, const float* beta, double* stats_ws, int B, int HW, int C,
+                             int groups, float eps, hipStream_t s);
+// PyTorch [Cout][Cin][taps] weights -> packed GEMM operand (buffer must be pre-zeroed for padding)
+int cp_launch_pack_weight(const float* w, float* wp, int Cout, int Cin, int taps, int CinP, int CoutPad, int coff,
+                          hipStream_t s);

@@ -1,0 +1,853 @@
+// DLA-34 (+DCNv2 up-sampling, optional ConvGRU + GroupNorm heads) inference engine and the C ABI
+// (include/centerpose_hip.h).  Host-side C++ only orchestrates: parameters are folded / packed once
+// at cp_model_finalize, the forward pass is a fixed sequence of HIP kernel launches on the caller's
+// stream out of a caller-provided workspace (deterministic arena, no allocation, no sync).
+//
+// Topology follows the reference modules (paths relative to /root/reference/src/lib/models/networks):
+//   DLA.forward pose_dla_dcn.py:310-322, Tree.forward :211-224, Root :160-168, BasicBlock :48-62,
+//   DLAUp :437-443, IDAUp :411-417, DeformConv :386-389 (DCN: DCNv2/dcn_v2.py:118-128),
+//   DLASeg.forward :523-570, ConvGRU convGRU.py:72-94, GroupNorm GN.py:4-9.
+#include "../../include/centerpose_hip.h"
+#undef CP_OK
+#undef CP_ERR_INVALID
+#undef CP_ERR_LAUNCH
+#undef CP_ERR_ALLOC
+#undef CP_ERR_STATE
+#include "cp_common.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// Deterministic first-fit arena over a caller-provided workspace.  A dry run (base == nullptr)
+// replays the same allocation sequence to measure the peak, so cp_model_workspace_bytes() and
+// cp_model_forward() always agree.
+// ---------------------------------------------------------------------------------------------
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, peak = 0;
+    bool overflow = false;
+    std::vector<std::pair<size_t, size_t>> free_;  // (offset, size), sorted by offset
+
+    void reset(void* b, size_t c) {
+        base = (char*)b;
+        cap = c;
+        peak = 0;
+        overflow = false;
+        free_.clear();
+        free_.push_back({0, (size_t)1 << 62});
+    }
+    size_t alloc(size_t bytes) {
+        bytes = align_up(bytes, 256);
+        for (size_t i = 0; i < free_.size(); ++i) {
+            if (free_[i].second >= bytes) {
+                const size_t off = free_[i].first;
+                free_[i].first += bytes;
+                free_[i].second -= bytes;
+                if (free_[i].second == 0) free_.erase(free_.begin() + i);
+                if (off + bytes > peak) peak = off + bytes;
+                if (base && off + bytes > cap) overflow = true;
+                return off;
+            }
+        }
+        overflow = true;
+        return 0;
+    }
+    void release(size_t off, size_t bytes) {
+        bytes = align_up(bytes, 256);
+        size_t i = 0;
+        while (i < free_.size() && free_[i].first < off) ++i;
+        free_.insert(free_.begin() + i, {off, bytes});
+        if (i + 1 < free_.size() && free_[i].first + free_[i].second == free_[i + 1].first) {
+            free_[i].second += free_[i + 1].second;
+            free_.erase(free_.begin() + i + 1);
+        }
+        if (i > 0 && free_[i - 1].first + free_[i - 1].second == free_[i].first) {
+            free_[i - 1].second += free_[i].second;
+            free_.erase(free_.begin() + i);
+        }
+    }
+};
+
+struct Block {
+    Arena* a;
+    size_t off, bytes;
+    Block(Arena* a_, size_t b) : a(a_), off(a_->alloc(b)), bytes(b) {}
+    ~Block() { a->release(off, bytes); }
+};
+
+// NHWC activation handle; memory returns to the arena when the last handle dies (the single stream
+// orders reuse after the last enqueued consumer).
+struct Tensor {
+    std::shared_ptr<Block> blk;
+    int C = 0, H = 0, W = 0;
+    float* ptr() const { return blk->a->base ? (float*)(blk->a->base + blk->off) : nullptr; }
+    bool valid() const { return (bool)blk; }
+};
+
+struct ConvW {
+    float* wp = nullptr;     // [Kpad][CoutPad]
+    float* scale = nullptr;  // [CoutPad] or nullptr
+    float* shift = nullptr;  // [CoutPad] or nullptr
+    int Cin = 0, CinP = 0, Cout = 0, CoutPad = 0, KH = 0, KW = 0, K = 0, Kpad = 0;
+};
+
+struct DeformW {
+    ConvW offset;  // conv_offset_mask (27 -> 32 padded), shift = bias
+    ConvW main;    // DCN weight, scale/shift = folded bias + BN
+};
+
+struct HeadW {
+    std::string name;
+    int classes = 0;
+    ConvW c0, c1;
+    float* gn_gamma = nullptr;
+    float* gn_beta = nullptr;
+};
+
+}  // namespace
+
+struct cp_model {
+    std::string arch;
+    bool gru = false, tracking = false, finalized = false;
+    int head_conv = 256;
+    std::vector<std::pair<std::string, int>> heads;
+    std::map<std::string, std::vector<float>> params;  // host copies until finalize
+    std::map<std::string, ConvW> convs;
+    std::map<std::string, DeformW> deforms;
+    std::map<std::string, float*> ups;
+    std::vector<HeadW> headw;
+    ConvW gru_x, gru_h;
+    std::vector<void*> device_allocs;
+    Arena arena;
+    // forward-call state
+    hipStream_t stream = nullptr;
+    int B = 0;
+    bool dry = false;
+    int status = CP_OK;
+    const char* tap_name = nullptr;
+    float* tap_out = nullptr;
+    int* tap_dims = nullptr;
+};
+
+namespace {
+
+// ------------------------------- parameter packing -------------------------------------------
+struct Packer {
+    cp_model* m;
+    int status = CP_OK;
+    std::string missing;
+
+    const std::vector<float>* get(const std::string& n, size_t numel) {
+        auto it = m->params.find(n);
+        if (it == m->params.end() || it->second.size() != numel) {
+            if (status == CP_OK) missing = n;
+            status = CP_ERR_STATE;
+            return nullptr;
+        }
+        return &it->second;
+    }
+    float* dev_alloc(size_t nfloat, bool zero = true) {
+        void* p = nullptr;
+        if (hipMalloc(&p, nfloat * sizeof(float)) != hipSuccess) {
+            status = CP_ERR_ALLOC;
+            return nullptr;
+        }
+        if (zero) hipMemset(p, 0, nfloat * sizeof(float));
+        m->device_allocs.push_back(p);
+        return (float*)p;
+    }
+    float* upload(const std::vector<float>& h) {
+        float* d = dev_alloc(h.size(), false);
+        if (d) hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+        return d;
+    }
+    // Pack several PyTorch-layout weights side by side along Cout (GRU gates) into one GEMM operand.
+    ConvW pack(const std::vector<std::string>& wnames, int cout_each, int cin, int kh, int kw, int cin_pad = 0) {
+        ConvW c;
+        c.Cin = cin;
+        c.CinP = cin_pad ? cin_pad : cin;
+        c.Cout = cout_each * (int)wnames.size();
+        c.CoutPad = (int)align_up(c.Cout, cp_conv_tile_n(c.Cout));
+        c.KH = kh;
+        c.KW = kw;
+        c.K = kh * kw * c.CinP;
+        c.Kpad = (int)align_up(c.K, 16);
+        c.wp = dev_alloc((size_t)c.Kpad * c.CoutPad);
+        if (!c.wp) return c;
+        for (size_t i = 0; i < wnames.size(); ++i) {
+            const auto* w = get(wnames[i], (size_t)cout_each * cin * kh * kw);
+            if (!w) return c;
+            float* tmp = nullptr;
+            if (hipMalloc((void**)&tmp, w->size() * sizeof(float)) != hipSuccess) {
+                status = CP_ERR_ALLOC;
+                return c;
+            }
+            hipMemcpy(tmp, w->data(), w->size() * sizeof(float), hipMemcpyHostToDevice);
+            int rc = cp_launch_pack_weight(tmp, c.wp, cout_each, cin, kh * kw, c.CinP, c.CoutPad, (int)i * cout_each,
+                                           nullptr);
+            hipDeviceSynchronize();
+            hipFree(tmp);
+            if (rc != CP_OK) status = rc;
+        }
+        return c;
+    }
+    // scale/shift vectors padded to CoutPad (scale pad = 1, shift pad = 0)
+    void set_affine(ConvW& c, const std::vector<float>* scale, const std::vector<float>& shift) {
+        std::vector<float> sh(c.CoutPad, 0.f);
+        for (size_t i = 0; i < shift.size(); ++i) sh[i] = shift[i];
+        c.shift = upload(sh);
+        if (scale) {
+            std::vector<float> sc(c.CoutPad, 1.f);
+            for (size_t i = 0; i < scale->size(); ++i) sc[i] = (*scale)[i];
+            c.scale = upload(sc);
+        }
+    }
+    // eval-mode BatchNorm folded to y = x*scale + shift; optional conv bias folded in as well
+    bool bn_fold(const std::string& bn, int c, const std::vector<float>* conv_bias, std::vector<float>& scale,
+                 std::vector<float>& shift) {
+        const auto* g = get(bn + ".weight", c);
+        const auto* b = get(bn + ".bias", c);
+        const auto* mu = get(bn + ".running_mean", c);
+        const auto* var = get(bn + ".running_var", c);
+        if (!g || !b || !mu || !var) return false;
+        scale.resize(c);
+        shift.resize(c);
+        for (int i = 0; i < c; ++i) {
+            const double s = (double)(*g)[i] / std::sqrt((double)(*var)[i] + 1e-5);
+            double t = (double)(*b)[i] - (double)(*mu)[i] * s;
+            if (conv_bias) t += (double)(*conv_bias)[i] * s;
+            scale[i] = (float)s;
+            shift[i] = (float)t;
+        }
+        return true;
+    }
+    void conv_bn(const std::string& key, const std::string& conv, const std::string& bn, int cout, int cin, int k,
+                 int cin_pad = 0) {
+        ConvW c = pack({conv + ".weight"}, cout, cin, k, k, cin_pad);
+        std::vector<float> sc, sh;
+        if (bn_fold(bn, cout, nullptr, sc, sh)) set_affine(c, &sc, sh);
+        m->convs[key] = c;
+    }
+    void block(const std::string& p, int cin, int cout) {
+        conv_bn(p + ".conv1", p + ".conv1", p + ".bn1", cout, cin, 3);
+        conv_bn(p + ".conv2", p + ".conv2", p + ".bn2", cout, cout, 3);
+    }
+    void tree(const std::string& p, int levels, int cin, int cout, bool level_root, int root_dim = 0) {
+        if (root_dim == 0) root_dim = 2 * cout;
+        if (level_root) root_dim += cin;
+        if (levels == 1) {
+            block(p + ".tree1", cin, cout);
+            block(p + ".tree2", cout, cout);
+            conv_bn(p + ".root", p + ".root.conv", p + ".root.bn", cout, root_dim, 1);
+            if (cin != cout) conv_bn(p + ".project", p + ".project.0", p + ".project.1", cout, cin, 1);
+        } else {
+            tree(p + ".tree1", levels - 1, cin, cout, false, 0);
+            tree(p + ".tree2", levels - 1, cout, cout, false, root_dim + cout);
+            // the outer project of a 2-level tree never influences the output (Tree.forward :214-217)
+        }
+    }
+    void deform(const std::string& p, int chi, int cho) {
+        DeformW d;
+        d.offset = pack({p + ".conv.conv_offset_mask.weight"}, 27, chi, 3, 3);
+        if (const auto* b = get(p + ".conv.conv_offset_mask.bias", 27)) set_affine(d.offset, nullptr, *b);
+        d.main = pack({p + ".conv.weight"}, cho, chi, 3, 3);
+        const auto* bias = get(p + ".conv.bias", cho);
+        std::vector<float> sc, sh;
+        if (bias && bn_fold(p + ".actf.0", cho, bias, sc, sh)) set_affine(d.main, &sc, sh);
+        m->deforms[p] = d;
+    }
+    void ida(const std::string& p, int o, const std::vector<int>& channels, const std::vector<int>& up_f) {
+        for (size_t i = 1; i < channels.size(); ++i) {
+            const std::string k = std::to_string(i);
+            deform(p + ".proj_" + k, channels[i], o);
+            deform(p + ".node_" + k, o, o);
+            const int f = up_f[i];
+            if (const auto* w = get(p + ".up_" + k + ".weight", (size_t)o * 4 * f * f)) m->ups[p + ".up_" + k] = upload(*w);
+        }
+    }
+    void run() {
+        conv_bn("base.base_layer", "base.base_layer.0", "base.base_layer.1", 16, 3, 7, 4);
+        if (m->tracking) {
+            conv_bn("base.pre_img_layer", "base.pre_img_layer.0", "base.pre_img_layer.1", 16, 3, 7, 4);
+            conv_bn("base.pre_hm_layer", "base.pre_hm_layer.0", "base.pre_hm_layer.1", 16, 1, 7, 4);
+            conv_bn("base.pre_hm_hp_layer", "base.pre_hm_hp_layer.0", "base.pre_hm_hp_layer.1", 16, 8, 7, 8);
+        }
+        conv_bn("base.level0", "base.level0.0", "base.level0.1", 16, 16, 3);
+        conv_bn("base.level1", "base.level1.0", "base.level1.1", 32, 16, 3);
+        tree("base.level2", 1, 32, 64, false);
+        tree("base.level3", 2, 64, 128, true);
+        tree("base.level4", 2, 128, 256, true);
+        tree("base.level5", 1, 256, 512, true);
+        ida("dla_up.ida_0", 256, {256, 512}, {1, 2});
+        ida("dla_up.ida_1", 128, {128, 256, 256}, {1, 2, 2});
+        ida("dla_up.ida_2", 64, {64, 128, 128, 128}, {1, 2, 2, 2});
+        ida("ida_up", 64, {64, 128, 256}, {1, 2, 4});
+        if (m->gru) {
+            const std::string c = "convGRU.cell0.";
+            m->gru_x = pack({c + "Wir.weight", c + "Wiz.weight", c + "Win.weight"}, 64, 64, 3, 3);
+            std::vector<float> b;
+            for (const char* g : {"Wir", "Wiz", "Win"}) {
+                const auto* v = get(c + g + ".bias", 64);
+                if (v) b.insert(b.end(), v->begin(), v->end());
+            }
+            if (b.size() == 192) set_affine(m->gru_x, nullptr, b);
+            m->gru_h = pack({c + "Whr.weight", c + "Whz.weight", c + "Whn.weight"}, 64, 64, 3, 3);
+        }
+        const int hc = m->head_conv;
+        for (auto& h : m->heads) {
+            HeadW hw;
+            hw.name = h.first;
+            hw.classes = h.second;
+            const std::string last = h.first + (m->gru ? ".3" : ".2");
+            hw.c0 = pack({h.first + ".0.weight"}, hc, 64, 3, 3);
+            if (const auto* b = get(h.first + ".0.bias", hc)) set_affine(hw.c0, nullptr, *b);
+            hw.c1 = pack({last + ".weight"}, h.second, hc, 1, 1);
+            if (const auto* b = get(last + ".bias", h.second)) set_affine(hw.c1, nullptr, *b);
+            if (m->gru) {
+                const auto* g = get(h.first + ".1.weight", hc);
+                const auto* be = get(h.first + ".1.bias", hc);
+                if (g && be) {
+                    hw.gn_gamma = upload(*g);
+                    hw.gn_beta = upload(*be);
+                }
+            }
+            m->headw.push_back(hw);
+        }
+    }
+};
+
+// ------------------------------------ forward -------------------------------------------------
+struct Fwd {
+    cp_model* m;
+    int B;
+    hipStream_t s;
+
+    void chk(int rc) {
+        if (rc != CP_OK && m->status == CP_OK) m->status = rc;
+    }
+    Tensor make(int C, int H, int W) {
+        Tensor t;
+        t.C = C;
+        t.H = H;
+        t.W = W;
+        t.blk = std::make_shared<Block>(&m->arena, (size_t)B * H * W * C * sizeof(float));
+        return t;
+    }
+    void tap(const char* name, const Tensor& t, int c_valid = 0) {
+        if (m->dry || !m->tap_name || std::strcmp(name, m->tap_name) != 0) return;
+        const int C = c_valid ? c_valid : t.C;
+        chk(cp_launch_nhwc_to_nchw(t.ptr(), m->tap_out, B, C, t.H, t.W, t.C, s));
+        if (m->tap_dims) {
+            m->tap_dims[0] = C;
+            m->tap_dims[1] = t.H;
+            m->tap_dims[2] = t.W;
+        }
+    }
+    void tap(const std::string& name, const Tensor& t, int c_valid = 0) { tap(name.c_str(), t, c_valid); }
+
+    // generic conv into a fresh NHWC tensor (or into user NCHW memory when out_nchw != nullptr)
+    Tensor conv(const ConvW& w, const std::vector<const Tensor*>& srcs, int stride, int pad, int act,
+                const Tensor* res = nullptr, const Tensor* offmask = nullptr, int act_from = 0,
+                float* out_nchw = nullptr, int out_ld = 0) {
+        const Tensor& x0 = *srcs[0];
+        ConvParams p;
+        std::memset(&p, 0, sizeof(p));
+        int cin = 0;
+        p.nsrc = (int)srcs.size();
+        for (int i = 0; i < p.nsrc; ++i) {
+            p.src[i] = srcs[i]->ptr();
+            p.src_c[i] = srcs[i]->C;
+            cin += srcs[i]->C;
+        }
+        if (cin != w.CinP) {
+            chk(fail(CP_ERR_INVALID, "conv: channel mismatch"));
+            return Tensor();
+        }
+        p.Cin = cin;
+        p.B = B;
+        p.H = x0.H;
+        p.W = x0.W;
+        p.Ho = (x0.H + 2 * pad - w.KH) / stride + 1;
+        p.Wo = (x0.W + 2 * pad - w.KW) / stride + 1;
+        p.KH = w.KH;
+        p.KW = w.KW;
+        p.stride = stride;
+        p.pad = pad;
+        p.K = w.K;
+        p.Kpad = w.Kpad;
+        p.wp = w.wp;
+        p.Cout = w.Cout;
+        p.CoutPad = w.CoutPad;
+        p.scale = w.scale;
+        p.shift = w.shift;
+        p.res = res ? res->ptr() : nullptr;
+        p.res_ld = res ? res->C : 0;
+        p.act = act;
+        p.act_from = act_from;
+        p.offmask = offmask ? offmask->ptr() : nullptr;
+        Tensor out;
+        if (out_nchw) {
+            p.out = out_nchw;
+            p.store = CP_STORE_NCHW;
+            p.ldo = out_ld;
+            p.coff = 0;
+        } else {
+            // offset/mask maps keep their padded width so the DCN loader can index [pixel*32 + c]
+            const int cstore = (act == CP_ACT_SIGMOID_FROM) ? w.CoutPad : w.Cout;
+            out = make(cstore, p.Ho, p.Wo);
+            p.out = out.ptr();
+            p.store = CP_STORE_NHWC;
+            p.ldo = cstore;
+            p.coff = 0;
+        }
+        if (!m->dry) chk(cp_launch_conv(p, s));
+        return out;
+    }
+    const ConvW& cw(const std::string& k) { return m->convs.at(k); }
+
+    Tensor maxpool(const Tensor& x) {
+        Tensor o = make(x.C, x.H / 2, x.W / 2);
+        if (!m->dry) chk(cp_launch_maxpool2(x.ptr(), o.ptr(), B, x.H, x.W, x.C, s));
+        return o;
+    }
+
+    Tensor basic_block(const std::string& p, const Tensor& x, int stride, const Tensor& residual) {
+        Tensor t = conv(cw(p + ".conv1"), {&x}, stride, 1, CP_ACT_RELU);
+        Tensor o = conv(cw(p + ".conv2"), {&t}, 1, 1, CP_ACT_RELU, &residual);
+        tap(p, o);
+        return o;
+    }
+
+    // one-level Tree (Tree.forward with levels == 1); `bottom` may be supplied by the caller when it
+    // already computed maxpool(x) (the outer two-level tree needs the same tensor as a root child)
+    Tensor tree1(const std::string& p, const Tensor& x, int cin, int cout, int stride, bool level_root,
+                 std::vector<const Tensor*> children, const Tensor* bottom_in = nullptr) {
+        Tensor bottom_own;
+        const Tensor* bottom = &x;
+        if (stride > 1) {
+            if (bottom_in) bottom = bottom_in;
+            else {
+                bottom_own = maxpool(x);
+                bottom = &bottom_own;
+            }
+        }
+        Tensor proj;
+        const Tensor* residual = bottom;
+        if (cin != cout) {
+            proj = conv(cw(p + ".project"), {bottom}, 1, 0, CP_ACT_NONE);
+            residual = &proj;
+        }
+        if (level_root) children.insert(children.begin(), bottom);
+        Tensor x1 = basic_block(p + ".tree1", x, stride, *residual);
+        proj = Tensor();
+        Tensor x2 = basic_block(p + ".tree2", x1, 1, x1);
+        std::vector<const Tensor*> srcs = {&x2, &x1};
+        for (auto* c : children) srcs.push_back(c);
+        Tensor o = conv(cw(p + ".root"), srcs, 1, 0, CP_ACT_RELU);
+        tap(p + ".root", o);
+        return o;
+    }
+    // two-level Tree with level_root = true (base.level3 / base.level4)
+    Tensor tree2(const std::string& p, const Tensor& x, int cin, int cout) {
+        Tensor bottom = maxpool(x);
+        Tensor x1 = tree1(p + ".tree1", x, cin, cout, 2, false, {}, &bottom);
+        return tree1(p + ".tree2", x1, cout, cout, 1, false, {&bottom, &x1});
+    }
+
+    Tensor deform(const std::string& p, const Tensor& x) {
+        const DeformW& d = m->deforms.at(p);
+        Tensor om = conv(d.offset, {&x}, 1, 1, CP_ACT_SIGMOID_FROM, nullptr, nullptr, 18);
+        Tensor o = conv(d.main, {&x}, 1, 1, CP_ACT_RELU, nullptr, &om);
+        tap(p, o);
+        return o;
+    }
+    Tensor upsample_add(const std::string& p, const Tensor& x, int f, const Tensor& add) {
+        Tensor o = make(x.C, x.H * f, x.W * f);
+        if (!m->dry) chk(cp_launch_upsample_add(x.ptr(), m->ups.at(p), add.ptr(), o.ptr(), B, x.H, x.W, x.C, f, s));
+        return o;
+    }
+    // IDAUp.forward: layers[i] = node(up(proj(layers[i])) + layers[i-1])
+    void ida(const std::string& p, std::vector<Tensor>& layers, int startp, int endp, const std::vector<int>& up_f) {
+        for (int i = startp + 1; i < endp; ++i) {
+            const std::string k = std::to_string(i - startp);
+            Tensor t = deform(p + ".proj_" + k, layers[i]);
+            Tensor u = upsample_add(p + ".up_" + k, t, up_f[i - startp], layers[i - 1]);
+            t = Tensor();
+            layers[i] = deform(p + ".node_" + k, u);
+        }
+    }
+
+    Tensor to_nhwc(const float* nchw, int C, int Cpad, int H, int W) {
+        Tensor t = make(Cpad, H, W);
+        if (!m->dry) chk(cp_launch_nchw_to_nhwc(nchw, t.ptr(), B, C, H, W, Cpad, s));
+        return t;
+    }
+
+    void run(int H, int W, const float* images, const float* pre_img, const float* pre_hm, const float* pre_hm_hp,
+             float* const* head_out, int sigmoid_hm) {
+        Tensor x0;
+        {
+            Tensor in = to_nhwc(images, 3, 4, H, W);
+            x0 = conv(cw("base.base_layer"), {&in}, 1, 3, CP_ACT_RELU);
+        }
+        if (m->tracking && (pre_img || pre_hm || pre_hm_hp)) {
+            Tensor a, b, c;
+            if (pre_img) {
+                Tensor in = to_nhwc(pre_img, 3, 4, H, W);
+                a = conv(cw("base.pre_img_layer"), {&in}, 1, 3, CP_ACT_RELU);
+            }
+            if (pre_hm) {
+                Tensor in = to_nhwc(pre_hm, 1, 4, H, W);
+                b = conv(cw("base.pre_hm_layer"), {&in}, 1, 3, CP_ACT_RELU);
+            }
+            if (pre_hm_hp) {
+                Tensor in = to_nhwc(pre_hm_hp, 8, 8, H, W);
+                c = conv(cw("base.pre_hm_hp_layer"), {&in}, 1, 3, CP_ACT_RELU);
+            }
+            // x = x + pre_img_layer(..) + pre_hm_layer(..) + pre_hm_hp_layer(..)  (left-to-right, :312-318)
+            std::vector<const Tensor*> adds;
+            for (Tensor* t : {&a, &b, &c})
+                if (t->valid()) adds.push_back(t);
+            Tensor sum = make(16, H, W);
+            if (!m->dry)
+                chk(cp_launch_add_relu_sum(x0.ptr(), adds[0]->ptr(), adds.size() > 1 ? adds[1]->ptr() : nullptr,
+                                           adds.size() > 2 ? adds[2]->ptr() : nullptr, sum.ptr(),
+                                           (size_t)B * H * W * 16, s));
+            x0 = sum;
+        }
+        tap("base.base_layer", x0);
+        Tensor l0 = conv(cw("base.level0"), {&x0}, 1, 1, CP_ACT_RELU);
+        tap("base.level0", l0);
+        x0 = Tensor();
+        Tensor l1 = conv(cw("base.level1"), {&l0}, 2, 1, CP_ACT_RELU);
+        tap("base.level1", l1);
+        l0 = Tensor();
+        std::vector<Tensor> L(6);
+        L[2] = tree1("base.level2", l1, 32, 64, 2, false, {});
+        l1 = Tensor();
+        L[3] = tree2("base.level3", L[2], 64, 128);
+        L[4] = tree2("base.level4", L[3], 128, 256);
+        L[5] = tree1("base.level5", L[4], 256, 512, 2, true, {});
+        tap("base.level2", L[2]);
+        tap("base.level3", L[3]);
+        tap("base.level4", L[4]);
+        tap("base.level5", L[5]);
+
+        // DLAUp.forward (:437-443): out = [after ida_2, after ida_1, after ida_0, L5]
+        ida("dla_up.ida_0", L, 4, 6, {1, 2});
+        Tensor o2 = L[5];  // 256 @ 1/8... (after ida_0: 256 ch at L4 resolution)
+        ida("dla_up.ida_1", L, 3, 6, {1, 2, 2});
+        Tensor o1 = L[5];
+        ida("dla_up.ida_2", L, 2, 6, {1, 2, 2, 2});
+        Tensor o0 = L[5];
+        for (auto& t : L) t = Tensor();
+        // DLASeg.forward (:531-536): ida_up over [o0, o1, o2]
+        std::vector<Tensor> y = {o0, o1, o2};
+        o0 = o1 = o2 = Tensor();
+        ida("ida_up", y, 0, 3, {1, 2, 4});
+        Tensor feat = y[2];
+        y.clear();
+        tap("feat", feat);
+
+        std::vector<Tensor> gru_out;
+        if (m->gru) {
+            const int steps = m->tracking ? 4 : 3;
+            Tensor x3 = conv(m->gru_x, {&feat}, 1, 1, CP_ACT_NONE);
+            Tensor h;
+            for (int st = 0; st < steps; ++st) {
+                Tensor hn = make(64, feat.H, feat.W);
+                const size_t M = (size_t)B * feat.H * feat.W;
+                if (st == 0) {
+                    // h0 = 0: the three hidden-side convolutions are identically zero (convGRU.py:51,80-84)
+                    if (!m->dry) chk(cp_launch_gru_gate(x3.ptr(), nullptr, nullptr, hn.ptr(), M, s));
+                } else {
+                    Tensor h3 = conv(m->gru_h, {&h}, 1, 1, CP_ACT_NONE);
+                    if (!m->dry) chk(cp_launch_gru_gate(x3.ptr(), h3.ptr(), h.ptr(), hn.ptr(), M, s));
+                }
+                h = hn;
+                gru_out.push_back(h);
+                tap(("convGRU.step" + std::to_string(st)).c_str(), h);
+            }
+        }
+
+        for (size_t i = 0; i < m->headw.size(); ++i) {
+            const HeadW& hw = m->headw[i];
+            const Tensor* src = &feat;
+            if (m->gru) {
+                int r = -1;
+                const std::string& n = hw.name;
+                if (m->tracking) {
+                    if (n == "tracking" || n == "tracking_hp") r = 0;
+                    else if (n == "hm" || n == "wh" || n == "reg") r = 1;
+                    else if (n == "hm_hp" || n == "hp_offset" || n == "hps" || n == "hps_uncertainty") r = 2;
+                    else if (n == "scale" || n == "scale_uncertainty") r = 3;
+                } else {
+                    if (n == "hm" || n == "wh" || n == "reg") r = 0;
+                    else if (n == "hm_hp" || n == "hp_offset" || n == "hps") r = 1;
+                    else if (n == "scale") r = 2;
+                }
+                if (r < 0) continue;  // the reference leaves such heads out of z (:545-563)
+                src = &gru_out[r];
+            }
+            Tensor hid = conv(hw.c0, {src}, 1, 1, m->gru ? CP_ACT_NONE : CP_ACT_RELU);
+            if (m->gru) {
+                // GroupNorm statistics: 32 groups x (sum, sumsq) doubles per image = 128 floats per image
+                Tensor stats = make(128, 1, 1);
+                if (!m->dry)
+                    chk(cp_launch_groupnorm_relu(hid.ptr(), hw.gn_gamma, hw.gn_beta, (double*)stats.ptr(), B,
+                                                 hid.H * hid.W, hid.C, 32, 1e-5f, s));
+            }
+            const bool sg = sigmoid_hm && (hw.name == "hm" || hw.name == "hm_hp");
+            conv(hw.c1, {&hid}, 1, 0, sg ? CP_ACT_SIGMOID : CP_ACT_NONE, nullptr, nullptr, 0,
+                 m->dry ? (float*)0x1000 : head_out[i], hw.classes);
+        }
+    }
+};
+
+int forward_impl(cp_model* m, hipStream_t stream, int B, int H, int W, const float* images, const float* pre_img,
+                 const float* pre_hm, const float* pre_hm_hp, float* const* head_out, int sigmoid_hm, void* ws,
+                 size_t ws_bytes, bool dry) {
+    if (!m || !m->finalized) return fail(CP_ERR_STATE, "model not finalized");
+    if (B < 1 || H % 32 || W % 32 || H < 32 || W < 32) return fail(CP_ERR_INVALID, "H and W must be multiples of 32");
+    m->arena.reset(dry ? nullptr : ws, ws_bytes);
+    m->dry = dry;
+    m->status = CP_OK;
+    Fwd f{m, B, stream};
+    f.run(H, W, images, pre_img, pre_hm, pre_hm_hp, head_out, sigmoid_hm);
+    if (!dry && m->arena.overflow) return fail(CP_ERR_INVALID, "workspace too small");
+    return m->status;
+}
+
+}  // namespace
+
+// ============================================ C ABI ==============================================
+extern "C" {
+
+const char* cp_version(void) { return "centerpose_hip 0.1.0 (gfx950, f32 MFMA)"; }
+const char* cp_last_error(void) { return g_err.c_str(); }
+
+int cp_model_create(const char* arch, int tracking_task, int num_heads, const char* const* head_names,
+                    const int* head_classes, int head_conv, cp_model** out) {
+    if (!arch || !out || num_heads < 1 || !head_names || !head_classes) return fail(CP_ERR_INVALID, "null argument");
+    std::string a(arch);
+    if (a != "dla_34" && a != "dlav1_34") return fail(CP_ERR_INVALID, "arch must be dla_34 or dlav1_34");
+    if (head_conv <= 0 || head_conv % 32 != 0) return fail(CP_ERR_INVALID, "head_conv must be a positive multiple of 32");
+    cp_model* m = new cp_model();
+    m->arch = a;
+    m->gru = (a == "dlav1_34");
+    m->tracking = tracking_task != 0;
+    m->head_conv = head_conv;
+    for (int i = 0; i < num_heads; ++i) m->heads.push_back({head_names[i], head_classes[i]});
+    *out = m;
+    return CP_OK;
+}
+
+int cp_model_set_param(cp_model* m, const char* name, const float* host_data, int64_t numel) {
+    if (!m || !name || !host_data || numel < 0) return fail(CP_ERR_INVALID, "null argument");
+    if (m->finalized) return fail(CP_ERR_STATE, "model already finalized");
+    m->params[name] = std::vector<float>(host_data, host_data + numel);
+    return CP_OK;
+}
+
+int cp_model_finalize(cp_model* m) {
+    if (!m) return fail(CP_ERR_INVALID, "null model");
+    if (m->finalized) return CP_OK;
+    Packer pk{m};
+    pk.run();
+    hipDeviceSynchronize();
+    if (pk.status != CP_OK) return fail(pk.status, "missing or mis-shaped parameter: " + pk.missing);
+    m->params.clear();
+    m->finalized = true;
+    return CP_OK;
+}
+
+void cp_model_destroy(cp_model* m) {
+    if (!m) return;
+    for (void* p : m->device_allocs) hipFree(p);
+    delete m;
+}
+
+size_t cp_model_workspace_bytes(cp_model* m, int B, int H, int W) {
+    if (forward_impl(m, nullptr, B, H, W, nullptr, (const float*)1, (const float*)1, (const float*)1, nullptr, 0,
+                     nullptr, 0, true) != CP_OK)
+        return 0;
+    return m->arena.peak;
+}
+
+int cp_model_forward(cp_model* m, cp_stream_t stream, int B, int H, int W, const float* images, const float* pre_img,
+                     const float* pre_hm, const float* pre_hm_hp, float* const* head_out, int sigmoid_hm,
+                     void* workspace, size_t workspace_bytes) {
+    if (!images || !head_out || !workspace) return fail(CP_ERR_INVALID, "null argument");
+    m->tap_name = nullptr;
+    return forward_impl(m, (hipStream_t)stream, B, H, W, images, pre_img, pre_hm, pre_hm_hp, head_out, sigmoid_hm,
+                        workspace, workspace_bytes, false);
+}
+
+int cp_model_forward_tap(cp_model* m, cp_stream_t stream, int B, int H, int W, const float* images,
+                         const float* pre_img, const float* pre_hm, const float* pre_hm_hp, float* const* head_out,
+                         int sigmoid_hm, void* workspace, size_t workspace_bytes, const char* tap_name, float* tap_out,
+                         int* tap_dims) {
+    if (!images || !head_out || !workspace) return fail(CP_ERR_INVALID, "null argument");
+    m->tap_name = tap_name;
+    m->tap_out = tap_out;
+    m->tap_dims = tap_dims;
+    int rc = forward_impl(m, (hipStream_t)stream, B, H, W, images, pre_img, pre_hm, pre_hm_hp, head_out, sigmoid_hm,
+                          workspace, workspace_bytes, false);
+    m->tap_name = nullptr;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+size_t cp_conv2d_workspace_bytes(int Cin, int Cout, int KH, int KW) {
+    const size_t kpad = align_up((size_t)KH * KW * Cin, 16);
+    const size_t cpad = align_up((size_t)Cout, cp_conv_tile_n(Cout));
+    return align_up(kpad * cpad * sizeof(float), 256);
+}
+
+int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const float* scale, const float* shift,
+                   const float* residual, float* out, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                   int stride, int pad, int act, void* workspace, size_t workspace_bytes) {
+    if (!x || !w || !out || !workspace) return fail(CP_ERR_INVALID, "null argument");
+    if (Cin % 4) return fail(CP_ERR_INVALID, "Cin must be a multiple of 4");
+    if (workspace_bytes < cp_conv2d_workspace_bytes(Cin, Cout, KH, KW)) return fail(CP_ERR_INVALID, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int bn = cp_conv_tile_n(Cout);
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.K = KH * KW * Cin;
+    p.Kpad = (int)align_up(p.K, 16);
+    p.CoutPad = (int)align_up(Cout, bn);
+    // scale/shift are read up to CoutPad: only allow un-padded Cout when they are given
+    if ((scale || shift) && p.CoutPad != Cout) return fail(CP_ERR_INVALID, "scale/shift need Cout % tile_n == 0");
+    float* wp = (float*)workspace;
+    if (hipMemsetAsync(wp, 0, (size_t)p.Kpad * p.CoutPad * sizeof(float), s) != hipSuccess) return CP_ERR_LAUNCH;
+    int rc = cp_launch_pack_weight(w, wp, Cout, Cin, KH * KW, Cin, p.CoutPad, 0, s);
+    if (rc != CP_OK) return rc;
+    p.src[0] = x;
+    p.src_c[0] = Cin;
+    p.nsrc = 1;
+    p.Cin = Cin;
+    p.B = B;
+    p.H = H;
+    p.W = W;
+    p.Ho = (H + 2 * pad - KH) / stride + 1;
+    p.Wo = (W + 2 * pad - KW) / stride + 1;
+    p.KH = KH;
+    p.KW = KW;
+    p.stride = stride;
+    p.pad = pad;
+    p.wp = wp;
+    p.Cout = Cout;
+    p.scale = scale;
+    p.shift = shift;
+    p.res = residual;
+    p.res_ld = Cout;
+    p.act = act;
+    p.out = out;
+    p.store = CP_STORE_NHWC;
+    p.ldo = Cout;
+    return cp_launch_conv(p, s);
+}
+
+// DCNv2 forward with the reference's NCHW layouts (see header).  Workspace layout:
+//   [x NHWC B*H*W*C][offmask NHWC B*H*W*32][y NHWC B*H*W*Co][packed weights][shift CoutPad]
+size_t cp_dcnv2_workspace_bytes(int B, int C, int H, int W, int Co) {
+    const size_t px = (size_t)B * H * W;
+    const size_t cpad = align_up((size_t)Co, cp_conv_tile_n(Co));
+    return align_up(px * C * 4, 256) + align_up(px * 32 * 4, 256) + align_up(px * Co * 4, 256) +
+           align_up((size_t)9 * C * cpad * 4, 256) + align_up(cpad * 4, 256);
+}
+
+}  // extern "C"
+
+namespace {
+__global__ void dcn_offmask_pack_kernel(const float* __restrict__ offset, const float* __restrict__ mask,
+                                        float* __restrict__ om, int B, int HW) {
+    // offset [B,18,HW], mask [B,9,HW] -> om [B,HW,32]
+    const size_t total = (size_t)B * HW * 32;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i & 31);
+        const size_t px = i >> 5;
+        const size_t b = px / HW, p = px - b * HW;
+        float v = 0.f;
+        if (c < 18) v = offset[(b * 18 + c) * HW + p];
+        else if (c < 27) v = mask[(b * 9 + (c - 18)) * HW + p];
+        om[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" int cp_dcnv2_forward(cp_stream_t stream, const float* input, const float* weight, const float* bias,
+                                const float* offset, const float* mask, float* output, int B, int C, int H, int W,
+                                int Co, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                                int deformable_group, void* workspace, size_t workspace_bytes) {
+    if (!input || !weight || !bias || !offset || !mask || !output || !workspace)
+        return fail(CP_ERR_INVALID, "null argument");
+    if (kh != 3 || kw != 3 || sh != 1 || sw != 1 || ph != 1 || pw != 1 || dh != 1 || dw != 1 || deformable_group != 1)
+        return fail(CP_ERR_INVALID, "only 3x3 / stride 1 / pad 1 / dilation 1 / deformable_group 1 is supported");
+    if (C % 16 != 0) return fail(CP_ERR_INVALID, "C must be a multiple of 16");
+    if (cp_conv_tile_n(Co) < 64) return fail(CP_ERR_INVALID, "Co must be > 32");
+    if (workspace_bytes < cp_dcnv2_workspace_bytes(B, C, H, W, Co)) return fail(CP_ERR_INVALID, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t px = (size_t)B * H * W;
+    const int cpad = (int)align_up((size_t)Co, cp_conv_tile_n(Co));
+    char* w8 = (char*)workspace;
+    float* x_nhwc = (float*)w8;
+    w8 += align_up(px * C * 4, 256);
+    float* om = (float*)w8;
+    w8 += align_up(px * 32 * 4, 256);
+    float* y_nhwc = (float*)w8;
+    w8 += align_up(px * Co * 4, 256);
+    float* wp = (float*)w8;
+    w8 += align_up((size_t)9 * C * cpad * 4, 256);
+    float* shift = (float*)w8;
+    int rc = cp_launch_nchw_to_nhwc(input, x_nhwc, B, C, H, W, C, s);
+    if (rc != CP_OK) return rc;
+    hipLaunchKernelGGL(dcn_offmask_pack_kernel, dim3(2048), dim3(256), 0, s, offset, mask, om, B, H * W);
+    if (hipMemsetAsync(wp, 0, (size_t)9 * C * cpad * 4, s) != hipSuccess) return CP_ERR_LAUNCH;
+    if (hipMemsetAsync(shift, 0, (size_t)cpad * 4, s) != hipSuccess) return CP_ERR_LAUNCH;
+    if (hipMemcpyAsync(shift, bias, (size_t)Co * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return CP_ERR_LAUNCH;
+    rc = cp_launch_pack_weight(weight, wp, Co, C, 9, C, cpad, 0, s);
+    if (rc != CP_OK) return rc;
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.src[0] = x_nhwc;
+    p.src_c[0] = C;
+    p.nsrc = 1;
+    p.Cin = C;
+    p.B = B;
+    p.H = p.Ho = H;
+    p.W = p.Wo = W;
+    p.KH = p.KW = 3;
+    p.stride = 1;
+    p.pad = 1;
+    p.K = p.Kpad = 9 * C;
+    p.wp = wp;
+    p.Cout = Co;
+    p.CoutPad = cpad;
+    p.shift = shift;
+    p.act = CP_ACT_NONE;
+    p.out = y_nhwc;
+    p.store = CP_STORE_NHWC;
+    p.ldo = Co;
+    p.offmask = om;
+    rc = cp_launch_conv(p, s);
+    if (rc != CP_OK) return rc;
+    return cp_launch_nhwc_to_nchw(y_nhwc, output, B, Co, H, W, Co, s);
+}

@@ -1,0 +1,284 @@
+// HBM-bound data-movement / element-wise kernels of the backbone (float32 NHWC, 16 B per lane).
+#include "cp_common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+inline int grid_for(size_t n, int cap = 256 * 16) {
+    size_t g = (n + TPB - 1) / TPB;
+    if (g > (size_t)cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// [B,C,H,W] -> [B,H,W,Cpad] (zero pad), used for the network inputs (image / pre_img / pre_hm / pre_hm_hp)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW,
+                                    int Cpad) {
+    const size_t total = (size_t)B * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / HW, p = i - b * HW;
+        const float* src = in + b * (size_t)C * HW + p;
+        float* dst = out + i * Cpad;
+        for (int c = 0; c < Cpad; ++c) dst[c] = c < C ? src[(size_t)c * HW] : 0.f;
+    }
+}
+
+// [B,H,W,ldi] (first C channels) -> [B,C,H,W]
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW,
+                                    int ldi) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i % HW, bc = i / HW;
+        const size_t c = bc % C, b = bc / C;
+        out[i] = in[(b * HW + p) * ldi + c];
+    }
+}
+
+__global__ void maxpool2_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C4) {
+    // in [B,H,W,C], out [B,H/2,W/2,C]; one float4 of channels per thread
+    const int Ho = H >> 1, Wo = W >> 1;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    const float4* in4 = reinterpret_cast<const float4*>(in);
+    float4* out4 = reinterpret_cast<float4*>(out);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t t = i / C4;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const size_t base = (((size_t)b * H + 2 * ho) * W + 2 * wo) * C4 + c;
+        const float4 a = in4[base], bb = in4[base + C4], cc = in4[base + (size_t)W * C4],
+                     d = in4[base + (size_t)W * C4 + C4];
+        float4 r;
+        r.x = fmaxf(fmaxf(a.x, bb.x), fmaxf(cc.x, d.x));
+        r.y = fmaxf(fmaxf(a.y, bb.y), fmaxf(cc.y, d.y));
+        r.z = fmaxf(fmaxf(a.z, bb.z), fmaxf(cc.z, d.z));
+        r.w = fmaxf(fmaxf(a.w, bb.w), fmaxf(cc.w, d.w));
+        out4[i] = r;
+    }
+}
+
+// Depth-wise ConvTranspose2d(C, C, k=2f, stride=f, padding=f/2, groups=C) + add (IDAUp.forward,
+// pose_dla_dcn.py:411-417).  out[y,x,c] = add[y,x,c] + sum_{ky,kx} in[(y+p-ky)/f, (x+p-kx)/f, c] * w[c,ky,kx]
+// over taps with (y+p-ky) % f == 0 and the source inside the image: exactly 2x2 taps per output pixel.
+// w is [C,1,k,k] exactly as in the checkpoint.
+__global__ void upsample_add_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                    const float* __restrict__ add, float* __restrict__ out, int B, int H, int W, int C,
+                                    int f) {
+    const int k = 2 * f, p = f / 2, Ho = H * f, Wo = W * f, C4 = C >> 2;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t t = i / C4;
+        const int x = (int)(t % Wo);
+        t /= Wo;
+        const int y = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float4 acc = add ? reinterpret_cast<const float4*>(add)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // ky ranges over { (y+p) % f, (y+p) % f + f }
+        const int ky0 = (y + p) % f, kx0 = (x + p) % f;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int ky = ky0 + a * f;
+            const int iy = (y + p - ky) / f;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int kx = kx0 + bb * f;
+                const int ix = (x + p - kx) / f;
+                if (ix < 0 || ix >= W) continue;
+                const float4 v = reinterpret_cast<const float4*>(in)[(((size_t)b * H + iy) * W + ix) * C4 + c4];
+                const float* wc = w + (size_t)(c4 * 4) * k * k + ky * k + kx;
+                s.x += v.x * wc[0];
+                s.y += v.y * wc[(size_t)k * k];
+                s.z += v.z * wc[(size_t)2 * k * k];
+                s.w += v.w * wc[(size_t)3 * k * k];
+            }
+        }
+        acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+        reinterpret_cast<float4*>(out)[i] = acc;
+    }
+}
+
+// out = a + b (+ c) (+ d)   (tracking stems: x = base + pre_img + pre_hm + pre_hm_hp, pose_dla_dcn.py:312-318)
+__global__ void add_n_kernel(const float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ c,
+                             const float4* __restrict__ d, float4* __restrict__ out, size_t n4) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 r = a[i];
+        const float4 y = b[i];
+        r.x += y.x; r.y += y.y; r.z += y.z; r.w += y.w;
+        if (c) { const float4 z = c[i]; r.x += z.x; r.y += z.y; r.z += z.z; r.w += z.w; }
+        if (d) { const float4 z = d[i]; r.x += z.x; r.y += z.y; r.z += z.z; r.w += z.w; }
+        out[i] = r;
+    }
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ConvGRUCell.forward (convGRU.py:32-39) given the two fused 64->192 convolutions:
+//   x3 = [Wir x + b_ir | Wiz x + b_iz | Win x + b_in],  h3 = [Whr h | Whz h | Whn h]  (h3 == nullptr at step 0: h = 0)
+//   r = sig(x3r + h3r); z = sig(x3z + h3z); n = tanh(x3n + r * h3n); h' = (1 - z) * n + z * h
+__global__ void gru_gate_kernel(const float* __restrict__ x3, const float* __restrict__ h3,
+                                const float* __restrict__ hprev, float* __restrict__ hout, size_t M) {
+    const size_t total = M * 16;  // 64 channels / 4
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i >> 4;
+        const int c = (int)(i & 15) * 4;
+        const float4 xr = *reinterpret_cast<const float4*>(x3 + m * 192 + c);
+        const float4 xz = *reinterpret_cast<const float4*>(x3 + m * 192 + 64 + c);
+        const float4 xn = *reinterpret_cast<const float4*>(x3 + m * 192 + 128 + c);
+        float4 hr = make_float4(0, 0, 0, 0), hz = hr, hn = hr, hp = hr;
+        if (h3) {
+            hr = *reinterpret_cast<const float4*>(h3 + m * 192 + c);
+            hz = *reinterpret_cast<const float4*>(h3 + m * 192 + 64 + c);
+            hn = *reinterpret_cast<const float4*>(h3 + m * 192 + 128 + c);
+            hp = *reinterpret_cast<const float4*>(hprev + m * 64 + c);
+        }
+        float4 o;
+#define CP_GRU(e)                                        \
+    {                                                    \
+        const float r = sigm(xr.e + hr.e);               \
+        const float z = sigm(xz.e + hz.e);               \
+        const float n = tanhf(xn.e + r * hn.e);          \
+        o.e = (1.f - z) * n + z * hp.e;                  \
+    }
+        CP_GRU(x) CP_GRU(y) CP_GRU(z) CP_GRU(w)
+#undef CP_GRU
+        *reinterpret_cast<float4*>(hout + m * 64 + c) = o;
+    }
+}
+
+// GroupNorm statistics: one workgroup per (b, slab of pixels); per-group sum / sum of squares in
+// double, combined with atomics into stats[b][g][2].
+__global__ void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW, int C, int groups,
+                                int slab) {
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * slab;
+    const int p1 = min(HW, p0 + slab);
+    const int cpg = C / groups;       // channels per group (8 for 256/32)
+    const int C4 = C >> 2;
+    // each thread owns one float4 column position c4 (fixed) and strides over pixels
+    const int c4 = threadIdx.x % C4;
+    const int prow = threadIdx.x / C4;
+    const int rows = blockDim.x / C4;
+    double s = 0.0, ss = 0.0;
+    for (int p = p0 + prow; p < p1; p += rows) {
+        const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * HW + p) * C + c4 * 4);
+        s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+        ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    // a float4 never straddles groups when cpg % 4 == 0
+    const int g = (c4 * 4) / cpg;
+    __shared__ double sh[2 * 64];
+    if (threadIdx.x < 2 * groups && threadIdx.x < 128) sh[threadIdx.x] = 0.0;
+    __syncthreads();
+    atomicAdd(&sh[2 * g], s);
+    atomicAdd(&sh[2 * g + 1], ss);
+    __syncthreads();
+    if (threadIdx.x < 2 * groups) atomicAdd(&stats[(size_t)b * groups * 2 + threadIdx.x], sh[threadIdx.x]);
+}
+
+__global__ void gn_apply_relu_kernel(float* __restrict__ x, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, const double* __restrict__ stats, int B, int HW,
+                                     int C, int groups, float eps) {
+    const int C4 = C >> 2, cpg = C / groups;
+    const size_t total = (size_t)B * HW * C4;
+    const double cnt = (double)HW * cpg;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const size_t b = i / ((size_t)HW * C4);
+        const int g = (c4 * 4) / cpg;
+        const double s = stats[(b * groups + g) * 2], ss = stats[(b * groups + g) * 2 + 1];
+        const double mean = s / cnt;
+        double var = ss / cnt - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float mu = (float)mean;
+        float4 v = reinterpret_cast<float4*>(x)[i];
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c4 * 4);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c4 * 4);
+        v.x = fmaxf((v.x - mu) * rstd * ga.x + be.x, 0.f);
+        v.y = fmaxf((v.y - mu) * rstd * ga.y + be.y, 0.f);
+        v.z = fmaxf((v.z - mu) * rstd * ga.z + be.z, 0.f);
+        v.w = fmaxf((v.w - mu) * rstd * ga.w + be.w, 0.f);
+        reinterpret_cast<float4*>(x)[i] = v;
+    }
+}
+
+// PyTorch conv weight [Cout][Cin][KH*KW] -> implicit-GEMM B matrix wp[(tap*CinP + ci) * CoutPad + coff + co]
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int taps,
+                                   int CinP, int CoutPad, int coff) {
+    const size_t total = (size_t)Cout * Cin * taps;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % taps);
+        const size_t r = i / taps;
+        const int ci = (int)(r % Cin), co = (int)(r / Cin);
+        wp[((size_t)t * CinP + ci) * CoutPad + coff + co] = w[i];
+    }
+}
+
+inline int check() { return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH; }
+
+}  // namespace
+
+int cp_launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int Cpad, hipStream_t s) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)B * H * W)), dim3(TPB), 0, s, in, out, B, C, H * W,
+                       Cpad);
+    return check();
+}
+
+int cp_launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, int ldi, hipStream_t s) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)B * C * H * W)), dim3(TPB), 0, s, in, out, B, C,
+                       H * W, ldi);
+    return check();
+}
+
+int cp_launch_maxpool2(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
+    if (C % 4 || H % 2 || W % 2) return CP_ERR_INVALID;
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for((size_t)B * (H / 2) * (W / 2) * (C / 4))), dim3(TPB), 0, s, in,
+                       out, B, H, W, C / 4);
+    return check();
+}
+
+int cp_launch_upsample_add(const float* in, const float* w, const float* add, float* out, int B, int H, int W, int C,
+                           int f, hipStream_t s) {
+    if (C % 4 || f < 2 || (f & 1)) return CP_ERR_INVALID;
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for((size_t)B * H * f * W * f * (C / 4))), dim3(TPB), 0, s, in,
+                       w, add, out, B, H, W, C, f);
+    return check();
+}
+
+int cp_launch_add_relu_sum(const float* a, const float* b, const float* c, const float* d, float* out, size_t n,
+                           hipStream_t s) {
+    if (n % 4) return CP_ERR_INVALID;
+    hipLaunchKernelGGL(add_n_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, s, (const float4*)a, (const float4*)b,
+                       (const float4*)c, (const float4*)d, (float4*)out, n / 4);
+    return check();
+}
+
+int cp_launch_gru_gate(const float* x3, const float* h3, const float* hprev, float* hout, size_t M, hipStream_t s) {
+    hipLaunchKernelGGL(gru_gate_kernel, dim3(grid_for(M * 16)), dim3(TPB), 0, s, x3, h3, hprev, hout, M);
+    return check();
+}
+
+int cp_launch_groupnorm_relu(float* x, const float* gamma, const float* beta, double* stats_ws, int B, int HW, int C,
+                             int groups, float eps, hipStream_t s) {
+    if (C % 4 || (C / groups) % 4 || groups > 64 || TPB % (C / 4)) return CP_ERR_INVALID;
+    if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * groups * B, s) != hipSuccess) return CP_ERR_LAUNCH;
+    const int slab = 512;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((HW + slab - 1) / slab, B), dim3(TPB), 0, s, x, stats_ws, HW, C, groups,
+                       slab);
+    hipLaunchKernelGGL(gn_apply_relu_kernel, dim3(grid_for((size_t)B * HW * (C / 4))), dim3(TPB), 0, s, x, gamma, beta,
+                       stats_ws, B, HW, C, groups, eps);
+    return check();
+}
+
+int cp_launch_pack_weight(const float* w, float* wp, int Cout, int Cin, int taps, int CinP, int CoutPad, int coff,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((size_t)Cout * Cin * taps)), dim3(TPB), 0, s, w, wp, Cout, Cin,
+                       taps, CinP, CoutPad, coff);
+    return check();
+}

@@ -1,0 +1,202 @@
+"""ctypes binding of libcenterpose_hip.so (C ABI: include/centerpose_hip.h).
+
+PyTorch-ROCm is only the tensor container / allocator / stream provider here: every call hands raw
+``data_ptr()`` device pointers and the current HIP stream to the library.  There is NO fallback:
+if the shared library is missing or a call fails, a ``RuntimeError`` is raised.
+"""
+import ctypes
+import os
+from collections import OrderedDict
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcenterpose_hip.so")
+
+_lib = None
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_size_t = ctypes.c_size_t
+c_char_p = ctypes.c_char_p
+
+
+def _sig(fn, restype, *argtypes):
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "centerpose_amd: %s not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C centerpose_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    _sig(L.cp_version, c_char_p)
+    _sig(L.cp_last_error, c_char_p)
+    _sig(L.cp_dcnv2_workspace_bytes, c_size_t, c_int, c_int, c_int, c_int, c_int)
+    _sig(L.cp_dcnv2_forward, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+         *([c_int] * 14), c_void_p, c_size_t)
+    _sig(L.cp_model_create, c_int, c_char_p, c_int, c_int, ctypes.POINTER(c_char_p), ctypes.POINTER(c_int), c_int,
+         ctypes.POINTER(c_void_p))
+    _sig(L.cp_model_set_param, c_int, c_void_p, c_char_p, c_void_p, ctypes.c_int64)
+    _sig(L.cp_model_finalize, c_int, c_void_p)
+    _sig(L.cp_model_destroy, None, c_void_p)
+    _sig(L.cp_model_workspace_bytes, c_size_t, c_void_p, c_int, c_int, c_int)
+    _sig(L.cp_model_forward, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+         ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t)
+    _sig(L.cp_model_forward_tap, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+         c_void_p, ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, c_char_p, c_void_p, ctypes.POINTER(c_int))
+    _sig(L.cp_conv2d_workspace_bytes, c_size_t, c_int, c_int, c_int, c_int)
+    _sig(L.cp_conv2d_nhwc, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+         *([c_int] * 10), c_void_p, c_size_t)
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    """Names every declaration in include/centerpose_hip.h must resolve to (used by CPU tests)."""
+    return ["cp_version", "cp_last_error", "cp_dcnv2_workspace_bytes", "cp_dcnv2_forward", "cp_model_create",
+            "cp_model_set_param", "cp_model_finalize", "cp_model_destroy", "cp_model_workspace_bytes",
+            "cp_model_forward", "cp_model_forward_tap", "cp_conv2d_workspace_bytes", "cp_conv2d_nhwc"]
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().cp_last_error().decode() if _lib is not None else ""
+        raise RuntimeError("centerpose_hip: %s failed with code %d (%s)" % (what, rc, msg))
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise RuntimeError("centerpose_hip: tensors must live on the HIP device (no CPU path)")
+    return t.contiguous().float()
+
+
+def dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, deformable_group):
+    """Same 14-argument signature as the reference's ``_ext.dcn_v2_forward`` (DCNv2/src/vision.cpp:5)."""
+    L = lib()
+    input, weight, bias, offset, mask = map(_dev, (input, weight, bias, offset, mask))
+    B, C, H, W = input.shape
+    Co = weight.shape[0]
+    out = torch.empty(B, Co, H, W, device=input.device, dtype=torch.float32)
+    nbytes = L.cp_dcnv2_workspace_bytes(B, C, H, W, Co)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=input.device)
+    rc = L.cp_dcnv2_forward(_stream(), _ptr(input), _ptr(weight), _ptr(bias), _ptr(offset), _ptr(mask), _ptr(out),
+                            B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, deformable_group, _ptr(ws), nbytes)
+    _check(rc, "cp_dcnv2_forward")
+    return out
+
+
+def conv2d_nhwc(x, w, scale=None, shift=None, residual=None, stride=1, pad=0, act=0):
+    """x [B,H,W,Cin] NHWC, w [Cout,Cin,KH,KW] -> [B,Ho,Wo,Cout] NHWC (unit-test entry of the igemm kernel)."""
+    L = lib()
+    x, w = _dev(x), _dev(w)
+    B, H, W, Cin = x.shape
+    Cout, _, KH, KW = w.shape
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    out = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
+    nbytes = L.cp_conv2d_workspace_bytes(Cin, Cout, KH, KW)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    scale = _dev(scale) if scale is not None else None
+    shift = _dev(shift) if shift is not None else None
+    residual = _dev(residual) if residual is not None else None
+    rc = L.cp_conv2d_nhwc(_stream(), _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
+                          B, H, W, Cin, Cout, KH, KW, stride, pad, act, _ptr(ws), nbytes)
+    _check(rc, "cp_conv2d_nhwc")
+    return out
+
+
+class HipModel(object):
+    """Device-resident DLA-34 / DLA-34+ConvGRU network built from a reference-format state dict."""
+
+    def __init__(self, arch, heads, state_dict, tracking_task=False, head_conv=256):
+        L = lib()
+        self.arch = arch
+        self.heads = OrderedDict(heads)
+        self.tracking_task = bool(tracking_task)
+        names = (c_char_p * len(self.heads))(*[k.encode() for k in self.heads])
+        classes = (c_int * len(self.heads))(*[int(v) for v in self.heads.values()])
+        h = c_void_p()
+        _check(L.cp_model_create(arch.encode(), int(self.tracking_task), len(self.heads), names, classes,
+                                 int(head_conv), ctypes.byref(h)), "cp_model_create")
+        self._h = h
+        for k, v in state_dict.items():
+            if k.startswith("module.") and not k.startswith("module_list"):
+                k = k[7:]  # lib/models/model.py:43-48
+            if not torch.is_floating_point(v):
+                continue  # num_batches_tracked
+            t = v.detach().cpu().contiguous().float()
+            _check(L.cp_model_set_param(h, k.encode(), c_void_p(t.data_ptr()), t.numel()), "cp_model_set_param")
+        _check(L.cp_model_finalize(h), "cp_model_finalize")
+        self._ws = None
+        self._ws_key = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and _lib is not None:
+                _lib.cp_model_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def workspace_bytes(self, B, H, W):
+        n = lib().cp_model_workspace_bytes(self._h, B, H, W)
+        if n == 0:
+            raise RuntimeError("cp_model_workspace_bytes failed: " + lib().cp_last_error().decode())
+        return n
+
+    def _workspace(self, B, H, W, device):
+        key = (B, H, W, str(device))
+        if self._ws_key != key:
+            self._ws = None
+            n = self.workspace_bytes(B, H, W)
+            self._ws = torch.empty(n, dtype=torch.uint8, device=device)
+            self._ws_key = key
+        return self._ws
+
+    def forward(self, images, pre_img=None, pre_hm=None, pre_hm_hp=None, sigmoid_hm=False, tap=None):
+        """images [B,3,H,W] on the HIP device -> OrderedDict head -> [B,classes,H/4,W/4].
+        With ``tap`` also returns the named intermediate activation as NCHW."""
+        L = lib()
+        images = _dev(images)
+        B, _, H, W = images.shape
+        pre_img = _dev(pre_img) if pre_img is not None else None
+        pre_hm = _dev(pre_hm) if pre_hm is not None else None
+        pre_hm_hp = _dev(pre_hm_hp) if pre_hm_hp is not None else None
+        outs = OrderedDict()
+        for k, c in self.heads.items():
+            outs[k] = torch.empty(B, c, H // 4, W // 4, device=images.device, dtype=torch.float32)
+        ptrs = (c_void_p * len(outs))(*[t.data_ptr() for t in outs.values()])
+        ws = self._workspace(B, H, W, images.device)
+        if tap is None:
+            rc = L.cp_model_forward(self._h, _stream(), B, H, W, _ptr(images), _ptr(pre_img), _ptr(pre_hm),
+                                    _ptr(pre_hm_hp), ptrs, int(bool(sigmoid_hm)), _ptr(ws), ws.numel())
+            _check(rc, "cp_model_forward")
+            return outs
+        tap_buf = torch.zeros(B * 512 * (H // 4) * (W // 4) if False else B * 16 * H * W, device=images.device,
+                              dtype=torch.float32)
+        dims = (c_int * 3)(0, 0, 0)
+        rc = L.cp_model_forward_tap(self._h, _stream(), B, H, W, _ptr(images), _ptr(pre_img), _ptr(pre_hm),
+                                    _ptr(pre_hm_hp), ptrs, int(bool(sigmoid_hm)), _ptr(ws), ws.numel(),
+                                    tap.encode(), _ptr(tap_buf), dims)
+        _check(rc, "cp_model_forward_tap")
+        C, h, w = dims[0], dims[1], dims[2]
+        if C == 0:
+            raise RuntimeError("unknown tap %r" % tap)
+        return outs, tap_buf[: B * C * h * w].view(B, C, h, w)
+
+    __call__ = forward

@@ -1,0 +1,102 @@
+/*
+ * centerpose_hip.h — C ABI of libcenterpose_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the CenterPose inference hot path.  Every entry point takes plain
+ * pointers and sizes (no torch / ATen types), returns 0 on success or a negative CP_ERR_* code
+ * (never prints-and-continues like the reference's launchers, dcn_v2_im2col_cuda.cu:346-350),
+ * launches on the caller's stream and never synchronises.  Unless stated otherwise pointers are
+ * DEVICE pointers to float32.  Paths below are relative to the reference tree
+ * (/root/reference/src/lib/...).
+ */
+#ifndef CENTERPOSE_HIP_H
+#define CENTERPOSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cp_stream_t; /* hipStream_t */
+typedef struct cp_model cp_model;
+
+#define CP_OK 0
+#define CP_ERR_INVALID (-1)
+#define CP_ERR_LAUNCH (-2)
+#define CP_ERR_ALLOC (-3)
+#define CP_ERR_STATE (-4)
+
+/* Library / device info.  cp_version() returns a static string. */
+const char* cp_version(void);
+const char* cp_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * DCNv2 forward — replaces `_ext.dcn_v2_forward`
+ *   models/networks/DCNv2/src/vision.cpp:5, dcn_v2.h:9-46, cuda/dcn_v2_cuda.cu:42-172 and its
+ *   raw-pointer launcher `modulated_deformable_im2col_cuda` (cuda/dcn_v2_im2col_cuda.h:67-79).
+ * Same tensor layouts as the reference (all contiguous NCHW float32):
+ *   input [B,C,H,W], weight [Co,C,kh,kw], bias [Co], offset [B,dg*2*kh*kw,Ho,Wo] ((dh,dw)
+ *   interleaved per tap), mask [B,dg*kh*kw,Ho,Wo], output [B,Co,Ho,Wo].
+ * Supported (what CenterPose uses, pose_dla_dcn.py:384): kh=kw=3, stride 1, pad 1, dilation 1,
+ * deformable_group 1, C % 16 == 0.  Anything else returns CP_ERR_INVALID.
+ * `workspace` must hold cp_dcnv2_workspace_bytes(...) bytes (NHWC staging + packed weights).
+ * ------------------------------------------------------------------------------------------ */
+size_t cp_dcnv2_workspace_bytes(int B, int C, int H, int W, int Co);
+int cp_dcnv2_forward(cp_stream_t stream, const float* input, const float* weight, const float* bias,
+                     const float* offset, const float* mask, float* output, int B, int C, int H, int W, int Co,
+                     int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int deformable_group,
+                     void* workspace, size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Backbone + heads — replaces `create_model` / `load_model` / `model(images, pre_images,
+ *   pre_hms, pre_hm_hp)[-1]`  (models/model.py:26-87, models/networks/pose_dla_dcn.py:457-570,
+ *   detectors/object_pose.py:135-138).
+ *
+ * arch: "dla_34" (DLA-34 + DCNv2 up-sampling) or "dlav1_34" (+ ConvGRU + GroupNorm heads).
+ * heads: names/classes in the order of `opt.heads` (opts.py:394-426).
+ * Parameters are fed one tensor at a time under the reference's state_dict names (HOST float32
+ * pointers; `module.` prefixes are the caller's business as in model.py:43-48); finalize folds
+ * eval-mode BatchNorm into per-channel scale/shift, re-packs every convolution as [tap][ci][co]
+ * and uploads.  Unknown names are ignored (CP_OK) like load_model's "Drop parameter" branch;
+ * finalize fails with CP_ERR_STATE if a required tensor is missing.
+ * ------------------------------------------------------------------------------------------ */
+int cp_model_create(const char* arch, int tracking_task, int num_heads, const char* const* head_names,
+                    const int* head_classes, int head_conv, cp_model** out);
+int cp_model_set_param(cp_model* m, const char* name, const float* host_data, int64_t numel);
+int cp_model_finalize(cp_model* m);
+void cp_model_destroy(cp_model* m);
+
+/* Bytes of device scratch needed by cp_model_forward for a batch of B images of H x W. */
+size_t cp_model_workspace_bytes(cp_model* m, int B, int H, int W);
+
+/* images [B,3,H,W] NCHW (H, W multiples of 32).  pre_img [B,3,H,W], pre_hm [B,1,H,W],
+ * pre_hm_hp [B,8,H,W] may each be NULL (pose_dla_dcn.py:312-318).  head_out[i] receives head i
+ * as [B,classes_i,H/4,W/4] NCHW — raw logits, except that with sigmoid_hm != 0 the 'hm' and
+ * 'hm_hp' heads are returned post-sigmoid (object_pose.py:136-138 fused into the epilogue). */
+int cp_model_forward(cp_model* m, cp_stream_t stream, int B, int H, int W, const float* images,
+                     const float* pre_img, const float* pre_hm, const float* pre_hm_hp, float* const* head_out,
+                     int sigmoid_hm, void* workspace, size_t workspace_bytes);
+
+/* Debug/parity aid: same as cp_model_forward but additionally copies the named intermediate
+ * activation (names follow the reference module paths, e.g. "base.level3", "dla_up.ida_2.node_3",
+ * "feat", "convGRU.step1") to tap_out as NCHW.  tap_dims receives {C,H,W}. */
+int cp_model_forward_tap(cp_model* m, cp_stream_t stream, int B, int H, int W, const float* images,
+                         const float* pre_img, const float* pre_hm, const float* pre_hm_hp, float* const* head_out,
+                         int sigmoid_hm, void* workspace, size_t workspace_bytes, const char* tap_name,
+                         float* tap_out, int* tap_dims);
+
+/* ------------------------------------------------------------------------------------------
+ * Generic NHWC convolution (exposed for unit tests of the implicit-GEMM kernel).
+ *   x [B,H,W,Cin] NHWC, w [Cout,Cin,KH,KW] (reference/PyTorch layout, DEVICE), scale/shift/
+ *   residual may be NULL.  out [B,Ho,Wo,Cout] NHWC.  act: 0 none, 1 relu, 2 sigmoid.
+ * ------------------------------------------------------------------------------------------ */
+size_t cp_conv2d_workspace_bytes(int Cin, int Cout, int KH, int KW);
+int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const float* scale, const float* shift,
+                   const float* residual, float* out, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                   int stride, int pad, int act, void* workspace, size_t workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CENTERPOSE_HIP_H */

@@ -1,0 +1,176 @@
+"""GPU diagnostic sweep (not a test): runs every kernel family against the CPU oracle and prints one
+line per case without stopping at the first mismatch.  Usage on the GPU box:
+    python tools/gpu_diag.py [--full]      (output is also what gpurun shows in its tail)
+"""
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, REPO)
+
+from centerpose_amd import hip, synth  # noqa: E402
+from oracle import backbone as ob  # noqa: E402
+from oracle import dcn as odcn  # noqa: E402
+
+dev = torch.device("cuda:0")
+results = []
+
+
+def report(name, got, ref, tol):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    err = (got - ref).abs().max().item() if got.numel() else 0.0
+    scale = ref.abs().max().item()
+    bad = not (err <= tol * max(1.0, scale)) or not torch.isfinite(got).all()
+    results.append((name, err, scale, bad))
+    print("%-58s err %.3e  ref_max %.3e  %s" % (name, err, scale, "FAIL" if bad else "ok"), flush=True)
+    return not bad
+
+
+def conv_case(B, H, W, Cin, Cout, k, stride, pad, act=0, res=False, affine=True, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bn = hip.lib().cp_conv2d_workspace_bytes  # noqa
+    tile = 16 if Cout <= 16 else 32 if Cout <= 32 else 128 if Cout % 128 == 0 else 64
+    affine = affine and (Cout % tile == 0)
+    sc = torch.rand(Cout, generator=g) + 0.5 if affine else None
+    sh = torch.randn(Cout, generator=g) if affine else None
+    y = F.conv2d(x, w, None, stride, pad)
+    if affine:
+        y = y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    r = None
+    if res:
+        r = torch.randn(y.shape, generator=g)
+        y = y + r
+    if act == 1:
+        y = F.relu(y)
+    elif act == 2:
+        y = torch.sigmoid(y)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    rg = r.permute(0, 2, 3, 1).contiguous().to(dev) if res else None
+    out = hip.conv2d_nhwc(xg, w.to(dev), sc.to(dev) if affine else None, sh.to(dev) if affine else None, rg,
+                          stride, pad, act)
+    torch.cuda.synchronize()
+    name = "conv B%d %dx%d %d->%d k%d s%d p%d act%d res%d aff%d" % (B, H, W, Cin, Cout, k, stride, pad, act, res, affine)
+    return report(name, out.permute(0, 3, 1, 2), y, 2e-5)
+
+
+def dcn_case(B, C, Co, H, W, off_std, seed=0, kat=None):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b = torch.randn(Co, generator=g)
+    off = torch.randn(B, 18, H, W, generator=g) * off_std
+    mask = torch.rand(B, 9, H, W, generator=g)
+    if kat == "zero_offset":  # check_zero_offset, DCNv2/testcpu.py:32-67 generalised: mask .5 -> 0.5*conv
+        off.zero_()
+        mask.fill_(0.5)
+    ref = odcn.dcn_v2_forward(x, w, b, off, mask, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    out = hip.dcn_v2_forward(x.to(dev), w.to(dev), b.to(dev), off.to(dev), mask.to(dev), 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    torch.cuda.synchronize()
+    ok = report("dcn B%d C%d->%d %dx%d off_std %.1f %s" % (B, C, Co, H, W, off_std, kat or ""), out, ref, 2e-5)
+    if kat == "zero_offset":
+        ref2 = 0.5 * F.conv2d(x, w, None, 1, 1) + b.view(1, -1, 1, 1)
+        report("   ... vs 0.5*conv2d+bias KAT", out, ref2, 2e-5)
+    return ok
+
+
+def backbone_case(arch, tracking, B, res, taps_on_fail=True, seed=11):
+    heads = synth.HEADS_TRACK if tracking else synth.HEADS_POSE
+    sd = synth.make_state_dict(arch, heads, tracking)
+    x = synth.frames(B, seed=seed, h=res, w=res)
+    kw = {}
+    if tracking:
+        kw = dict(pre_img=synth.frames(B, seed=seed + 1, h=res, w=res),
+                  pre_hm=torch.rand(B, 1, res, res, generator=synth._gen(seed, "pre_hm")) ** 8,
+                  pre_hm_hp=torch.rand(B, 8, res, res, generator=synth._gen(seed, "pre_hm_hp")) ** 8)
+    taps = {}
+    t0 = time.time()
+    zo = ob.dlaseg_forward(sd, x, heads, arch=arch.split("_")[0], tracking_task=tracking, taps=taps, **kw)
+    t_cpu = time.time() - t0
+    model = hip.HipModel(arch, heads, sd, tracking_task=tracking)
+    kwg = {k: v.to(dev) for k, v in kw.items()}
+    zg = model(x.to(dev), **kwg)
+    torch.cuda.synchronize()
+    ok = True
+    tag = "%s%s B%d %d" % (arch, "+trk" if tracking else "", B, res)
+    for k in zo:
+        ok &= report("backbone %s head %s" % (tag, k), zg[k], zo[k], 1e-3)
+    hm_ok = report("backbone %s sigmoid(hm)" % tag, torch.sigmoid(zg["hm"]), torch.sigmoid(zo["hm"]), 1e-3)
+    if (not ok or not hm_ok) and taps_on_fail:
+        for name in ["base.base_layer", "base.level0", "base.level1", "base.level2.tree1", "base.level2.tree2",
+                     "base.level2.root", "base.level3", "base.level4", "base.level5", "dla_up.ida_0.proj_1",
+                     "dla_up.ida_0.node_1", "dla_up.ida_1.node_2", "dla_up.ida_2.node_3", "ida_up.node_1", "feat",
+                     "convGRU.step0", "convGRU.step1", "convGRU.step2"]:
+            oname = {"base.level2": "base.level2.root", "base.level3": "base.level3.tree2.root",
+                     "base.level4": "base.level4.tree2.root", "base.level5": "base.level5.root"}.get(name, name)
+            if oname not in taps:
+                continue
+            _, t = model(x.to(dev), tap=name, **kwg)
+            torch.cuda.synchronize()
+            report("   tap %s" % name, t, taps[oname], 1e-4)
+    print("   (oracle CPU forward %.2fs)" % t_cpu)
+    return model, sd
+
+
+def timing(model, B, res=512, iters=5):
+    x = synth.frames(min(B, 4), seed=3, h=res, w=res).to(dev)
+    x = x.repeat((B + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:B].contiguous()
+    for _ in range(2):
+        model(x)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(iters):
+        model(x)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / iters
+    print("timing %s B%d %dx%d: %.2f ms/batch  %.1f img/s  (ws %.2f GB)" % (
+        model.arch, B, res, res, dt * 1e3, B / dt, model.workspace_bytes(B, res, res) / 2 ** 30), flush=True)
+
+
+def main():
+    full = "--full" in sys.argv
+    print(hip.lib().cp_version().decode(), torch.cuda.get_device_name(0), flush=True)
+    # --- implicit-GEMM conv: every tile config, strides, kernel sizes, ragged M, residual, acts ---
+    conv_case(1, 8, 8, 16, 16, 3, 1, 1)             # FRAG16 path, tiny (ragged M)
+    conv_case(2, 16, 16, 4, 16, 7, 1, 3, act=1)     # stem-like: Cin=4, K=196 -> padded K
+    conv_case(1, 32, 32, 16, 32, 3, 2, 1, act=1)    # BN=32, stride 2
+    conv_case(2, 16, 16, 32, 64, 3, 2, 1, act=1)    # BN=64 stride 2
+    conv_case(2, 16, 16, 64, 64, 3, 1, 1, act=1, res=True)
+    conv_case(1, 16, 16, 64, 128, 3, 1, 1, act=1, res=True)   # BN=128
+    conv_case(1, 8, 8, 128, 256, 1, 1, 0)           # 1x1
+    conv_case(3, 12, 20, 48, 64, 3, 1, 1, act=2)    # non-pow2 dims, sigmoid
+    conv_case(1, 16, 16, 64, 192, 3, 1, 1, affine=True)  # GRU-like N=192
+    conv_case(1, 16, 16, 64, 27, 3, 1, 1, affine=False)   # offset-conv-like N=27 (padded to 32)
+    conv_case(1, 16, 16, 256, 8, 1, 1, 0, affine=False)   # head-final-like N=8
+    conv_case(1, 20, 20, 32, 16, 3, 1, 1, act=1)    # ragged M with FRAG16
+    # --- DCNv2 ---
+    dcn_case(2, 16, 64, 4, 4, 0.0, kat="zero_offset")
+    dcn_case(2, 64, 64, 16, 16, 0.0, kat="zero_offset")
+    dcn_case(2, 64, 64, 16, 16, 2.0)
+    dcn_case(1, 128, 128, 16, 16, 2.0, seed=1)
+    dcn_case(1, 256, 128, 8, 8, 5.0, seed=2)       # large offsets: many out-of-image samples
+    dcn_case(1, 64, 64, 32, 48, 1.0, seed=3)
+    # --- full network vs oracle ---
+    m, _ = backbone_case("dla_34", False, 2, 128)
+    backbone_case("dlav1_34", False, 2, 128)
+    backbone_case("dla_34", True, 1, 128)
+    backbone_case("dlav1_34", True, 1, 128)
+    if full:
+        m, _ = backbone_case("dla_34", False, 1, 512)
+        m1, _ = backbone_case("dlav1_34", False, 1, 512)
+        for B in (1, 8, 32):
+            timing(m, B)
+        timing(m1, 32)
+    nbad = sum(1 for r in results if r[3])
+    print("SUMMARY: %d cases, %d FAIL" % (len(results), nbad))
+    return 1 if nbad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
