@@ -80,3 +80,25 @@ int cp_launch_groupnorm_relu(float* x, const float* gamma, const float* beta, do
 // PyTorch [Cout][Cin][taps] weights -> packed GEMM operand (buffer must be pre-zeroed for padding)
 int cp_launch_pack_weight(const float* w, float* wp, int Cout, int Cin, int taps, int CinP, int CoutPad, int coff,
                           hipStream_t s);
+
+// ---- decode (decode.hip) ----
+// detection record: 118 float32 per detection, J = 8 joints (field order of decode.py:347-361)
+#define CP_DET_BBOX 0
+#define CP_DET_SCORE 4
+#define CP_DET_KPS 5
+#define CP_DET_CLS 21
+#define CP_DET_SCALE 22
+#define CP_DET_SCALE_UNC 25
+#define CP_DET_TRACKING 28
+#define CP_DET_TRACKING_HP 30
+#define CP_DET_KPS_DISP_MEAN 46
+#define CP_DET_KPS_DISP_STD 62
+#define CP_DET_KPS_HM_MEAN 78
+#define CP_DET_KPS_HM_STD 94
+#define CP_DET_KPS_HM_HEIGHT 110
+#define CP_DET_STRIDE 118
+size_t cp_decode_ws_bytes(int B, int J, int K);
+int cp_launch_decode(hipStream_t s, int B, int J, int H, int W, float* hm, const float* hps, const float* wh,
+                     const float* hps_unc, const float* scale, const float* scale_unc, const float* reg, float* hm_hp,
+                     const float* hp_offset, const float* tracking, const float* tracking_hp, int K, int rep_mode,
+                     int fit_gaussian, float balance, int legacy_bool_mask, int apply_sigmoid, float* det, void* ws);

@@ -13,6 +13,7 @@
 #undef CP_ERR_LAUNCH
 #undef CP_ERR_ALLOC
 #undef CP_ERR_STATE
+#undef CP_DET_STRIDE
 #include "cp_common.h"
 
 #include <cmath>
@@ -763,6 +764,24 @@ int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const flo
     p.store = CP_STORE_NHWC;
     p.ldo = Cout;
     return cp_launch_conv(p, s);
+}
+
+size_t cp_decode_workspace_bytes(int B, int K) { return cp_decode_ws_bytes(B, 8, K); }
+
+int cp_decode(cp_stream_t stream, int B, int H, int W, float* hm, const float* hps, const float* wh,
+              const float* hps_uncertainty, const float* scale, const float* scale_uncertainty, const float* reg,
+              float* hm_hp, const float* hp_offset, const float* tracking, const float* tracking_hp, int K,
+              int rep_mode, int fit_gaussian, float balance, int legacy_bool_mask, int apply_sigmoid, float* det,
+              void* workspace, size_t workspace_bytes) {
+    if (!hm || !hps || !wh || !hm_hp || !det || !workspace)
+        return fail(CP_ERR_INVALID, "hm, hps, wh, hm_hp, det and workspace are required");
+    if (B < 1 || rep_mode < 0 || rep_mode > 4) return fail(CP_ERR_INVALID, "bad B / rep_mode");
+    if (workspace_bytes < cp_decode_workspace_bytes(B, K)) return fail(CP_ERR_INVALID, "workspace too small");
+    int rc = cp_launch_decode((hipStream_t)stream, B, 8, H, W, hm, hps, wh, hps_uncertainty, scale, scale_uncertainty,
+                              reg, hm_hp, hp_offset, tracking, tracking_hp, K, rep_mode, fit_gaussian, balance,
+                              legacy_bool_mask, apply_sigmoid, det, workspace);
+    if (rc != CP_OK) return fail(rc, "decode: unsupported shape (need K <= 128 <= H*W <= 16384) or launch failure");
+    return CP_OK;
 }
 
 // DCNv2 forward with the reference's NCHW layouts (see header).  Workspace layout:

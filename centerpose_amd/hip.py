@@ -54,6 +54,9 @@ def lib():
     _sig(L.cp_conv2d_workspace_bytes, c_size_t, c_int, c_int, c_int, c_int)
     _sig(L.cp_conv2d_nhwc, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
          *([c_int] * 10), c_void_p, c_size_t)
+    _sig(L.cp_decode_workspace_bytes, c_size_t, c_int, c_int)
+    _sig(L.cp_decode, c_int, c_void_p, c_int, c_int, c_int, *([c_void_p] * 11), c_int, c_int, c_int, ctypes.c_float,
+         c_int, c_int, c_void_p, c_void_p, c_size_t)
     _lib = L
     return L
 
@@ -62,7 +65,8 @@ def exported_symbols():
     """Names every declaration in include/centerpose_hip.h must resolve to (used by CPU tests)."""
     return ["cp_version", "cp_last_error", "cp_dcnv2_workspace_bytes", "cp_dcnv2_forward", "cp_model_create",
             "cp_model_set_param", "cp_model_finalize", "cp_model_destroy", "cp_model_workspace_bytes",
-            "cp_model_forward", "cp_model_forward_tap", "cp_conv2d_workspace_bytes", "cp_conv2d_nhwc"]
+            "cp_model_forward", "cp_model_forward_tap", "cp_conv2d_workspace_bytes", "cp_conv2d_nhwc",
+            "cp_decode_workspace_bytes", "cp_decode"]
 
 
 def _check(rc, what):
@@ -118,6 +122,42 @@ def conv2d_nhwc(x, w, scale=None, shift=None, residual=None, stride=1, pad=0, ac
                           B, H, W, Cin, Cout, KH, KW, stride, pad, act, _ptr(ws), nbytes)
     _check(rc, "cp_conv2d_nhwc")
     return out
+
+
+DET_FIELDS = OrderedDict([  # field -> (offset, width) inside a 118-float detection record (decode.py:347-361)
+    ("bboxes", (0, 4)), ("scores", (4, 1)), ("kps", (5, 16)), ("clses", (21, 1)), ("obj_scale", (22, 3)),
+    ("obj_scale_uncertainty", (25, 3)), ("tracking", (28, 2)), ("tracking_hp", (30, 16)),
+    ("kps_displacement_mean", (46, 16)), ("kps_displacement_std", (62, 16)), ("kps_heatmap_mean", (78, 16)),
+    ("kps_heatmap_std", (94, 16)), ("kps_heatmap_height", (110, 8))])
+DET_STRIDE = 118
+
+
+def decode_raw(hm, hps, wh, hm_hp, hps_uncertainty=None, scale=None, scale_uncertainty=None, reg=None,
+               hp_offset=None, tracking=None, tracking_hp=None, K=100, rep_mode=1, fit_gaussian=False,
+               balance=2.0, legacy_bool_mask=False, apply_sigmoid=False):
+    """Device decode -> det [B,K,118] (device tensor).  hm / hm_hp are modified in place when
+    apply_sigmoid is set.  Tensors must be contiguous float32 NCHW on the HIP device."""
+    L = lib()
+    for t in (hm, hps, wh, hm_hp):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+            raise RuntimeError("decode: required heads must be contiguous float32 device tensors")
+    opt = [None if t is None else _dev(t) for t in (hps_uncertainty, scale, scale_uncertainty, reg, hp_offset,
+                                                    tracking, tracking_hp)]
+    B, _, H, W = hm.shape
+    det = torch.empty(B, K, DET_STRIDE, device=hm.device, dtype=torch.float32)
+    n = L.cp_decode_workspace_bytes(B, K)
+    ws = torch.empty(n, dtype=torch.uint8, device=hm.device)
+    rc = L.cp_decode(_stream(), B, H, W, _ptr(hm), _ptr(hps), _ptr(wh), _ptr(opt[0]), _ptr(opt[1]), _ptr(opt[2]),
+                     _ptr(opt[3]), _ptr(hm_hp), _ptr(opt[4]), _ptr(opt[5]), _ptr(opt[6]), int(K), int(rep_mode),
+                     int(bool(fit_gaussian)), float(balance), int(bool(legacy_bool_mask)), int(bool(apply_sigmoid)),
+                     _ptr(det), _ptr(ws), n)
+    _check(rc, "cp_decode")
+    return det
+
+
+def split_detections(det):
+    """[B,K,118] -> dict of the 13 reference keys (views)."""
+    return OrderedDict((k, det[..., o:o + w]) for k, (o, w) in DET_FIELDS.items())
 
 
 class HipModel(object):

@@ -96,6 +96,38 @@ int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const flo
                    const float* residual, float* out, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                    int stride, int pad, int act, void* workspace, size_t workspace_bytes);
 
+/* ------------------------------------------------------------------------------------------
+ * Heat-map decode — replaces `object_pose_decode(..., Inference=True)` (models/decode.py:72-375,
+ *   models/utils.py:43-47; called from detectors/object_pose.py:154-161) including the 13
+ *   device->host copies and the per-point Python loop (decode.py:191-252).
+ * Inputs are the head tensors, NCHW float32 on the device, H x W = output grid (<= 16384 pixels),
+ * one category, 8 joints: hm [B,1,H,W], hps [B,16,H,W], wh [B,2,H,W], hm_hp [B,8,H,W] are
+ * required (the detector's Inference configuration); hps_uncertainty [B,16], scale [B,3],
+ * scale_uncertainty [B,3], reg [B,2], hp_offset [B,2], tracking [B,2], tracking_hp [B,16] may be
+ * NULL (decode.py:304-345 zero-fill / +0.5 rules).  hm and hm_hp must already be sigmoided unless
+ * apply_sigmoid != 0, in which case they hold logits and are overwritten with their sigmoid
+ * (object_pose.py:136-138).
+ *   K                 opt.K (<= 128)                      rep_mode   opt.rep_mode (0..4)
+ *   fit_gaussian      opt.tracking_task || opt.refined_Kalman || rep_mode == 2 (decode.py:222)
+ *   balance           opt.balance_coefficient[opt.c] (decode.py:309)
+ *   legacy_bool_mask  0: `mask_2 == 7` is the AND of its 7 conditions (torch <= 1.1, what the
+ *                     published models were used with); 1: reproduce torch >= 1.2, where the sum of
+ *                     bool tensors can never equal 7 and every kps_heatmap_* stays -10000.
+ * Output det [B,K,118]: bboxes[0:4] score[4] kps[5:21] cls[21] obj_scale[22:25]
+ *   obj_scale_uncertainty[25:28] tracking[28:30] tracking_hp[30:46] kps_displacement_mean[46:62]
+ *   kps_displacement_std[62:78] kps_heatmap_mean[78:94] kps_heatmap_std[94:110]
+ *   kps_heatmap_height[110:118]  — the 13 keys of decode.py:347-361, output-grid units.
+ * Ordering: (score desc, pixel index asc); torch.topk's order among exactly equal scores is
+ * implementation-defined, so parity is defined on distinct scores.
+ * ------------------------------------------------------------------------------------------ */
+#define CP_DET_STRIDE 118
+size_t cp_decode_workspace_bytes(int B, int K);
+int cp_decode(cp_stream_t stream, int B, int H, int W, float* hm, const float* hps, const float* wh,
+              const float* hps_uncertainty, const float* scale, const float* scale_uncertainty, const float* reg,
+              float* hm_hp, const float* hp_offset, const float* tracking, const float* tracking_hp, int K,
+              int rep_mode, int fit_gaussian, float balance, int legacy_bool_mask, int apply_sigmoid, float* det,
+              void* workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

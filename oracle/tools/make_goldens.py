@@ -1,0 +1,142 @@
+"""ORACLE tooling (build container only): generate tests/golden/* from the REFERENCE itself.
+
+Run:  python -m oracle.tools.make_goldens
+Every fixture below is an output of the reference's own code (imported from /root/reference via
+oracle/tools/ref_harness.py), on seeded inputs that the tests regenerate; the oracle restatements
+and the HIP path are both checked against them.
+
+  state_dict_keys.json      name -> shape of the reference ``create_model(...).state_dict()``
+  backbone_<cfg>.npz        reference ``model(x, pre_img, pre_hm, pre_hm_hp)[-1]`` at 128x128, B=1
+  dcn_ref.npz               reference CPU im2col + GEMM on a random-offset case + the reference's
+                            own known-answer test (DCNv2/testcpu.py:32-67, check_zero_offset)
+  decode_<cfg>.npz          reference ``object_pose_decode`` (Inference=True) on seeded heads:
+                            as imported under torch>=1.2 ("bool"), and with torch<=1.1 comparison
+                            semantics emulated at run time on the unmodified function ("uint8")
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from centerpose_amd import synth  # noqa: E402
+from oracle import decode as odec  # noqa: E402
+from oracle import dcn as odcn  # noqa: E402
+from oracle.tools import ref_harness as rh  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+CONFIGS = [("dla_34", False), ("dlav1_34", False), ("dla_34", True), ("dlav1_34", True)]
+BACKBONE_RES = 128
+BACKBONE_SEED = 11
+
+
+class U8Cmp(torch.Tensor):
+    """Tensor subclass whose comparison operators return uint8 like torch<=1.1 did, so the
+    unmodified reference decode evaluates ``mask_2 == 7`` (decode.py:183-188) as intended."""
+    _CMP = ("__gt__", "__lt__", "__ge__", "__le__", "__eq__", "__ne__", "gt", "lt", "ge", "le", "eq", "ne")
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        out = super().__torch_function__(func, types, args, kwargs or {})
+        if isinstance(out, torch.Tensor) and out.dtype == torch.bool and getattr(func, "__name__", "") in cls._CMP:
+            out = out.to(torch.uint8)
+        return out
+
+
+class DecodeOpt:
+    def __init__(self, tracking, rep_mode=1, K=100):
+        self.K = K
+        self.rep_mode = rep_mode
+        self.tracking_task = tracking
+        self.refined_Kalman = False
+        self.c = "cup"
+        self.balance_coefficient = {"cup": 2.0}  # opts.py:239-241 (all categories 2)
+
+
+def backbone_inputs(tracking, res=BACKBONE_RES, seed=BACKBONE_SEED, batch=1):
+    x = synth.frames(batch, seed=seed, h=res, w=res)
+    kw = {}
+    if tracking:
+        kw = dict(pre_img=synth.frames(batch, seed=seed + 1, h=res, w=res),
+                  pre_hm=torch.rand(batch, 1, res, res, generator=synth._gen(seed, "pre_hm")) ** 8,
+                  pre_hm_hp=torch.rand(batch, 8, res, res, generator=synth._gen(seed, "pre_hm_hp")) ** 8)
+    return x, kw
+
+
+def reference_decode_run(d, tracking, semantics, rep_mode=1):
+    ref_decode = rh.reference_decode()
+    t = {k: torch.from_numpy(v.copy()) for k, v in d.items()}
+    if semantics == "uint8":
+        t = {k: v.as_subclass(U8Cmp) for k, v in t.items()}
+    r = ref_decode(t["hm"], t["hps"], wh=t["wh"], kps_displacement_std=t.get("hps_uncertainty"),
+                   obj_scale=t["scale"], obj_scale_uncertainty=t.get("scale_uncertainty"), reg=t["reg"],
+                   hm_hp=t["hm_hp"], hp_offset=t["hp_offset"], tracking=t.get("tracking"),
+                   tracking_hp=t.get("tracking_hp"), opt=DecodeOpt(tracking, rep_mode), Inference=True)
+    return {k: np.asarray(v.detach().cpu().numpy()) for k, v in r.items()}
+
+
+def dcn_case(seed=5, B=2, C=16, Co=64, H=12, W=10):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b = torch.randn(Co, generator=g)
+    off = torch.randn(B, 18, H, W, generator=g) * 2.0
+    mask = torch.rand(B, 9, H, W, generator=g)
+    return x, w, b, off, mask
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    odcn.build()
+    keys = {}
+    for arch, tr in CONFIGS:
+        heads = synth.HEADS_TRACK if tr else synth.HEADS_POSE
+        cfg = synth.config_key(arch, tr)
+        model = rh.create_reference_model(arch, heads, tr)
+        keys[cfg] = {k: list(v.shape) for k, v in model.state_dict().items()}
+        sd = synth.make_state_dict(arch, heads, tr)
+        model.load_state_dict(sd, strict=True)
+        x, kw = backbone_inputs(tr)
+        with torch.no_grad():
+            z = model(x, kw.get("pre_img"), kw.get("pre_hm"), kw.get("pre_hm_hp"))[-1]
+        out = {k: v.numpy() for k, v in z.items()}
+        out["_weights_checksum"] = np.array([float(sum(v.double().sum() for v in sd.values() if v.is_floating_point()))])
+        np.savez_compressed(os.path.join(GOLD, "backbone_%s.npz" % cfg), **out)
+        print("backbone", cfg, {k: v.shape for k, v in out.items() if not k.startswith("_")})
+    with open(os.path.join(GOLD, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+
+    # DCN: reference im2col + GEMM, and the reference's own known-answer test
+    x, w, b, off, mask = dcn_case()
+    y = odcn.dcn_v2_forward(x, w, b, off, mask, 3, 3, 1, 1, 1, 1, 1, 1, 1, kind="reference")
+    # check_zero_offset (testcpu.py:32-67): N,C,H,W = 2,2,4,4; identity 3x3 weights; offset 0; mask 0.5
+    xi = torch.randn(2, 2, 4, 4, generator=torch.Generator().manual_seed(1))
+    wi = torch.zeros(2, 2, 3, 3)
+    wi[0, 0, 1, 1] = 1.0
+    wi[1, 1, 1, 1] = 1.0
+    yi = odcn.dcn_v2_forward(xi, wi, torch.zeros(2), torch.zeros(2, 18, 4, 4), torch.full((2, 9, 4, 4), 0.5),
+                             3, 3, 1, 1, 1, 1, 1, 1, 1, kind="reference")
+    assert float((yi * 2 - xi).abs().max()) < 1e-10, "reference KAT failed?!"
+    np.savez_compressed(os.path.join(GOLD, "dcn_ref.npz"), y=y.numpy(), kat_in=xi.numpy(), kat_out=yi.numpy())
+    print("dcn", tuple(y.shape))
+
+    for tr, sem, B in ((False, "bool", 2), (False, "uint8", 2), (True, "uint8", 1)):
+        d = odec.synth_heads(B, seed=317, tracking=tr)
+        r = reference_decode_run(d, tr, sem)
+        name = "decode_%s_%s.npz" % ("track" if tr else "pose", sem)
+        np.savez_compressed(os.path.join(GOLD, name), **r)
+        print(name, "valid heat-map kps frac %.3f" % float((r["kps_heatmap_mean"] != -10000).mean()))
+    # rep_mode 0 (plain CenterNet keypoints) under uint8 semantics
+    d = odec.synth_heads(1, seed=318)
+    r = reference_decode_run(d, False, "uint8", rep_mode=0)
+    np.savez_compressed(os.path.join(GOLD, "decode_pose_uint8_rep0.npz"), **r)
+    print("done ->", GOLD)
+
+
+if __name__ == "__main__":
+    main()

@@ -118,6 +118,32 @@ def backbone_case(arch, tracking, B, res, taps_on_fail=True, seed=11):
     return model, sd
 
 
+def decode_case(B, sem, tracking=False, seed=317, rep_mode=1, sparse=False):
+    from oracle import decode as odec
+    d = odec.synth_heads(B, seed=seed, tracking=tracking)
+    if sparse:  # fewer than K peaks: most of the map exactly zero -> ties at 0 fall back to index order
+        keep = (d["hm"] > 0.9)
+        d["hm"] = d["hm"] * keep
+        d["hm_hp"] = d["hm_hp"] * (d["hm_hp"] > 0.9)
+    o = odec.object_pose_decode(
+        d["hm"], d["hps"], wh=d["wh"], kps_displacement_std=d.get("hps_uncertainty"), obj_scale=d["scale"],
+        obj_scale_uncertainty=d.get("scale_uncertainty"), reg=d["reg"], hm_hp=d["hm_hp"], hp_offset=d["hp_offset"],
+        tracking=d.get("tracking"), tracking_hp=d.get("tracking_hp"), K=100, rep_mode=rep_mode,
+        tracking_task=tracking, mask_semantics=sem)
+    g = {k: torch.from_numpy(v).to(dev) for k, v in d.items()}
+    det = hip.decode_raw(g["hm"], g["hps"], g["wh"], g["hm_hp"], g.get("hps_uncertainty"), g["scale"],
+                         g.get("scale_uncertainty"), g["reg"], g["hp_offset"], g.get("tracking"), g.get("tracking_hp"),
+                         K=100, rep_mode=rep_mode, fit_gaussian=tracking, balance=2.0,
+                         legacy_bool_mask=(sem == "bool"))
+    torch.cuda.synchronize()
+    r = hip.split_detections(det.cpu())
+    tag = "decode B%d %s trk%d rep%d%s" % (B, sem, tracking, rep_mode, " sparse" if sparse else "")
+    for k in o:
+        tol = 2e-6 if k in ("kps_displacement_std", "obj_scale_uncertainty") or tracking else 0.0
+        exact = bool((r[k].numpy() == o[k]).all())
+        report("%s %s%s" % (tag, k, " [bit-exact]" if exact else ""), r[k], torch.from_numpy(o[k]), tol)
+
+
 def timing(model, B, res=512, iters=5):
     x = synth.frames(min(B, 4), seed=3, h=res, w=res).to(dev)
     x = x.repeat((B + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:B].contiguous()
@@ -156,6 +182,17 @@ def main():
     dcn_case(1, 128, 128, 16, 16, 2.0, seed=1)
     dcn_case(1, 256, 128, 8, 8, 5.0, seed=2)       # large offsets: many out-of-image samples
     dcn_case(1, 64, 64, 32, 48, 1.0, seed=3)
+    # --- decode vs oracle ---
+    decode_case(2, "uint8")
+    decode_case(1, "bool")
+    decode_case(1, "uint8", rep_mode=0, seed=318)
+    decode_case(1, "uint8", rep_mode=4, seed=319)
+    decode_case(1, "uint8", sparse=True, seed=320)
+    decode_case(1, "uint8", tracking=True)
+    if "--decode-only" in sys.argv:
+        nbad = sum(1 for r in results if r[3])
+        print("SUMMARY: %d cases, %d FAIL" % (len(results), nbad))
+        return 1 if nbad else 0
     # --- full network vs oracle ---
     m, _ = backbone_case("dla_34", False, 2, 128)
     backbone_case("dlav1_34", False, 2, 128)
