@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py — throughput of the CenterPose inference hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): dlav1_34 at
+512x512, batch 32 per GPU, synthetic random frames, seeded random-init weights of that architecture
+-> backbone forward (DLA-34 + DCNv2 up-sampling + ConvGRU + GroupNorm heads) -> sigmoid ->
+heat-map decode (NMS, top-100, gathers, keypoint association) on device.  `--workload full` runs
+configs[2] instead (dla_34, batch 64, backbone + decode + batched PnP).
+One "step" = one batch through that chain, inputs resident in HBM before the timed region.
+Images shard by batch across ranks (weak scaling, no data-path collective: the chain is per-image).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel (the f32-MFMA implicit-GEMM convolution): algorithmic FLOPs of its
+                launches inside the timed region / their HIP-event durations, vs the 157.3 TFLOP/s
+                dense f32 matrix peak of gfx950 (MI355X_MICROARCH.md)
+  cpu_baseline  the oracle (CPU restatement of the reference graph, oracle/) timed on this host's
+                cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from centerpose_amd import hip, synth  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, dense f32 matrix
+GFLOP_PER_IMG = {"dlav1_34": 106.85, "dla_34": 85.11}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="decode", choices=["decode", "full"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 / 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    return ap.parse_args()
+
+
+class Pipeline(object):
+    """frames -> heads -> detections [-> poses], all on device."""
+
+    def __init__(self, workload, batch, device, seed):
+        self.workload = workload
+        self.arch = "dlav1_34" if workload == "decode" else "dla_34"
+        self.heads = synth.HEADS_POSE
+        self.batch = batch
+        self.device = device
+        sd = synth.make_state_dict(self.arch, self.heads, False)
+        self.model = hip.HipModel(self.arch, self.heads, sd)
+        # distinct frames per batch slot (generated in chunks of 8 to bound host memory)
+        xs = [synth.frames(min(8, batch - i), seed=seed + i).to(device) for i in range(0, batch, 8)]
+        self.x = torch.cat(xs, 0).contiguous()
+        self.cam = torch.tensor([663.0287679036459, 663.0287679036459, 300.2775065104167, 395.00066121419275],
+                                dtype=torch.float64, device=device)  # demo.py:143-144
+
+    def step(self, x=None):
+        x = self.x if x is None else x
+        z = self.model(x, sigmoid_hm=True)
+        det = hip.decode_raw(z["hm"], z["hps"], z["wh"], z["hm_hp"], None, z["scale"], None, z["reg"],
+                             z["hp_offset"], None, None, K=100, rep_mode=1, fit_gaussian=False, balance=2.0)
+        if self.workload != "full":
+            return det
+        # PnP input assembly for rep_mode 1 (base_detector.py:558-566): per vertex (displacement, heat-map),
+        # output-grid -> input-image scale (x4); every detection above vis_thresh 0.3 (opts.py:68)
+        B, K = det.shape[0], det.shape[1]
+        keep = det[..., 4] > 0.3
+        d = det[keep]
+        disp = d[:, 46:62].reshape(-1, 8, 1, 2)
+        hmk = d[:, 78:94].reshape(-1, 8, 1, 2)
+        pts = torch.cat([disp, hmk], 2).reshape(-1, 16, 2)
+        pts = torch.where(pts == -10000, pts, pts * 4.0)
+        poses = hip.pnp_solve(pts, d[:, 22:25], self.cam.expand(pts.shape[0], 4))
+        return det, poses
+
+
+def cpu_baseline(workload, arch, budget_s=12.0, max_imgs=16):
+    """Oracle (CPU port of the reference graph) on a bounded sample of the same workload."""
+    from oracle import backbone as ob
+    from oracle import decode as odec
+
+    heads = synth.HEADS_POSE
+    sd = synth.make_state_dict(arch, heads, False)
+    cores = torch.get_num_threads()
+    n, t0 = 0, time.time()
+    while n < max_imgs and (time.time() - t0 < budget_s or n < 2):
+        x = synth.frames(1, seed=1000 + n)
+        z = ob.dlaseg_forward(sd, x, heads, arch=arch.split("_")[0])
+        hm = torch.sigmoid(z["hm"]).numpy()
+        hm_hp = torch.sigmoid(z["hm_hp"]).numpy()
+        odec.object_pose_decode(hm, z["hps"].numpy(), wh=z["wh"].numpy(), obj_scale=z["scale"].numpy(),
+                                reg=z["reg"].numpy(), hm_hp=hm_hp, hp_offset=z["hp_offset"].numpy(), K=100,
+                                rep_mode=1)
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(n / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d images of the same workload (oracle: %s forward with OpenMP im2col + torch CPU convs, "
+                      "numpy decode), %.1f s" % (n, arch, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    batch = args.batch or (32 if args.workload == "decode" else 64)
+    pipe = Pipeline(args.workload, batch, device, seed=317 + 1000 * rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pipe.step()
+    pipe.model.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    pipe.model.profile(False)
+    prof = pipe.model.profile_read()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * batch * args.steps / dt
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (largest share of event time inside the timed region) ----
+        roof = None
+        if prof:
+            name, r = max(prof.items(), key=lambda kv: kv[1]["ms"])
+            achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            total_ms = sum(v["ms"] for v in prof.values())
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": r["launches"] // args.steps,
+                    "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
+                    "flops_per_launch": r["flops"] / r["launches"],
+                    "share_of_conv_time": round(r["ms"] / total_ms, 4),
+                    "all_conv_kernels": {k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                             "ms_per_step": round(v["ms"] / args.steps, 3),
+                                             "launches_per_step": v["launches"] // args.steps}
+                                         for k, v in prof.items()},
+                    "conv_ms_per_step": round(total_ms / args.steps, 3)}
+            tr = os.path.join(REPO, "profiles", "pmc_traffic.json")
+            if os.path.exists(tr):
+                with open(tr) as f:
+                    roof["traffic"] = json.load(f).get(name)
+        lat = None
+        if not args.no_latency:
+            x1 = pipe.x[:1].contiguous()
+            for _ in range(3):
+                pipe.step(x1)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(30):
+                t1 = time.perf_counter()
+                pipe.step(x1)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            ts.sort()
+            lat = round(ts[len(ts) // 2], 3)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.workload, pipe.arch)
+        out = {
+            "metric": "images/sec at 512x512 DLA-34 (backbone + heat-map decode%s)" % (
+                " + PnP" if args.workload == "full" else ""),
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s 512x512 batch=%d/GPU, synthetic random frames, seeded random-init weights, "
+                                   "backbone + sigmoid + heat-map decode%s" % (
+                                       pipe.arch, batch, " + batched PnP" if args.workload == "full" else ""),
+                       "arch": pipe.arch, "global_batch": world * batch, "input": "512x512",
+                       "parallelism": "batch-shard x%d (no collective)" % world,
+                       "gflop_per_image": GFLOP_PER_IMG[pipe.arch]},
+            "p50_frame_ms_batch1": lat,
+            "whole_step_tflops": round(value * GFLOP_PER_IMG[pipe.arch] / 1e3 / world, 2),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

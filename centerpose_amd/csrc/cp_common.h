@@ -62,6 +62,9 @@ struct ConvParams {
 int cp_launch_conv(const ConvParams& p, hipStream_t stream);
 // Tile N-width the launcher will pick for `cout` (weights must be padded to a multiple of it).
 int cp_conv_tile_n(int cout);
+int cp_conv_variant(const ConvParams& p);
+const char* cp_conv_variant_name(int v);
+#define CP_NUM_CONV_VARIANTS 6
 
 // ---- element-wise / data-movement kernels (ewise.hip) ----
 int cp_launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int Cpad, hipStream_t s);
@@ -102,3 +105,9 @@ int cp_launch_decode(hipStream_t s, int B, int J, int H, int W, float* hm, const
                      const float* hps_unc, const float* scale, const float* scale_unc, const float* reg, float* hm_hp,
                      const float* hp_offset, const float* tracking, const float* tracking_hp, int K, int rep_mode,
                      int fit_gaussian, float balance, int legacy_bool_mask, int apply_sigmoid, float* det, void* ws);
+
+// ---- batched PnP (pnp.hip) ----
+#define CP_PNP_STRIDE 40
+size_t cp_pnp_ws_bytes(int N);
+int cp_launch_pnp(hipStream_t s, const float* pts, const float* scale, const double* cam, int N, int npts, double* out,
+                  void* ws);

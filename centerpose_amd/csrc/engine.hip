@@ -14,6 +14,7 @@
 #undef CP_ERR_ALLOC
 #undef CP_ERR_STATE
 #undef CP_DET_STRIDE
+#undef CP_PNP_STRIDE
 #include "cp_common.h"
 
 #include <cmath>
@@ -144,6 +145,25 @@ struct cp_model {
     const char* tap_name = nullptr;
     float* tap_out = nullptr;
     int* tap_dims = nullptr;
+    // optional per-launch profiling of the implicit-GEMM kernels (HIP events on the launch stream)
+    struct ProfRec {
+        int variant;
+        double flops, bytes;
+        hipEvent_t e0, e1;
+    };
+    bool profile = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> event_pool;
+    hipEvent_t get_event() {
+        if (!event_pool.empty()) {
+            hipEvent_t e = event_pool.back();
+            event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
 };
 
 namespace {
@@ -417,7 +437,27 @@ struct Fwd {
             p.ldo = cstore;
             p.coff = 0;
         }
-        if (!m->dry) chk(cp_launch_conv(p, s));
+        if (!m->dry) {
+            if (m->profile) {
+                cp_model::ProfRec r;
+                r.variant = cp_conv_variant(p);
+                const double M = (double)B * p.Ho * p.Wo;
+                const int cin_real = w.Cin;  // un-padded input channels
+                r.flops = 2.0 * M * w.Cout * (double)(w.KH * w.KW * cin_real);
+                // algorithmic bytes: input once + output once + weights (+ offsets/mask for DCN, + residual)
+                r.bytes = 4.0 * ((double)B * x0.H * x0.W * cin_real + M * w.Cout +
+                                 (double)w.KH * w.KW * cin_real * w.Cout + (offmask ? M * 27 : 0.0) +
+                                 (res ? M * w.Cout : 0.0));
+                r.e0 = m->get_event();
+                r.e1 = m->get_event();
+                (void)hipEventRecord(r.e0, s);
+                chk(cp_launch_conv(p, s));
+                (void)hipEventRecord(r.e1, s);
+                m->prof.push_back(r);
+            } else {
+                chk(cp_launch_conv(p, s));
+            }
+        }
         return out;
     }
     const ConvW& cw(const std::string& k) { return m->convs.at(k); }
@@ -678,8 +718,41 @@ int cp_model_finalize(cp_model* m) {
     return CP_OK;
 }
 
+int cp_model_profile(cp_model* m, int enable) {
+    if (!m) return fail(CP_ERR_INVALID, "null model");
+    m->profile = enable != 0;
+    return CP_OK;
+}
+
+// Drains the recorded launches (synchronises their events).  out[v*4 + {0,1,2,3}] = {launches, total ms,
+// total algorithmic FLOPs, total algorithmic bytes} for kernel variant v (names: cp_conv_variant_name).
+int cp_model_profile_read(cp_model* m, double* out, int num_variants) {
+    if (!m || !out || num_variants < CP_NUM_CONV_VARIANTS) return fail(CP_ERR_INVALID, "bad argument");
+    for (int i = 0; i < num_variants * 4; ++i) out[i] = 0.0;
+    for (auto& r : m->prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess)
+            return fail(CP_ERR_LAUNCH, "event timing failed");
+        out[r.variant * 4 + 0] += 1.0;
+        out[r.variant * 4 + 1] += ms;
+        out[r.variant * 4 + 2] += r.flops;
+        out[r.variant * 4 + 3] += r.bytes;
+        m->event_pool.push_back(r.e0);
+        m->event_pool.push_back(r.e1);
+    }
+    m->prof.clear();
+    return CP_OK;
+}
+
+const char* cp_kernel_variant_name(int v) { return cp_conv_variant_name(v); }
+
 void cp_model_destroy(cp_model* m) {
     if (!m) return;
+    for (auto& r : m->prof) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    for (auto e : m->event_pool) (void)hipEventDestroy(e);
     for (void* p : m->device_allocs) hipFree(p);
     delete m;
 }
@@ -764,6 +837,17 @@ int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const flo
     p.store = CP_STORE_NHWC;
     p.ldo = Cout;
     return cp_launch_conv(p, s);
+}
+
+size_t cp_pnp_workspace_bytes(int N) { return cp_pnp_ws_bytes(N); }
+
+int cp_pnp_solve(cp_stream_t stream, const float* pts, const float* scale, const double* cam, int N, int npts,
+                 double* out, void* workspace, size_t workspace_bytes) {
+    if (N == 0) return CP_OK;
+    if (!pts || !scale || !cam || !out || !workspace || N < 0) return fail(CP_ERR_INVALID, "null argument");
+    if (npts != 8 && npts != 16) return fail(CP_ERR_INVALID, "npts must be 8 or 16");
+    if (workspace_bytes < cp_pnp_ws_bytes(N)) return fail(CP_ERR_INVALID, "workspace too small");
+    return cp_launch_pnp((hipStream_t)stream, pts, scale, cam, N, npts, out, workspace);
 }
 
 size_t cp_decode_workspace_bytes(int B, int K) { return cp_decode_ws_bytes(B, 8, K); }

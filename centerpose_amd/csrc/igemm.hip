@@ -314,6 +314,20 @@ int cp_conv_tile_n(int cout) {
     return 64;
 }
 
+// 0..3: plain conv with N tile 16/32/64/128; 4..5: fused DCNv2 with N tile 64/128
+int cp_conv_variant(const ConvParams& p) {
+    const int bn = cp_conv_tile_n(p.Cout);
+    if (p.offmask) return bn == 128 ? 5 : 4;
+    return bn == 16 ? 0 : bn == 32 ? 1 : bn == 64 ? 2 : 3;
+}
+
+const char* cp_conv_variant_name(int v) {
+    static const char* names[6] = {"igemm_f32_16x16x4_m256n16", "igemm_f32_32x32x2_m256n32", "igemm_f32_32x32x2_m128n64",
+                                   "igemm_f32_32x32x2_m128n128", "dcn_igemm_f32_32x32x2_m128n64",
+                                   "dcn_igemm_f32_32x32x2_m128n128"};
+    return (v >= 0 && v < 6) ? names[v] : "?";
+}
+
 int cp_launch_conv(const ConvParams& p, hipStream_t stream) {
     if (p.nsrc < 1 || p.nsrc > CP_MAX_SRC || p.Cin % 4 != 0) return CP_ERR_INVALID;
     for (int s = 0; s < p.nsrc; ++s)

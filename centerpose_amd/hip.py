@@ -57,6 +57,11 @@ def lib():
     _sig(L.cp_decode_workspace_bytes, c_size_t, c_int, c_int)
     _sig(L.cp_decode, c_int, c_void_p, c_int, c_int, c_int, *([c_void_p] * 11), c_int, c_int, c_int, ctypes.c_float,
          c_int, c_int, c_void_p, c_void_p, c_size_t)
+    _sig(L.cp_model_profile, c_int, c_void_p, c_int)
+    _sig(L.cp_model_profile_read, c_int, c_void_p, ctypes.POINTER(ctypes.c_double), c_int)
+    _sig(L.cp_kernel_variant_name, c_char_p, c_int)
+    _sig(L.cp_pnp_workspace_bytes, c_size_t, c_int)
+    _sig(L.cp_pnp_solve, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t)
     _lib = L
     return L
 
@@ -66,7 +71,8 @@ def exported_symbols():
     return ["cp_version", "cp_last_error", "cp_dcnv2_workspace_bytes", "cp_dcnv2_forward", "cp_model_create",
             "cp_model_set_param", "cp_model_finalize", "cp_model_destroy", "cp_model_workspace_bytes",
             "cp_model_forward", "cp_model_forward_tap", "cp_conv2d_workspace_bytes", "cp_conv2d_nhwc",
-            "cp_decode_workspace_bytes", "cp_decode"]
+            "cp_decode_workspace_bytes", "cp_decode", "cp_pnp_workspace_bytes", "cp_pnp_solve", "cp_model_profile", "cp_model_profile_read",
+            "cp_kernel_variant_name"]
 
 
 def _check(rc, what):
@@ -160,6 +166,29 @@ def split_detections(det):
     return OrderedDict((k, det[..., o:o + w]) for k, (o, w) in DET_FIELDS.items())
 
 
+PNP_STRIDE = 40
+
+
+def pnp_solve(pts, scale, cam):
+    """Batched cuboid PnP.  pts [N,npts,2] float32 (npts 8 or 16), scale [N,3] float32, cam [N,4] float64
+    (fx, fy, cx, cy); all on the HIP device.  Returns out [N,40] float64 (layout: centerpose_hip.h)."""
+    L = lib()
+    if not (pts.is_cuda and scale.is_cuda and cam.is_cuda):
+        raise RuntimeError("pnp_solve: tensors must live on the HIP device (no CPU path)")
+    pts = pts.contiguous().float()
+    scale = scale.contiguous().float()
+    cam = cam.contiguous().double()
+    N, npts = pts.shape[0], pts.shape[1]
+    out = torch.zeros(N, PNP_STRIDE, device=pts.device, dtype=torch.float64)
+    if N == 0:
+        return out
+    n = L.cp_pnp_workspace_bytes(N)
+    ws = torch.empty(n, dtype=torch.uint8, device=pts.device)
+    _check(L.cp_pnp_solve(_stream(), _ptr(pts), _ptr(scale), _ptr(cam), N, npts, _ptr(out), _ptr(ws), n),
+           "cp_pnp_solve")
+    return out
+
+
 class HipModel(object):
     """Device-resident DLA-34 / DLA-34+ConvGRU network built from a reference-format state dict."""
 
@@ -192,6 +221,22 @@ class HipModel(object):
                 self._h = None
         except Exception:
             pass
+
+    def profile(self, enable=True):
+        """Arm / disarm per-launch HIP-event timing of the implicit-GEMM kernels."""
+        _check(lib().cp_model_profile(self._h, int(bool(enable))), "cp_model_profile")
+
+    def profile_read(self):
+        """-> {kernel name: dict(launches, ms, flops, bytes)} accumulated since the last read."""
+        nv = 6
+        buf = (ctypes.c_double * (nv * 4))()
+        _check(lib().cp_model_profile_read(self._h, buf, nv), "cp_model_profile_read")
+        out = OrderedDict()
+        for v in range(nv):
+            if buf[v * 4] > 0:
+                out[lib().cp_kernel_variant_name(v).decode()] = dict(
+                    launches=int(buf[v * 4]), ms=buf[v * 4 + 1], flops=buf[v * 4 + 2], bytes=buf[v * 4 + 3])
+        return out
 
     def workspace_bytes(self, B, H, W):
         n = lib().cp_model_workspace_bytes(self._h, B, H, W)

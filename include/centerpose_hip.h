@@ -86,6 +86,17 @@ int cp_model_forward_tap(cp_model* m, cp_stream_t stream, int B, int H, int W, c
                          int sigmoid_hm, void* workspace, size_t workspace_bytes, const char* tap_name,
                          float* tap_out, int* tap_dims);
 
+/* Per-launch timing of the implicit-GEMM kernels with HIP events recorded on the launch stream
+ * (replaces the reference's wall-clock `torch.cuda.synchronize()` fences, base_detector.py:466-498).
+ * cp_model_profile(m, 1) arms it; every conv / DCN launch of later forwards is bracketed by an event
+ * pair.  cp_model_profile_read drains them: out[v*4 + 0..3] = {launches, total milliseconds, total
+ * algorithmic FLOPs (2*M*Cout*KH*KW*Cin), total algorithmic bytes (input + output + weights
+ * [+ offsets/mask] [+ residual], float32)} per kernel variant v in [0, CP_NUM_KERNEL_VARIANTS). */
+#define CP_NUM_KERNEL_VARIANTS 6
+int cp_model_profile(cp_model* m, int enable);
+int cp_model_profile_read(cp_model* m, double* out, int num_variants);
+const char* cp_kernel_variant_name(int v);
+
 /* ------------------------------------------------------------------------------------------
  * Generic NHWC convolution (exposed for unit tests of the implicit-GEMM kernel).
  *   x [B,H,W,Cin] NHWC, w [Cout,Cin,KH,KW] (reference/PyTorch layout, DEVICE), scale/shift/
@@ -127,6 +138,30 @@ int cp_decode(cp_stream_t stream, int B, int H, int W, float* hm, const float* h
               float* hm_hp, const float* hp_offset, const float* tracking, const float* tracking_hp, int K,
               int rep_mode, int fit_gaussian, float balance, int legacy_bool_mask, int apply_sigmoid, float* det,
               void* workspace, size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched cuboid PnP — replaces the per-detection loop `pnp_shell` -> `CuboidPNPSolver.solve_pnp`
+ *   -> `cv2.solvePnPGeneric(SOLVEPNP_ITERATIVE)` + `cv2.projectPoints`
+ *   (utils/pnp/cuboid_pnp_shell.py:11-24, utils/pnp/cuboid_pnp_solver.py:141-239,
+ *   detectors/base_detector.py:547-654).
+ *   pts   [N, npts, 2] float32 image points, npts = 8 (rep_mode 0/3/4: `kps`) or 16 (rep_mode 1:
+ *         displacement/heat-map pairs interleaved per vertex, base_detector.py:558-566); a point
+ *         with x or y < -5000 is invalid (cuboid_pnp_solver.py:145)
+ *   scale [N, 3] float32 relative cuboid size (divided by its y component inside, shell :12)
+ *   cam   [N, 4] float64 (fx, fy, cx, cy) of each detection's image
+ *   out   [N, 40] float64:
+ *     [0] status: 1 solved, 2 solved but t_z < 0 (reference drops it, solver :207-220),
+ *                 -1 < 4 valid points, -2 4-5 valid points (reference switches to EPnP: not
+ *                 implemented), -3 planar model (homography branch: not implemented), 0 failure
+ *     [1:4] rvec  [4:7] tvec (OpenCV frame)  [7] RMS reprojection error
+ *     [8:24] the 8 cuboid vertices projected with (rvec, tvec), pixels
+ *     [24:28] quaternion xyzw (OpenCV frame)   [28:31] location, [31:35] quaternion xyzw in the
+ *     OpenGL frame the evaluation uses (solver :179-196)   [35] valid points  [36] LM iterations
+ * ------------------------------------------------------------------------------------------ */
+#define CP_PNP_STRIDE 40
+size_t cp_pnp_workspace_bytes(int N);
+int cp_pnp_solve(cp_stream_t stream, const float* pts, const float* scale, const double* cam, int N, int npts,
+                 double* out, void* workspace, size_t workspace_bytes);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,79 @@
+"""CPU tests (no GPU): the C-ABI library builds, loads and exports every symbol include/centerpose_hip.h
+declares; host-side helpers; the product refuses to run without a device (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import __graft_entry__ as ge
+from centerpose_amd import hip, synth
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def built():
+    ge.build()
+    return hip.lib()
+
+
+def test_library_exports_every_declared_symbol(built):
+    header = open(os.path.join(REPO, "include", "centerpose_hip.h")).read()
+    declared = set(re.findall(r"\b(cp_[a-z0-9_]+)\s*\(", header))
+    declared -= {"cp_stream_t"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(built, name), "missing export %s" % name
+    assert declared == set(hip.exported_symbols())
+    assert b"gfx950" in built.cp_version()
+
+
+def test_argument_validation_without_gpu(built):
+    import ctypes
+
+    h = ctypes.c_void_p()
+    names = (ctypes.c_char_p * 1)(b"hm")
+    classes = (ctypes.c_int * 1)(1)
+    assert built.cp_model_create(b"resnet_18", 0, 1, names, classes, 256, ctypes.byref(h)) == -1
+    assert b"arch" in built.cp_last_error()
+    assert built.cp_model_create(b"dla_34", 0, 1, names, classes, 100, ctypes.byref(h)) == -1
+    # sizes are pure host arithmetic
+    assert built.cp_decode_workspace_bytes(32, 100) >= 32 * 9 * 100 * 8
+    assert built.cp_pnp_workspace_bytes(10) >= 10 * 288 * 8
+    assert built.cp_conv2d_workspace_bytes(64, 64, 3, 3) == 576 * 64 * 4
+
+
+def test_no_cpu_fallback(built):
+    x = torch.zeros(1, 16, 4, 4)
+    with pytest.raises(RuntimeError):
+        hip.dcn_v2_forward(x, torch.zeros(64, 16, 3, 3), torch.zeros(64), torch.zeros(1, 18, 4, 4),
+                           torch.zeros(1, 9, 4, 4), 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError):
+        hip.decode_raw(torch.zeros(1, 1, 16, 16), torch.zeros(1, 16, 16, 16), torch.zeros(1, 2, 16, 16),
+                       torch.zeros(1, 8, 16, 16))
+
+
+def test_synth_weights_are_deterministic_and_calibrated():
+    a = synth.make_state_dict("dlav1_34")
+    b = synth.make_state_dict("dlav1_34")
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    assert float(a["hm.3.bias"][0]) == pytest.approx(-2.19)
+    assert synth.load_scales("dla_34", False), "synth_scales.json missing"
+    x = synth.frames(2, seed=1, h=32, w=32)
+    assert x.shape == (2, 3, 32, 32) and x.dtype == torch.float32
+    assert abs(float(x.mean())) < 0.5
+
+
+def test_detection_record_layout_matches_reference_keys():
+    keys = ["bboxes", "scores", "kps", "clses", "obj_scale", "obj_scale_uncertainty", "tracking", "tracking_hp",
+            "kps_displacement_mean", "kps_displacement_std", "kps_heatmap_mean", "kps_heatmap_std",
+            "kps_heatmap_height"]  # decode.py:347-361
+    assert list(hip.DET_FIELDS) == keys
+    off = 0
+    for k, (o, w) in hip.DET_FIELDS.items():
+        assert o == off
+        off += w
+    assert off == hip.DET_STRIDE == 118

@@ -144,6 +144,70 @@ def decode_case(B, sem, tracking=False, seed=317, rep_mode=1, sparse=False):
         report("%s %s%s" % (tag, k, " [bit-exact]" if exact else ""), r[k], torch.from_numpy(o[k]), tol)
 
 
+def pnp_case(N=256, noise=0.0, seed=0, npts=16, drop=0.0):
+    import numpy as np
+    from oracle import pnp as opnp
+    rng = np.random.RandomState(seed)
+    K = np.array([[663.0287679036459, 0, 300.2775065104167], [0, 663.0287679036459, 395.00066121419275], [0, 0, 1]])
+    pts = np.zeros((N, npts, 2), np.float32)
+    scale = np.zeros((N, 3), np.float32)
+    for i in range(N):
+        sc = np.array([rng.uniform(0.3, 3), rng.uniform(0.5, 2.0), rng.uniform(0.3, 3)])
+        V = opnp.cuboid_vertices(sc / sc[1])
+        q = rng.randn(4)
+        R = opnp.quat_xyzw_to_matrix(q / np.linalg.norm(q))
+        t = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(6.0, 12.0)])
+        uv = opnp.project_points(V, opnp.matrix_to_rodrigues(R), t, K)
+        p = np.repeat(uv, npts // 8, axis=0) + rng.randn(npts, 2) * noise
+        if drop > 0:
+            dead = rng.rand(npts) < drop
+            if npts == 16:
+                dead[0::2] = False  # displacement points are always present (rep_mode 1)
+            p[dead] = -10000
+        pts[i] = p
+        scale[i] = sc
+    cam = np.tile(np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]]), (N, 1))
+    t0 = time.time()
+    out = hip.pnp_solve(torch.from_numpy(pts).to(dev), torch.from_numpy(scale).to(dev), torch.from_numpy(cam).to(dev))
+    torch.cuda.synchronize()
+    t_gpu = time.time() - t0
+    out = out.cpu().numpy()
+    ref = np.zeros_like(out)
+    t0 = time.time()
+    for i in range(N):
+        try:
+            s = opnp.solve_cuboid_pnp(pts[i].astype(np.float64), scale[i].astype(np.float64), K, opencv_return=True)
+            s2 = opnp.solve_cuboid_pnp(pts[i].astype(np.float64), scale[i].astype(np.float64), K, opencv_return=False)
+        except NotImplementedError:
+            continue
+        if s is None:
+            continue
+        ref[i, 0] = 1
+        ref[i, 1:4] = s["rvec"]; ref[i, 4:7] = s["tvec"]; ref[i, 7] = s["reproj_err"]
+        ref[i, 8:24] = s["projected_points"].reshape(-1)
+        ref[i, 24:28] = s["quaternion_xyzw"]; ref[i, 28:31] = s2["location"]; ref[i, 31:35] = s2["quaternion_xyzw"]
+    t_cpu = time.time() - t0
+    okm = ref[:, 0] == 1
+    tag = "pnp N%d npts%d noise %.1f drop %.1f" % (N, npts, noise, drop)
+    report(tag + " status", torch.from_numpy((out[:, 0] == 1).astype(np.float32)), torch.from_numpy(okm.astype(np.float32)), 0)
+    # rotation geodesic (deg) and relative translation error vs the float64 oracle
+    ang = np.zeros(N)
+    for i in np.where(okm)[0]:
+        Ra = opnp.rodrigues_to_matrix(out[i, 1:4]); Rb = opnp.rodrigues_to_matrix(ref[i, 1:4])
+        ang[i] = np.degrees(np.arccos(np.clip((np.trace(Ra.T @ Rb) - 1) / 2, -1, 1)))
+    report(tag + " rot geodesic deg (tol 1e-3)", torch.from_numpy(ang), torch.zeros(N, dtype=torch.float64), 1e-3)
+    rel_t = np.linalg.norm(out[okm, 4:7] - ref[okm, 4:7], axis=1) / np.linalg.norm(ref[okm, 4:7], axis=1)
+    report(tag + " rel |dt| (tol 1e-5)", torch.from_numpy(rel_t), torch.zeros(len(rel_t), dtype=torch.float64), 1e-5)
+    report(tag + " projected px", torch.from_numpy(out[okm, 8:24]), torch.from_numpy(ref[okm, 8:24]), 1e-6)
+    qs = np.sign(np.sum(out[okm, 24:28] * ref[okm, 24:28], axis=1, keepdims=True))
+    report(tag + " quat cv", torch.from_numpy(out[okm, 24:28] * qs), torch.from_numpy(ref[okm, 24:28]), 1e-6)
+    report(tag + " loc gl", torch.from_numpy(out[okm, 28:31]), torch.from_numpy(ref[okm, 28:31]), 1e-5)
+    qs = np.sign(np.sum(out[okm, 31:35] * ref[okm, 31:35], axis=1, keepdims=True))
+    report(tag + " quat gl", torch.from_numpy(out[okm, 31:35] * qs), torch.from_numpy(ref[okm, 31:35]), 1e-6)
+    print("   gpu %.2f ms (first call, incl. launch)  oracle %.1f ms  LM iters mean %.1f max %d" % (
+        t_gpu * 1e3, t_cpu * 1e3, out[okm, 36].mean(), out[okm, 36].max()))
+
+
 def timing(model, B, res=512, iters=5):
     x = synth.frames(min(B, 4), seed=3, h=res, w=res).to(dev)
     x = x.repeat((B + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:B].contiguous()
@@ -182,6 +246,15 @@ def main():
     dcn_case(1, 128, 128, 16, 16, 2.0, seed=1)
     dcn_case(1, 256, 128, 8, 8, 5.0, seed=2)       # large offsets: many out-of-image samples
     dcn_case(1, 64, 64, 32, 48, 1.0, seed=3)
+    if "--pnp-only" in sys.argv:
+        pnp_case(256, 0.0)
+        pnp_case(256, 1.0, seed=1)
+        pnp_case(256, 1.0, seed=2, drop=0.3)
+        pnp_case(128, 0.5, seed=3, npts=8)
+        pnp_case(4096, 1.0, seed=4)
+        nbad = sum(1 for r in results if r[3])
+        print("SUMMARY: %d cases, %d FAIL" % (len(results), nbad))
+        return 1 if nbad else 0
     # --- decode vs oracle ---
     decode_case(2, "uint8")
     decode_case(1, "bool")
