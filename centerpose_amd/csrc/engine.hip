@@ -19,6 +19,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -149,6 +150,7 @@ struct cp_model {
     struct ProfRec {
         int variant;
         double flops, bytes;
+        int M, N, K, kh, stride;
         hipEvent_t e0, e1;
     };
     bool profile = false;
@@ -448,6 +450,7 @@ struct Fwd {
                 r.bytes = 4.0 * ((double)B * x0.H * x0.W * cin_real + M * w.Cout +
                                  (double)w.KH * w.KW * cin_real * w.Cout + (offmask ? M * 27 : 0.0) +
                                  (res ? M * w.Cout : 0.0));
+                r.M = (int)M; r.N = w.Cout; r.K = w.KH * w.KW * cin_real; r.kh = w.KH; r.stride = stride;
                 r.e0 = m->get_event();
                 r.e1 = m->get_event();
                 (void)hipEventRecord(r.e0, s);
@@ -729,10 +732,15 @@ int cp_model_profile(cp_model* m, int enable) {
 int cp_model_profile_read(cp_model* m, double* out, int num_variants) {
     if (!m || !out || num_variants < CP_NUM_CONV_VARIANTS) return fail(CP_ERR_INVALID, "bad argument");
     for (int i = 0; i < num_variants * 4; ++i) out[i] = 0.0;
+    const char* dump = getenv("CP_PROFILE_DUMP");  // optional per-launch CSV for kernel tuning
+    FILE* df = dump ? fopen(dump, "a") : nullptr;
     for (auto& r : m->prof) {
         float ms = 0.f;
         if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess)
             return fail(CP_ERR_LAUNCH, "event timing failed");
+        if (df)
+            fprintf(df, "%s,%d,%d,%d,%d,%d,%.4f,%.2f\n", cp_conv_variant_name(r.variant), r.M, r.N, r.K, r.kh, r.stride, ms,
+                    r.flops / (ms * 1e-3) / 1e12);
         out[r.variant * 4 + 0] += 1.0;
         out[r.variant * 4 + 1] += ms;
         out[r.variant * 4 + 2] += r.flops;
@@ -741,6 +749,7 @@ int cp_model_profile_read(cp_model* m, double* out, int num_variants) {
         m->event_pool.push_back(r.e1);
     }
     m->prof.clear();
+    if (df) fclose(df);
     return CP_OK;
 }
 

@@ -12,15 +12,36 @@ inline int grid_for(size_t n, int cap = 256 * 16) {
     return (int)g;
 }
 
-// [B,C,H,W] -> [B,H,W,Cpad] (zero pad), used for the network inputs (image / pre_img / pre_hm / pre_hm_hp)
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW,
-                                    int Cpad) {
-    const size_t total = (size_t)B * HW;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t b = i / HW, p = i - b * HW;
-        const float* src = in + b * (size_t)C * HW + p;
-        float* dst = out + i * Cpad;
-        for (int c = 0; c < Cpad; ++c) dst[c] = c < C ? src[(size_t)c * HW] : 0.f;
+// [B,C,H,W] -> [B,H,W,Cpad] (zero pad), used for the network inputs (image / pre_img / pre_hm / pre_hm_hp).
+// One pixel per lane: C coalesced plane reads, Cpad/4 16-byte stores.
+template <int CPAD>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW) {
+    const int total = B * HW;  // < 2^31 for every supported shape
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / HW, p = i - b * HW;
+        const float* src = in + (size_t)b * C * HW + p;
+        float v[CPAD];
+#pragma unroll
+        for (int c = 0; c < CPAD; ++c) v[c] = c < C ? src[(size_t)c * HW] : 0.f;
+        float4* dst = reinterpret_cast<float4*>(out + (size_t)i * CPAD);
+#pragma unroll
+        for (int q = 0; q < CPAD / 4; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+}
+
+// General [B,C,HW] -> [B,HW,C] through a 32 x 32 LDS tile (both sides coalesced); C % 4 == 0 not required.
+__global__ void nchw_to_nhwc_tiled_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        tile[r][tx] = (c < C && p < HW) ? in[((size_t)b * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        if (p < HW && c < C) out[((size_t)b * HW + p) * C + c] = tile[tx][r];
     }
 }
 
@@ -225,8 +246,13 @@ inline int check() { return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAU
 }  // namespace
 
 int cp_launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int Cpad, hipStream_t s) {
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)B * H * W)), dim3(TPB), 0, s, in, out, B, C, H * W,
-                       Cpad);
+    const int g = grid_for((size_t)B * H * W, 256 * 64);
+    if (Cpad == 4) hipLaunchKernelGGL(nchw_to_nhwc_kernel<4>, dim3(g), dim3(TPB), 0, s, in, out, B, C, H * W);
+    else if (Cpad == 8) hipLaunchKernelGGL(nchw_to_nhwc_kernel<8>, dim3(g), dim3(TPB), 0, s, in, out, B, C, H * W);
+    else if (Cpad == C)
+        hipLaunchKernelGGL(nchw_to_nhwc_tiled_kernel, dim3((H * W + 31) / 32, (C + 31) / 32, B), dim3(TPB), 0, s, in, out,
+                           C, H * W);
+    else return CP_ERR_INVALID;
     return check();
 }
 

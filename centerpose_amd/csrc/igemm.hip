@@ -59,12 +59,18 @@ __device__ __forceinline__ float blend(float w1, float v1, float w2, float v2, f
     return __fmul_rn(s, mk);
 }
 
-template <int FRAG, int MT, int NT, int WM, int WN, bool DCN>
-__global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
+// ALIGNED: Cin % 16 == 0 and every source's channel count % 16 == 0, so a K-step lies inside one tap and
+// one concat source: the (tap, source, channel) walk is then wave-uniform scalar state advanced once per
+// K-step, per-lane work is one add + one 64-bit mad + a predicated 16-byte load per slot, and tap
+// validity comes from a per-slot bit-mask computed once.  (The unaligned variant serves the 7x7 stems.)
+template <int FRAG, int MT, int NT, int WM, int WN, bool DCN, bool ALIGNED, bool MULTISRC>
+__global__ __launch_bounds__(NTHREADS, 3) void igemm_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     typedef Frag<FRAG> F;
     typedef typename F::acc_t acc_t;
     constexpr int BM = FRAG * MT * WM, BN = FRAG * NT * WN;
     static_assert(WM * WN * 64 == NTHREADS, "4 waves");
+    static_assert(!DCN || ALIGNED, "DCN needs aligned channels");
+    static_assert(!MULTISRC || (ALIGNED && !DCN), "virtual concat only on the aligned plain-conv path");
     constexpr int LDA = BM + (FRAG == 16 ? 18 : 2);
     constexpr int LDB = BN + (FRAG == 16 ? 0 : 4);
     constexpr int A_SLOTS = BM * BK / 4 / NTHREADS;  // float4 per thread per K-step
@@ -96,6 +102,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvParams p, con
     // ---- per-thread A-slot geometry (fixed over the K loop) ----
     const int k4 = tid & 3;
     int a_b[A_SLOTS], a_h0[A_SLOTS], a_w0[A_SLOTS];
+    int a_pix0[A_SLOTS];       // (b*H + h0)*W + w0, may be negative (halo)
+    unsigned a_vmask[A_SLOTS];  // bit t: tap t reads inside the image (aligned path: KH*KW <= 32)
     bool a_ok[A_SLOTS];
 #pragma unroll
     for (int j = 0; j < A_SLOTS; ++j) {
@@ -107,10 +115,34 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvParams p, con
         a_b[j] = b;
         a_h0[j] = ho * p.stride - p.pad;
         a_w0[j] = wo * p.stride - p.pad;
+        a_pix0[j] = (b * p.H + a_h0[j]) * p.W + a_w0[j];
+        unsigned vm = 0u;
+        if (ALIGNED && !DCN && a_ok[j]) {
+            for (int kh = 0; kh < p.KH; ++kh)
+                for (int kw = 0; kw < p.KW; ++kw) {
+                    const int hi = a_h0[j] + kh, wi = a_w0[j] + kw;
+                    if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) vm |= 1u << (kh * p.KW + kw);
+                }
+        }
+        a_vmask[j] = vm;
     }
 
     float4 a_reg[A_SLOTS];
     float4 b_reg[B_SLOTS];
+
+    // wave-uniform K-walk state (ALIGNED): advanced once per K-step, lives in SGPRs
+    int u_tap = 0, u_kh = 0, u_kw = 0, u_c0 = 0, u_src = 0, u_cs = 0;
+    // DCN: per-slot bilinear taps of the current kernel tap, recomputed only when the tap changes
+    int d_idx[DCN ? A_SLOTS : 1][4];
+    float d_w[DCN ? A_SLOTS : 1][4];
+
+    const float* b_ptr[B_SLOTS];
+#pragma unroll
+    for (int j = 0; j < B_SLOTS; ++j) {
+        const int f = tid + j * NTHREADS;
+        const int row = f / (BN / 4), c4 = f % (BN / 4);
+        b_ptr[j] = p.wp + (size_t)row * p.CoutPad + tn * BN + c4 * 4;
+    }
 
     auto load_tile = [&](int kt) {
         // ---- B (weights): BK rows of BN floats ----
@@ -118,64 +150,101 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvParams p, con
         for (int j = 0; j < B_SLOTS; ++j) {
             const int f = tid + j * NTHREADS;
             if (B_F4 % NTHREADS == 0 || f < B_F4) {
-                const int row = f / (BN / 4), c4 = f % (BN / 4);
-                b_reg[j] = ld4(p.wp + (size_t)(kt * BK + row) * p.CoutPad + tn * BN + c4 * 4);
+                b_reg[j] = ld4(b_ptr[j]);
+                b_ptr[j] += (size_t)BK * p.CoutPad;
             }
         }
         // ---- A ----
-        const int kk = kt * BK + k4 * 4;
-        const int tap = kk / p.Cin;
-        const int ci = kk - tap * p.Cin;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
-        const bool kvalid = kk < p.K;
-        if (!DCN) {
+        if (ALIGNED && !DCN) {
             const float* base = p.src[0];
-            int sc = p.src_c[0], c = ci;
-            if (p.nsrc > 1 && c >= sc) {
-                c -= sc; base = p.src[1]; sc = p.src_c[1];
-                if (p.nsrc > 2 && c >= sc) {
-                    c -= sc; base = p.src[2]; sc = p.src_c[2];
-                    if (p.nsrc > 3 && c >= sc) { c -= sc; base = p.src[3]; sc = p.src_c[3]; }
-                }
+            int sc = p.src_c[0];
+            if (MULTISRC) {
+                if (u_src == 1) { base = p.src[1]; sc = p.src_c[1]; }
+                else if (u_src == 2) { base = p.src[2]; sc = p.src_c[2]; }
+                else if (u_src == 3) { base = p.src[3]; sc = p.src_c[3]; }
             }
+            const int tap_pix = u_kh * p.W + u_kw;
+            const int coff = u_cs + k4 * 4;
+            const unsigned bit = 1u << u_tap;
+#pragma unroll
+            for (int j = 0; j < A_SLOTS; ++j) {
+                const long long off = (long long)(a_pix0[j] + tap_pix) * sc + coff;
+                a_reg[j] = (a_vmask[j] & bit) ? ld4(base + off) : zero4();
+            }
+        } else if (!DCN) {
+            const int kk = kt * BK + k4 * 4;
+            const int tap = kk / p.Cin;
+            const int ci = kk - tap * p.Cin;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            const bool kvalid = kk < p.K;
+            const float* base = p.src[0];
+            const int sc = p.src_c[0];  // unaligned convolutions are single-source (checked by the launcher)
 #pragma unroll
             for (int j = 0; j < A_SLOTS; ++j) {
                 const int hi = a_h0[j] + kh, wi = a_w0[j] + kw;
                 const bool ok = a_ok[j] && kvalid && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-                a_reg[j] = ok ? ld4(base + ((size_t)(a_b[j] * p.H + hi) * p.W + wi) * sc + c) : zero4();
+                a_reg[j] = ok ? ld4(base + ((size_t)(a_b[j] * p.H + hi) * p.W + wi) * sc + ci) : zero4();
             }
         } else {
             const float* base = p.src[0];
             const int C = p.Cin;
+            if (u_c0 == 0) {
+                // new kernel tap: sample positions and (mask-folded) bilinear weights per slot
+#pragma unroll
+                for (int j = 0; j < A_SLOTS; ++j) {
+                    int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
+                    float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+                    if (a_ok[j]) {
+                        // (ho, wo) = (a_h0 + pad, a_w0 + pad) since stride == 1
+                        const size_t pix = (size_t)(a_b[j] * p.H + (a_h0[j] + p.pad)) * p.W + (a_w0[j] + p.pad);
+                        const float* om = p.offmask + pix * 32;
+                        const float dh = om[2 * u_tap], dw = om[2 * u_tap + 1], mk = om[18 + u_tap];
+                        const float h_im = (float)(a_h0[j] + u_kh) + dh;
+                        const float w_im = (float)(a_w0[j] + u_kw) + dw;
+                        if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
+                            const int h_lo = (int)floorf(h_im), w_lo = (int)floorf(w_im);
+                            const int h_hi = h_lo + 1, w_hi = w_lo + 1;
+                            const float lh = h_im - (float)h_lo, lw = w_im - (float)w_lo;
+                            const float hh = 1.f - lh, hw = 1.f - lw;
+                            const int bb = a_b[j] * p.H;
+                            if (h_lo >= 0 && w_lo >= 0) i0 = (bb + h_lo) * p.W + w_lo;
+                            if (h_lo >= 0 && w_hi <= p.W - 1) i1 = (bb + h_lo) * p.W + w_hi;
+                            if (h_hi <= p.H - 1 && w_lo >= 0) i2 = (bb + h_hi) * p.W + w_lo;
+                            if (h_hi <= p.H - 1 && w_hi <= p.W - 1) i3 = (bb + h_hi) * p.W + w_hi;
+                            w1 = hh * hw * mk; w2 = hh * lw * mk; w3 = lh * hw * mk; w4 = lh * lw * mk;
+                        }
+                    }
+                    d_idx[j][0] = i0; d_idx[j][1] = i1; d_idx[j][2] = i2; d_idx[j][3] = i3;
+                    d_w[j][0] = w1; d_w[j][1] = w2; d_w[j][2] = w3; d_w[j][3] = w4;
+                }
+            }
+            const int coff = u_c0 + k4 * 4;
 #pragma unroll
             for (int j = 0; j < A_SLOTS; ++j) {
-                float4 v = zero4();
-                if (a_ok[j]) {
-                    // (ho, wo) = (a_h0 + pad, a_w0 + pad) since stride == 1
-                    const size_t pix = (size_t)(a_b[j] * p.H + (a_h0[j] + p.pad)) * p.W + (a_w0[j] + p.pad);
-                    const float* om = p.offmask + pix * 32;
-                    const float dh = om[2 * tap], dw = om[2 * tap + 1], mk = om[18 + tap];
-                    const float h_im = (float)(a_h0[j] + kh) + dh;
-                    const float w_im = (float)(a_w0[j] + kw) + dw;
-                    if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
-                        const int h_lo = (int)floorf(h_im), w_lo = (int)floorf(w_im);
-                        const int h_hi = h_lo + 1, w_hi = w_lo + 1;
-                        const float lh = h_im - (float)h_lo, lw = w_im - (float)w_lo;
-                        const float hh = 1.f - lh, hw = 1.f - lw;
-                        const float* img = base + (size_t)a_b[j] * p.H * p.W * C + ci;
-                        float4 v1 = zero4(), v2 = zero4(), v3 = zero4(), v4 = zero4();
-                        if (h_lo >= 0 && w_lo >= 0) v1 = ld4(img + ((size_t)h_lo * p.W + w_lo) * C);
-                        if (h_lo >= 0 && w_hi <= p.W - 1) v2 = ld4(img + ((size_t)h_lo * p.W + w_hi) * C);
-                        if (h_hi <= p.H - 1 && w_lo >= 0) v3 = ld4(img + ((size_t)h_hi * p.W + w_lo) * C);
-                        if (h_hi <= p.H - 1 && w_hi <= p.W - 1) v4 = ld4(img + ((size_t)h_hi * p.W + w_hi) * C);
-                        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-                        v.x = blend(w1, v1.x, w2, v2.x, w3, v3.x, w4, v4.x, mk);
-                        v.y = blend(w1, v1.y, w2, v2.y, w3, v3.y, w4, v4.y, mk);
-                        v.z = blend(w1, v1.z, w2, v2.z, w3, v3.z, w4, v4.z, mk);
-                        v.w = blend(w1, v1.w, w2, v2.w, w3, v3.w, w4, v4.w, mk);
-                    }
-                }
+                float4 v1 = zero4(), v2 = zero4(), v3 = zero4(), v4 = zero4();
+                if (d_idx[j][0] >= 0) v1 = ld4(base + (long long)d_idx[j][0] * C + coff);
+                if (d_idx[j][1] >= 0) v2 = ld4(base + (long long)d_idx[j][1] * C + coff);
+                if (d_idx[j][2] >= 0) v3 = ld4(base + (long long)d_idx[j][2] * C + coff);
+                if (d_idx[j][3] >= 0) v4 = ld4(base + (long long)d_idx[j][3] * C + coff);
+                const float w1 = d_w[j][0], w2 = d_w[j][1], w3 = d_w[j][2], w4 = d_w[j][3];
+                float4 v;
+                v.x = fmaf(w4, v4.x, fmaf(w3, v3.x, fmaf(w2, v2.x, w1 * v1.x)));
+                v.y = fmaf(w4, v4.y, fmaf(w3, v3.y, fmaf(w2, v2.y, w1 * v1.y)));
+                v.z = fmaf(w4, v4.z, fmaf(w3, v3.z, fmaf(w2, v2.z, w1 * v1.z)));
+                v.w = fmaf(w4, v4.w, fmaf(w3, v3.w, fmaf(w2, v2.w, w1 * v1.w)));
                 a_reg[j] = v;
+            }
+        }
+        if (ALIGNED) {  // advance the uniform K walk
+            u_c0 += BK;
+            u_cs += BK;
+            if (u_c0 >= p.Cin) {
+                u_c0 = 0; u_cs = 0; u_src = 0;
+                ++u_tap;
+                if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
+            } else if (MULTISRC) {
+                const int cur = u_src == 0 ? p.src_c[0] : u_src == 1 ? p.src_c[1] : u_src == 2 ? p.src_c[2] : p.src_c[3];
+                if (u_cs >= cur) { u_cs = 0; ++u_src; }
             }
         }
     };
@@ -222,18 +291,30 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvParams p, con
         if (kt + 1 < nk) load_tile(kt + 1);
         const float* A = As + buf * A_SZ + wm * (MT * FRAG) + lcol;
         const float* Bt = Bs + buf * B_SZ + wn * (NT * FRAG) + lcol;
+        // fragment reads for k-step s+1 are issued before the MFMAs of step s (register double buffer), so
+        // the LDS latency hides under the matrix pipe instead of stalling the in-order wave
+        constexpr int NKS = BK / F::KSTEP;
+        float a[2][MT], b[2][NT];
 #pragma unroll
-        for (int ks = 0; ks < BK / F::KSTEP; ++ks) {
-            const int krow = ks * F::KSTEP + lrow;
-            float a[MT], b[NT];
+        for (int i = 0; i < MT; ++i) a[0][i] = A[lrow * LDA + i * FRAG];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = A[krow * LDA + i * FRAG];
+        for (int j = 0; j < NT; ++j) b[0][j] = Bt[lrow * LDB + j * FRAG];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = Bt[krow * LDB + j * FRAG];
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < NKS) {
+                const int krow = (ks + 1) * F::KSTEP + lrow;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[nxt][i] = A[krow * LDA + i * FRAG];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[nxt][j] = Bt[krow * LDB + j * FRAG];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ahead of this step's MFMAs
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = F::mfma(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < NT; ++j) acc[i][j] = F::mfma(a[cur][i], b[cur][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
@@ -293,16 +374,27 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const ConvParams p, con
     }
 }
 
-template <int FRAG, int MT, int NT, int WM, int WN, bool DCN>
-int launch(const ConvParams& p, hipStream_t stream) {
+template <int FRAG, int MT, int NT, int WM, int WN, bool DCN, bool ALIGNED, bool MULTISRC>
+int launch_a(const ConvParams& p, hipStream_t stream) {
     constexpr int BM = FRAG * MT * WM, BN = FRAG * NT * WN;
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = (M + BM - 1) / BM;
     const int tiles_n = p.CoutPad / BN;
     if (p.CoutPad % BN != 0 || p.Kpad % BK != 0) return CP_ERR_INVALID;
-    hipLaunchKernelGGL((igemm_kernel<FRAG, MT, NT, WM, WN, DCN>), dim3(tiles_m * tiles_n), dim3(NTHREADS), 0, stream,
-                       p, tiles_m, tiles_n);
+    hipLaunchKernelGGL((igemm_kernel<FRAG, MT, NT, WM, WN, DCN, ALIGNED, MULTISRC>), dim3(tiles_m * tiles_n),
+                       dim3(NTHREADS), 0, stream, p, tiles_m, tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}
+
+template <int FRAG, int MT, int NT, int WM, int WN, bool DCN>
+int launch(const ConvParams& p, hipStream_t stream) {
+    bool aligned = p.Cin % BK == 0 && p.KH * p.KW <= 32;
+    for (int s = 0; s < p.nsrc; ++s) aligned = aligned && (p.src_c[s] % BK == 0);
+    if (DCN) return aligned ? launch_a<FRAG, MT, NT, WM, WN, DCN, true, false>(p, stream) : CP_ERR_INVALID;
+    if (aligned && p.nsrc > 1) return launch_a<FRAG, MT, NT, WM, WN, false, true, true>(p, stream);
+    if (aligned) return launch_a<FRAG, MT, NT, WM, WN, false, true, false>(p, stream);
+    if (p.nsrc != 1) return CP_ERR_INVALID;
+    return launch_a<FRAG, MT, NT, WM, WN, false, false, false>(p, stream);
 }
 
 }  // namespace
