@@ -1,0 +1,309 @@
+"""``BaseDetector`` with the reference's public surface (detectors/base_detector.py:31-776):
+``run(image_or_path_or_tensor, filename=None, meta_inp={}, preprocessed_flag=False)`` returns the same
+dict ({'results','boxes','output','tot','load','pre','net','dec','post','merge','pnp','track'}), with the
+network, decode and PnP stages executed by libcenterpose_hip.so.  ``run_batch`` is the added batched
+entry point (the reference processes one image per call, base_detector.py:134,431).
+
+Not mirrored (out of scope for the inference hot path): the Debugger drawing
+(debug 1-3 only prints), CenterPoseTrack's host-side tracker / Kalman state (tracking_task, refined_Kalman),
+and the GMM sampling of rep_mode 2.
+"""
+import copy
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from ..models.model import create_model, load_model
+from ..utils.image import get_affine_transform, affine_transform, warp_affine_bilinear
+from ..utils.pnp.cuboid_pnp_shell import pnp_shell, finish_detection
+from ..utils.pnp.cuboid_pnp_solver import solve_pnp_batch
+
+
+def _imread_bgr(path):
+    """cv2.imread stand-in: HxWx3 uint8 in BGR order (the reference's mean/std are BGR-ordered, opts.py:436-437)."""
+    try:
+        import cv2  # noqa: F401
+
+        return cv2.imread(path)
+    except ImportError:
+        from PIL import Image
+
+        return np.asarray(Image.open(path).convert('RGB'))[:, :, ::-1].copy()
+
+
+def _resize(image, new_w, new_h):
+    if image.shape[1] == new_w and image.shape[0] == new_h:
+        return image
+    try:
+        import cv2
+
+        return cv2.resize(image, (new_w, new_h))
+    except ImportError:
+        from PIL import Image
+
+        return np.asarray(Image.fromarray(image).resize((new_w, new_h), Image.BILINEAR))
+
+
+class BaseDetector(object):
+    def __init__(self, opt):
+        if opt.gpus[0] >= 0:
+            opt.device = torch.device('cuda')
+        else:
+            opt.device = torch.device('cpu')
+        if opt.tracking_task or opt.refined_Kalman:
+            raise NotImplementedError("CenterPoseTrack's host tracker is outside this library's hot path "
+                                      "(SURVEY.md section 8(f) N2); the tracking heads themselves are supported by "
+                                      "create_model / object_pose_decode")
+        print('Creating model...')
+        self.model = create_model(opt.arch, opt.heads, opt.head_conv, opt)
+        self.model = load_model(self.model, opt.load_model)
+        self.model = self.model.to(opt.device)
+        self.model.eval()
+        self.mean = np.array(opt.mean, dtype=np.float32).reshape(1, 1, 3)
+        self.std = np.array(opt.std, dtype=np.float32).reshape(1, 1, 3)
+        self.max_per_image = 100
+        self.num_classes = opt.num_classes
+        self.scales = opt.test_scales
+        self.opt = opt
+        self.pause = True
+        self.pre_images = None
+
+    def process(self, images, pre_images=None, pre_hms=None, pre_inds=None, return_time=False):
+        raise NotImplementedError
+
+    def post_process(self, dets, meta, scale=1):
+        raise NotImplementedError
+
+    def merge_outputs(self, detections):
+        raise NotImplementedError
+
+    def show_results(self, debugger, image, results):
+        raise NotImplementedError
+
+    def _trans_bbox(self, bbox, trans, width, height):
+        bbox = np.array(copy.deepcopy(bbox), dtype=np.float32)
+        bbox[:2] = affine_transform(bbox[:2], trans)
+        bbox[2:] = affine_transform(bbox[2:], trans)
+        bbox[[0, 2]] = np.clip(bbox[[0, 2]], 0, width - 1)
+        bbox[[1, 3]] = np.clip(bbox[[1, 3]], 0, height - 1)
+        return bbox
+
+    def pre_process(self, image, scale, input_meta={}):
+        """base_detector.py:91-148"""
+        height, width = image.shape[0:2]
+        new_height = int(height * scale)
+        new_width = int(width * scale)
+        if self.opt.fix_short > 0:
+            if height < width:
+                inp_height = self.opt.fix_short
+                inp_width = (int(width / height * self.opt.fix_short) + 63) // 64 * 64
+            else:
+                inp_height = (int(height / width * self.opt.fix_short) + 63) // 64 * 64
+                inp_width = self.opt.fix_short
+            c = np.array([width / 2, height / 2], dtype=np.float32)
+            s = np.array([width, height], dtype=np.float32)
+        elif self.opt.fix_res:
+            inp_height, inp_width = self.opt.input_h, self.opt.input_w
+            c = np.array([new_width / 2., new_height / 2.], dtype=np.float32)
+            s = max(height, width) * 1.0
+        else:
+            inp_height = (new_height | self.opt.pad) + 1
+            inp_width = (new_width | self.opt.pad) + 1
+            c = np.array([new_width // 2, new_height // 2], dtype=np.float32)
+            s = np.array([inp_width, inp_height], dtype=np.float32)
+        trans_input = get_affine_transform(c, s, 0, [inp_width, inp_height])
+        out_height = inp_height // self.opt.down_ratio
+        out_width = inp_width // self.opt.down_ratio
+        trans_output = get_affine_transform(c, s, 0, [out_width, out_height])
+        resized_image = _resize(image, new_width, new_height)
+        inp_image = warp_affine_bilinear(resized_image, trans_input, inp_width, inp_height)
+        inp_image = ((inp_image / 255. - self.mean) / self.std).astype(np.float32)
+        images = torch.from_numpy(inp_image.transpose(2, 0, 1).reshape(1, 3, inp_height, inp_width))
+        meta = {'c': c, 's': s, 'height': height, 'width': width, 'out_height': out_height, 'out_width': out_width,
+                'inp_height': inp_height, 'inp_width': inp_width, 'trans_input': trans_input,
+                'trans_output': trans_output}
+        for k in ('pre_dets', 'camera_matrix', 'id'):
+            if k in input_meta:
+                meta[k] = input_meta[k]
+        return images, meta
+
+    # ------------------------------------------------------------------ PnP input assembly
+    def _pnp_points(self, det):
+        """base_detector.py:549-566"""
+        if self.opt.rep_mode in (0, 3, 4):
+            return np.array(det['kps']).reshape(-1, 2)
+        if self.opt.rep_mode == 1:
+            p1 = np.array(det['kps_displacement_mean']).reshape(-1, 2)
+            p2 = np.array(det['kps_heatmap_mean']).reshape(-1, 2)
+            return np.hstack((p1, p2)).reshape(-1, 2)
+        raise NotImplementedError("rep_mode 2 (GMM sampling with np.random, base_detector.py:568-650) is out of scope")
+
+    def _pnp_all(self, results, meta):
+        """One batched device solve for every surviving detection, then the reference's per-detection
+        packaging / visibility filters (cuboid_pnp_shell.py:26-91)."""
+        boxes = []
+        if not len(results):
+            return boxes
+        pts = [self._pnp_points(d) for d in results]
+        scales = [np.asarray(d['obj_scale'], np.float64) / d['obj_scale'][1] for d in results]
+        raw = solve_pnp_batch(pts, scales, meta['camera_matrix'], device=self.opt.device)
+        for det, r in zip(results, raw):
+            if int(r[0]) == -2:
+                raise NotImplementedError("4-5 valid points: EPnP branch is not built")
+            if int(r[0]) != 1:
+                continue
+            proj = r[8:24].reshape(8, 2).copy()
+            if self.opt.show_axes:  # OPENCV_RETURN (base_detector.py:652)
+                loc, quat = list(r[4:7]), r[24:28].copy()
+            else:
+                loc, quat = list(r[28:31]), r[31:35].copy()
+            ret = finish_detection(self.opt, meta, det, det['obj_scale'], loc, quat, proj)
+            if ret is not None:
+                boxes.append(ret)
+        return boxes
+
+    def _dict_out(self, meta, boxes):
+        """base_detector.py:672-754 (non-tracking branch)"""
+        dict_out = {"camera_data": [], "objects": []}
+        if 'camera_matrix' in meta:
+            dict_out['camera_data'] = np.asarray(meta['camera_matrix']).tolist()
+        for box in boxes:
+            b = box[4]
+            obj = {'class': self.opt.c, 'ct': b['ct'], 'bbox': np.array(b['bbox']).tolist(), 'confidence': b['score'],
+                   'kps_displacement_mean': b['kps_displacement_mean'].tolist(),
+                   'kps_heatmap_mean': b['kps_heatmap_mean'].tolist(), 'kps_heatmap_std': b['kps_heatmap_std'].tolist(),
+                   'kps_heatmap_height': b['kps_heatmap_height'].tolist(), 'obj_scale': b['obj_scale'].tolist()}
+            if self.opt.use_pnp:
+                if 'location' in b:
+                    obj['location'] = [float(v) for v in b['location']]
+                    obj['quaternion_xyzw'] = np.asarray(b['quaternion_xyzw']).tolist()
+                if 'kps_pnp' in b:
+                    obj['kps_pnp'] = b['kps_pnp'].tolist()
+                    obj['kps_3d_cam'] = b['kps_3d_cam'].tolist()
+            dict_out['objects'].append(obj)
+        return dict_out
+
+    def _sync(self):
+        if self.opt.device.type == 'cuda':
+            torch.cuda.synchronize()
+
+    def run(self, image_or_path_or_tensor, filename=None, meta_inp={}, preprocessed_flag=False):
+        load_time, pre_time, net_time, dec_time, post_time = 0, 0, 0, 0, 0
+        merge_time, track_time, pnp_time, tot_time = 0, 0, 0, 0
+        start_time = time.time()
+        pre_processed = preprocessed_flag
+        if isinstance(image_or_path_or_tensor, np.ndarray):
+            image = image_or_path_or_tensor
+            if filename is not None:
+                image_or_path_or_tensor = filename
+        elif type(image_or_path_or_tensor) == type(''):
+            image = _imread_bgr(image_or_path_or_tensor)
+        else:
+            image = image_or_path_or_tensor['image'][0].numpy()
+            pre_processed = True
+        loaded_time = time.time()
+        load_time += (loaded_time - start_time)
+
+        detections = []
+        for scale in self.scales:
+            scale_start_time = time.time()
+            if not pre_processed:
+                images, meta = self.pre_process(image, scale, meta_inp)
+            else:
+                images = torch.from_numpy(np.expand_dims(image, axis=0))
+                meta = meta_inp
+            images = images.to(self.opt.device)
+            self._sync()
+            pre_process_time = time.time()
+            pre_time += pre_process_time - scale_start_time
+            output, dets, forward_time = self.process(images, self.pre_images, None, None, None, return_time=True)
+            self._sync()
+            net_time += forward_time - pre_process_time
+            decode_time = time.time()
+            dec_time += decode_time - forward_time
+            dets = self.post_process(dets, meta, scale)
+            post_process_time = time.time()
+            post_time += post_process_time - decode_time
+            detections.append(dets)
+
+        results = self.merge_outputs(detections)
+        merge_outputs_time = time.time()
+        merge_time += merge_outputs_time - post_process_time
+
+        boxes = []
+        if self.opt.use_pnp == True:  # noqa: E712
+            boxes = self._pnp_all(results, meta)
+        pnp_process_time = time.time()
+        pnp_time += pnp_process_time - merge_outputs_time
+        end_time = time.time()
+        track_time += end_time - pnp_process_time
+        tot_time += end_time - start_time
+
+        dict_out = self._dict_out(meta, boxes)
+        if self.opt.debug >= 1 and self.opt.debug < 4:
+            self.show_results(None, image, results)
+        elif self.opt.debug == 4:
+            self.save_results(None, image, results, image_or_path_or_tensor, dict_out)
+        return {'results': results, 'boxes': boxes, 'output': output, 'tot': tot_time, 'load': load_time,
+                'pre': pre_time, 'net': net_time, 'dec': dec_time, 'post': post_time, 'merge': merge_time,
+                'pnp': pnp_time, 'track': track_time}
+
+    def run_batch(self, images, metas):
+        """Batched inference (added): ``images`` [B,3,H,W] already pre-processed (float32, on any device),
+        ``metas`` a list of B meta dicts as produced by ``pre_process`` (+ 'camera_matrix').  Returns a list of
+        B dicts with the keys of ``run`` ('results', 'boxes'); the network, decode and PnP each run once
+        for the whole batch."""
+        t0 = time.time()
+        images = images.to(self.opt.device)
+        output, dets = self.process(images, None, None, None, None)
+        self._sync()
+        t1 = time.time()
+        outs = []
+        all_results = []
+        for b, meta in enumerate(metas):
+            d_b = {k: v[b:b + 1] for k, v in dets.items()}
+            results = self.merge_outputs([self.post_process(d_b, meta, 1)])
+            all_results.append(results)
+        t2 = time.time()
+        if self.opt.use_pnp == True:  # noqa: E712
+            flat = [(b, d) for b, rs in enumerate(all_results) for d in rs]
+            boxes_per = [[] for _ in metas]
+            if flat:
+                pts = [self._pnp_points(d) for _, d in flat]
+                scales = [np.asarray(d['obj_scale'], np.float64) / d['obj_scale'][1] for _, d in flat]
+                cams = np.stack([np.asarray(metas[b]['camera_matrix'], np.float64) for b, _ in flat])
+                raw = solve_pnp_batch(pts, scales, cams, device=self.opt.device)
+                for (b, det), r in zip(flat, raw):
+                    if int(r[0]) != 1:
+                        continue
+                    proj = r[8:24].reshape(8, 2).copy()
+                    loc, quat = (list(r[4:7]), r[24:28].copy()) if self.opt.show_axes else \
+                        (list(r[28:31]), r[31:35].copy())
+                    ret = finish_detection(self.opt, metas[b], det, det['obj_scale'], loc, quat, proj)
+                    if ret is not None:
+                        boxes_per[b].append(ret)
+        else:
+            boxes_per = [[] for _ in metas]
+        t3 = time.time()
+        for b in range(len(metas)):
+            outs.append({'results': all_results[b], 'boxes': boxes_per[b], 'net+dec': t1 - t0, 'post+merge': t2 - t1,
+                         'pnp': t3 - t2})
+        return outs
+
+    def save_results(self, debugger, image, results, image_or_path_or_tensor, dict_out=None):
+        """JSON side of object_pose.py:383-414 (image drawing is out of scope)."""
+        if os.path.isdir(self.opt.demo):
+            target = os.path.join(self.opt.demo_save, os.path.basename(self.opt.demo))
+        else:
+            target = os.path.join(self.opt.demo_save, os.path.splitext(os.path.basename(self.opt.demo))[0])
+        os.makedirs(target, exist_ok=True)
+        if dict_out is not None and isinstance(image_or_path_or_tensor, str):
+            name = os.path.splitext(os.path.basename(image_or_path_or_tensor))[0]
+            with open(os.path.join(target, name + '.json'), 'w') as fp:
+                json.dump(dict_out, fp)
+
+    def reset_tracking(self):
+        self.pre_images = None

@@ -90,6 +90,87 @@ def dcn_case(seed=5, B=2, C=16, Co=64, H=12, W=10):
     return x, w, b, off, mask
 
 
+class HostOpt:
+    """What the reference's post_process / merge_outputs read from opt."""
+    vis_thresh = 0.3
+    nms = True
+    test_scales = [1.0]
+
+
+def host_cases():
+    """Seeded decode outputs (reference-pinned, uint8 semantics) + two image geometries."""
+    d = np.load(os.path.join(GOLD, "decode_pose_uint8.npz"))
+    dets = {k: d[k] for k in d.files}
+    # make a handful of detections overlap strongly so the Gaussian soft-NMS has work to do
+    dets["bboxes"] = dets["bboxes"].copy()
+    dets["bboxes"][:, 1] = dets["bboxes"][:, 0] + 0.5
+    dets["bboxes"][:, 3] = dets["bboxes"][:, 2] + 1.5
+    metas = [{"c": np.array([300.0, 400.0], np.float32), "s": 800.0, "out_height": 128, "out_width": 128},
+             {"c": np.array([320.0, 240.0], np.float32), "s": 640.0, "out_height": 128, "out_width": 128}]
+    return dets, metas
+
+
+def _jsonable(results):
+    out = []
+    for r in results:
+        out.append({k: (np.asarray(v).tolist() if not isinstance(v, (int, float)) else v) for k, v in r.items()})
+    return out
+
+
+def host_goldens():
+    """Reference post_process + merge_outputs (Gaussian soft-NMS) on seeded detections -> host_post.json."""
+    rimage, rpost, rop = rh.reference_host_modules()
+    dets, metas = host_cases()
+    cases = []
+    for b, meta in enumerate(metas):
+        d_b = {k: v[b:b + 1] for k, v in dets.items()}
+        fake_self = type("S", (), {"opt": HostOpt()})()
+        post = rop.ObjectPoseDetector.post_process(fake_self, d_b, meta, 1)
+        merged = rop.ObjectPoseDetector.merge_outputs(fake_self, [post])
+        cases.append({"n_post": len(post), "first_post": _jsonable(post[:3]), "merged": _jsonable(list(merged))})
+    # affine helper on its own (rot != 0 and inverse)
+    t1 = rimage.get_affine_transform(np.array([300.0, 400.0], np.float32), 800.0, 0, [512, 512])
+    t2 = rimage.get_affine_transform(np.array([100.0, 50.0], np.float32), np.array([640.0, 480.0], np.float32), 30,
+                                     [128, 96], inv=1)
+    with open(os.path.join(GOLD, "host_post.json"), "w") as f:
+        json.dump({"cases": cases, "affine_fwd": t1.tolist(), "affine_inv_rot30": t2.tolist()}, f)
+    print("host_post.json:", [(c["n_post"], len(c["merged"])) for c in cases])
+
+
+OPTS_SCENARIOS = [
+    [],
+    ["--arch", "dlav1_34", "--c", "cup", "--rep_mode", "1"],
+    ["--tracking_task", "--tracking", "--tracking_hp", "--pre_img", "--pre_hm", "--pre_hm_hp", "--hps_uncertainty",
+     "--obj_scale", "--obj_scale_uncertainty", "--gpus", "0,1", "--debug", "0", "--batch_size", "33"],
+    ["--gpus", "-1", "--keep_res", "--not_hm_hp", "--use_residual", "--c", "cup", "--mug"],
+]
+
+
+def run_opts(cls, argv):
+    import contextlib
+    import io
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        o = cls().parser.parse_args(argv)
+        o = cls().parse(o)
+        o = cls().init(o)
+    d = dict(vars(o))
+    for k in ("root_dir", "data_dir", "exp_dir", "save_dir", "debug_dir"):
+        d.pop(k)
+    return d
+
+
+def opts_goldens():
+    """Reference opts: parse_args -> parse -> init for a few flag sets -> opts_scenarios.json."""
+    rh.setup()
+    from lib.opts import opts as ref_opts
+
+    out = [{"argv": a, "opt": run_opts(ref_opts, a)} for a in OPTS_SCENARIOS]
+    with open(os.path.join(GOLD, "opts_scenarios.json"), "w") as f:
+        json.dump(out, f, sort_keys=True)
+    print("opts_scenarios.json:", len(out), "scenarios,", len(out[0]["opt"]), "fields")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     odcn.build()
@@ -135,6 +216,8 @@ def main():
     d = odec.synth_heads(1, seed=318)
     r = reference_decode_run(d, False, "uint8", rep_mode=0)
     np.savez_compressed(os.path.join(GOLD, "decode_pose_uint8_rep0.npz"), **r)
+    host_goldens()
+    opts_goldens()
     print("done ->", GOLD)
 
 

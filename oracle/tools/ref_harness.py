@@ -88,3 +88,61 @@ def reference_decode():
     from lib.models.decode import object_pose_decode
 
     return object_pose_decode
+
+
+def install_host_shims():
+    """Fake third-party modules so the reference's HOST-side detector code (post-process, soft-NMS,
+    merge) can be imported for pinning.  cv2.getAffineTransform is the documented 3-point linear solve;
+    everything else is an import-time placeholder that is never called by the pinned functions."""
+    import json as _json
+
+    import numpy as np
+
+    def fake(name, **attrs):
+        if name in sys.modules:
+            return sys.modules[name]
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    def get_affine(src, dst):
+        src = np.asarray(src, np.float64)
+        dst = np.asarray(dst, np.float64)
+        A = np.zeros((6, 6))
+        b = np.zeros(6)
+        for i in range(3):
+            A[2 * i, 0:3] = [src[i, 0], src[i, 1], 1]
+            A[2 * i + 1, 3:6] = [src[i, 0], src[i, 1], 1]
+            b[2 * i], b[2 * i + 1] = dst[i, 0], dst[i, 1]
+        return np.linalg.solve(A, b).reshape(2, 3)
+
+    try:
+        import cv2  # noqa: F401
+    except ImportError:
+        fake("cv2", getAffineTransform=get_affine, __version__="4.5.3", INTER_LINEAR=1)
+    fake("progress")
+    fake("progress.bar", Bar=object)
+    fake("simplejson", dump=_json.dump, dumps=_json.dumps, load=_json.load)
+    fake("pyrr", Quaternion=object)
+    fake("filterpy")
+    fake("filterpy.kalman", KalmanFilter=object)
+    fake("filterpy.common", Q_discrete_white_noise=None)
+    fake("numba", jit=lambda *a, **k: (lambda f: f))
+    import sklearn.utils  # noqa: F401
+
+    fake("sklearn.utils.linear_assignment_", linear_assignment=None)
+
+
+def reference_host_modules():
+    """(lib.utils.image, lib.utils.post_process, lib.detectors.object_pose) of the reference."""
+    setup()
+    install_host_shims()
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from lib.detectors import object_pose as rop
+        from lib.utils import image as rimage
+        from lib.utils import post_process as rpost
+    return rimage, rpost, rop

@@ -1,0 +1,124 @@
+"""GPU tests of the drop-in detector path (centerpose_amd/lib): decode -> post-process -> soft-NMS -> batched
+PnP on Objectron-shaped synthetic heads must return the generating pose (<= 1 deg, <= 1 %), and the
+detector object must reproduce the reference's return schema."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from centerpose_amd import hip, synth
+from centerpose_amd.lib.detectors.detector_factory import detector_factory
+from centerpose_amd.lib.models.decode import object_pose_decode
+from centerpose_amd.lib.models.model import create_model, load_model, save_model
+from centerpose_amd.lib.opts import opts
+from centerpose_amd.lib.utils.pnp.cuboid_pnp_shell import pnp_shell
+from oracle import backbone as ob
+from oracle import pnp as opnp
+from tests import scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _demo_opt(extra=()):
+    o = opts().parser.parse_args(["--arch", "dlav1_34", "--c", "cup", "--debug", "5"] + list(extra))
+    o.nms = True            # demo.py:113-114
+    o.obj_scale = True
+    o.use_pnp = True        # demo.py:149
+    o = opts().init(opts().parse(o))
+    return o
+
+
+def _geodesic(Ra, Rb):
+    return np.degrees(np.arccos(np.clip((np.trace(Ra.T @ Rb) - 1) / 2, -1, 1)))
+
+
+def test_decode_to_pose_known_answer(device):
+    """heads rendered from known poses -> cp_decode -> reference post-process/merge -> cp_pnp_solve."""
+    B, n_obj = 4, 3
+    heads, scenes = scene.render(B, n_obj, seed=12)
+    opt = _demo_opt()
+    opt.show_axes = True  # OpenCV-frame pose, comparable with the generating (R, t)
+    g = {k: torch.from_numpy(v).to(device) for k, v in heads.items()}
+    dets = object_pose_decode(g["hm"], g["hps"], wh=g["wh"], obj_scale=g["scale"], reg=g["reg"], hm_hp=g["hm_hp"],
+                              hp_offset=g["hp_offset"], opt=opt, Inference=True)
+    dets = {k: v.cpu().numpy() for k, v in dets.items()}
+    from centerpose_amd.lib.detectors.object_pose import ObjectPoseDetector
+
+    fake = type("S", (), {"opt": opt})()
+    meta = {"c": np.array([256.0, 256.0], np.float32), "s": 512.0, "out_height": 128, "out_width": 128,
+            "width": 512, "height": 512, "camera_matrix": scene.K_DEMO}
+    n_found = 0
+    for b in range(B):
+        d_b = {k: v[b:b + 1] for k, v in dets.items()}
+        results = ObjectPoseDetector.merge_outputs(fake, [ObjectPoseDetector.post_process(fake, d_b, meta, 1)])
+        assert len(results) == len(scenes[b]), "image %d: %d detections for %d objects" % (b, len(results), len(scenes[b]))
+        for det in results:
+            pts = np.hstack((np.array(det["kps_displacement_mean"]).reshape(-1, 2),
+                             np.array(det["kps_heatmap_mean"]).reshape(-1, 2))).reshape(-1, 2)
+            assert (pts > -5000).all(), "every heat-map keypoint must survive the inference filter"
+            ret = pnp_shell(opt, meta, det, pts, det["obj_scale"], OPENCV_RETURN=True)
+            assert ret is not None
+            # match to the generating object by centre
+            gt = min(scenes[b], key=lambda o: np.linalg.norm(o["kps_img"].mean(0) - np.array(det["kps"]).reshape(8, 2).mean(0)))
+            R = opnp.quat_xyzw_to_matrix(det["quaternion_xyzw"])
+            assert _geodesic(R, gt["R"]) < 1.0                                     # <= 1 degree
+            loc = np.array(det["location"]) * gt["height"]   # pose is recovered in units of the object height
+            assert np.linalg.norm(loc - gt["t"]) / np.linalg.norm(gt["t"]) < 0.01                 # <= 1 %
+            np.testing.assert_allclose(np.array(det["obj_scale"]) / det["obj_scale"][1], gt["scale"], rtol=1e-5)
+            assert ret[0].shape == (9, 2) and ret[1].shape == (9, 3)               # kps_pnp, kps_3d_cam
+            n_found += 1
+    assert n_found == sum(len(s) for s in scenes) > 0
+
+
+def test_detector_run_and_run_batch_schema(device, tmp_path):
+    """detector_factory['object_pose'](opt).run(...) on synthetic weights: reference return schema, agreement with
+    the CPU oracle on the head tensors, and run_batch == run image by image."""
+    opt = _demo_opt()
+    sd = synth.make_state_dict("dlav1_34", opt.heads)
+    ck = os.path.join(str(tmp_path), "synthetic_dlav1_34.pth")
+    m = create_model(opt.arch, opt.heads, opt.head_conv, opt)
+    m.load_state_dict(sd, strict=True)
+    save_model(ck, 7, m)                       # reference checkpoint container (model.py:90-105)
+    opt.load_model = ck
+    det = detector_factory[opt.task](opt)
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 255, (480, 640, 3)).astype(np.uint8)   # BGR frame as cv2.imread would return
+    meta_inp = {"camera_matrix": scene.K_DEMO}
+    ret = det.run(img, meta_inp=meta_inp)
+    assert set(ret) == {"results", "boxes", "output", "tot", "load", "pre", "net", "dec", "post", "merge", "pnp", "track"}
+    assert set(ret["output"]) >= set(opt.heads)
+    keys = {"score", "cls", "obj_scale", "obj_scale_uncertainty", "kps_displacement_std", "bbox", "ct", "kps", "tracking",
+            "tracking_hp", "kps_displacement_mean", "kps_heatmap_mean", "kps_heatmap_std", "kps_heatmap_height"}
+    for r in ret["results"]:
+        assert keys <= set(r)
+    # head tensors vs the CPU oracle on the same pre-processed frame (post-sigmoid heat-map <= 1e-3)
+    images, meta = det.pre_process(img, 1.0, meta_inp)
+    zo = ob.dlaseg_forward(sd, images, opt.heads, arch="dlav1")
+    assert float((ret["output"]["hm"].cpu() - torch.sigmoid(zo["hm"])).abs().max()) < 1e-3
+    # batched path gives the same detections as the per-image path
+    img2 = rng.randint(0, 255, (480, 640, 3)).astype(np.uint8)
+    i2, m2 = det.pre_process(img2, 1.0, meta_inp)
+    outs = det.run_batch(torch.cat([images, i2]), [meta, m2])
+    r2 = det.run(img2, meta_inp=meta_inp)
+    for single, batched in ((ret, outs[0]), (r2, outs[1])):
+        assert len(single["results"]) == len(batched["results"])
+        for a, b in zip(single["results"], batched["results"]):
+            np.testing.assert_allclose(a["bbox"], b["bbox"], atol=1e-3)
+            assert abs(a["score"] - b["score"]) < 1e-5
+        assert len(single["boxes"]) == len(batched["boxes"])
+
+
+def test_load_model_handles_reference_checkpoint_quirks(device, tmp_path):
+    heads = synth.HEADS_POSE
+    sd = synth.make_state_dict("dla_34", heads)
+    wrapped = {"module." + k: v for k, v in sd.items()}          # DataParallel prefix (model.py:43-48)
+    wrapped["module.base.fc.weight"] = torch.zeros(1000, 512, 1, 1)  # ImageNet classifier rides along
+    del wrapped["module.hm.2.bias"]                               # a missing key keeps the constructor value
+    p = os.path.join(str(tmp_path), "ck.pth")
+    torch.save({"epoch": 3, "state_dict": wrapped}, p)
+    m = load_model(create_model("dla_34", heads, 256, None), p).to("cuda")
+    assert float(m.state_dict()["hm.2.bias"][0]) == pytest.approx(-2.19)
+    x = synth.frames(1, seed=3, h=64, w=64).to(device)
+    z = m(x)[-1]
+    assert z["hm"].shape == (1, 1, 16, 16) and torch.isfinite(z["hps"]).all()
