@@ -29,10 +29,11 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+from centerpose_amd import distributed as cpd  # noqa: E402
 from centerpose_amd import hip, synth  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, dense f32 matrix
-GFLOP_PER_IMG = {"dlav1_34": 106.85, "dla_34": 85.11}
+GFLOP_PER_IMG = {"dlav1_34": 106.85, "dla_34": 85.11, "dla_34_track": 109.68}
 
 
 def parse():
@@ -40,7 +41,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="decode", choices=["decode", "full"])
+    ap.add_argument("--workload", default="decode", choices=["decode", "full", "track"],
+                    help="decode: configs[1] (default); full: configs[2] dla_34 + PnP; track: dla_34 two-frame "
+                         "CenterPoseTrack inputs + Gaussian-moment decode + RCCL all-gather of detection records")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 / 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
@@ -53,11 +56,19 @@ class Pipeline(object):
     def __init__(self, workload, batch, device, seed):
         self.workload = workload
         self.arch = "dlav1_34" if workload == "decode" else "dla_34"
-        self.heads = synth.HEADS_POSE
+        self.track = workload == "track"
+        self.heads = synth.HEADS_TRACK if self.track else synth.HEADS_POSE
         self.batch = batch
         self.device = device
-        sd = synth.make_state_dict(self.arch, self.heads, False)
-        self.model = hip.HipModel(self.arch, self.heads, sd)
+        sd = synth.make_state_dict(self.arch, self.heads, self.track)
+        self.model = hip.HipModel(self.arch, self.heads, sd, tracking_task=self.track)
+        self.extra = {}
+        if self.track:  # previous frame + rendered previous heat-maps (base_detector.py:150-388)
+            g = synth._gen(seed, "pre")
+            self.extra = dict(
+                pre_img=torch.cat([synth.frames(min(8, batch - i), seed=seed + 500 + i) for i in range(0, batch, 8)]).to(device),
+                pre_hm=(torch.rand(batch, 1, 512, 512, generator=g) ** 16).to(device),
+                pre_hm_hp=(torch.rand(batch, 8, 512, 512, generator=g) ** 16).to(device))
         # distinct frames per batch slot (generated in chunks of 8 to bound host memory)
         xs = [synth.frames(min(8, batch - i), seed=seed + i).to(device) for i in range(0, batch, 8)]
         self.x = torch.cat(xs, 0).contiguous()
@@ -65,8 +76,17 @@ class Pipeline(object):
                                 dtype=torch.float64, device=device)  # demo.py:143-144
 
     def step(self, x=None):
-        x = self.x if x is None else x
-        z = self.model(x, sigmoid_hm=True)
+        if x is None:
+            x, extra = self.x, self.extra
+        else:
+            extra = {k: v[: x.shape[0]] for k, v in self.extra.items()}
+        z = self.model(x, sigmoid_hm=True, **extra)
+        if self.track:
+            det = hip.decode_raw(z["hm"], z["hps"], z["wh"], z["hm_hp"], z["hps_uncertainty"], z["scale"],
+                                 z["scale_uncertainty"], z["reg"], z["hp_offset"], z["tracking"], z["tracking_hp"],
+                                 K=100, rep_mode=1, fit_gaussian=True, balance=2.0)
+            # the tracker of every video needs all detections: one RCCL all-gather of the fixed-size records
+            return cpd.allgather_detections(det)
         det = hip.decode_raw(z["hm"], z["hps"], z["wh"], z["hm_hp"], None, z["scale"], None, z["reg"],
                              z["hp_offset"], None, None, K=100, rep_mode=1, fit_gaussian=False, balance=2.0)
         if self.workload != "full":
@@ -86,6 +106,8 @@ class Pipeline(object):
 
 def cpu_baseline(workload, arch, budget_s=12.0, max_imgs=16):
     """Oracle (CPU port of the reference graph) on a bounded sample of the same workload."""
+    if workload == "track":
+        return None
     from oracle import backbone as ob
     from oracle import decode as odec
 
@@ -121,9 +143,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    batch = args.batch or (32 if args.workload == "decode" else 64)
+        cpd.init_from_env("nccl")
+    batch = args.batch or {"decode": 32, "full": 64, "track": 16}[args.workload]
     pipe = Pipeline(args.workload, batch, device, seed=317 + 1000 * rank)
 
     def barrier():
@@ -188,20 +209,23 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.workload, pipe.arch)
+        gf = GFLOP_PER_IMG[pipe.arch + ("_track" if pipe.track else "")]
         out = {
             "metric": "images/sec at 512x512 DLA-34 (backbone + heat-map decode%s)" % (
-                " + PnP" if args.workload == "full" else ""),
+                " + PnP" if args.workload == "full" else " + detection all-gather" if pipe.track else ""),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s 512x512 batch=%d/GPU, synthetic random frames, seeded random-init weights, "
                                    "backbone + sigmoid + heat-map decode%s" % (
-                                       pipe.arch, batch, " + batched PnP" if args.workload == "full" else ""),
+                                       pipe.arch, batch, " + batched PnP" if args.workload == "full" else
+                                       " (two-frame tracking inputs, Gaussian moments) + all-gather" if pipe.track else ""),
                        "arch": pipe.arch, "global_batch": world * batch, "input": "512x512",
-                       "parallelism": "batch-shard x%d (no collective)" % world,
-                       "gflop_per_image": GFLOP_PER_IMG[pipe.arch]},
+                       "parallelism": "batch-shard x%d (%s)" % (
+                           world, "all-gather of detection records" if pipe.track else "no collective"),
+                       "gflop_per_image": gf},
             "p50_frame_ms_batch1": lat,
-            "whole_step_tflops": round(value * GFLOP_PER_IMG[pipe.arch] / 1e3 / world, 2),
+            "whole_step_tflops": round(value * gf / 1e3 / world, 2),
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

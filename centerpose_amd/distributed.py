@@ -1,0 +1,68 @@
+"""Single-node multi-GPU execution of the hot path: one process per GPU, images sharded by batch.
+
+The chain backbone -> decode -> PnP has no cross-image dependency (eval-mode BatchNorm, per-image top-K), so
+CenterPose inference needs NO data-path collective: each rank processes its contiguous shard of the global
+batch and scaling is "weak" (per-GPU batch fixed).  The reference has no distributed inference at all
+(its only multi-GPU code is training-time ``torch.nn.DataParallel``, models/data_parallel.py:120-129, and
+per-video process sharding in the evaluator, eval_video_official.py:1999-2006); this module supplies the
+batch sharding both of those imply.
+
+The one collective is for the tracking path, where the host-side tracker of a video needs the detections of
+every frame: ``allgather_detections`` gathers the fixed-size detection records ([b, K, 118] float32 per rank)
+with a single ``all_gather`` (RCCL over xGMI when the backend is "nccl").  Records are ~47 KB per image, so the
+exchange is latency-bound; one un-bucketed all-gather of the whole shard is the right shape for point-to-point
+xGMI links (no ring pipeline to fill).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous [start, end) of ``n_items`` owned by ``rank``; remainders go to the lowest ranks (the same
+    rule as the reference's chunk_sizes, opts.py:358-367, without its master-GPU special case)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def allgather_detections(det, group=None):
+    """det: [b, K, F] float32 on this rank (same b on every rank) -> [world * b, K, F] in rank order."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return det
+    world = dist.get_world_size(group)
+    det = det.contiguous()
+    out = torch.empty((world * det.shape[0],) + tuple(det.shape[1:]), dtype=det.dtype, device=det.device)
+    dist.all_gather_into_tensor(out, det, group=group)  # concatenation along dim 0, rank order
+    return out
+
+
+def allgather_detections_ragged(det, counts_hint=None, group=None):
+    """Variant for uneven shards (last ranks own one image fewer): pads to the largest shard, gathers, and
+    returns the concatenation without the padding."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return det
+    world = dist.get_world_size(group)
+    n = torch.tensor([det.shape[0]], dtype=torch.int64, device=det.device)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n, group=group)
+    ns = [int(x.item()) for x in ns]
+    m = max(ns)
+    pad = torch.zeros((m,) + tuple(det.shape[1:]), dtype=det.dtype, device=det.device)
+    pad[: det.shape[0]] = det
+    full = allgather_detections(pad, group).view((world, m) + tuple(det.shape[1:]))
+    return torch.cat([full[r, : ns[r]] for r in range(world)], 0)
