@@ -64,7 +64,7 @@ int cp_launch_conv(const ConvParams& p, hipStream_t stream);
 int cp_conv_tile_n(int cout);
 int cp_conv_variant(const ConvParams& p);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 6
+#define CP_NUM_CONV_VARIANTS 14
 
 // ---- element-wise / data-movement kernels (ewise.hip) ----
 int cp_launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int Cpad, hipStream_t s);

@@ -386,10 +386,15 @@ int launch_a(const ConvParams& p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
-template <int FRAG, int MT, int NT, int WM, int WN, bool DCN>
-int launch(const ConvParams& p, hipStream_t stream) {
+static bool conv_aligned(const ConvParams& p) {
     bool aligned = p.Cin % BK == 0 && p.KH * p.KW <= 32;
     for (int s = 0; s < p.nsrc; ++s) aligned = aligned && (p.src_c[s] % BK == 0);
+    return aligned;
+}
+
+template <int FRAG, int MT, int NT, int WM, int WN, bool DCN>
+int launch(const ConvParams& p, hipStream_t stream) {
+    const bool aligned = conv_aligned(p);
     if (DCN) return aligned ? launch_a<FRAG, MT, NT, WM, WN, DCN, true, false>(p, stream) : CP_ERR_INVALID;
     if (aligned && p.nsrc > 1) return launch_a<FRAG, MT, NT, WM, WN, false, true, true>(p, stream);
     if (aligned) return launch_a<FRAG, MT, NT, WM, WN, false, true, false>(p, stream);
@@ -406,18 +411,26 @@ int cp_conv_tile_n(int cout) {
     return 64;
 }
 
-// 0..3: plain conv with N tile 16/32/64/128; 4..5: fused DCNv2 with N tile 64/128
+// Kernel variant id = one template instantiation family (what rocprofv3 lists as one kernel name):
+//   0..3  plain conv, N tile 16/32/64/128      4..5  fused DCNv2, N tile 64/128
+//   6..9  plain conv over a virtual channel concat (Root), N tile 16/32/64/128
+//   10..13 unaligned-channel plain conv (7x7 stems), N tile 16/32/64/128
 int cp_conv_variant(const ConvParams& p) {
     const int bn = cp_conv_tile_n(p.Cout);
     if (p.offmask) return bn == 128 ? 5 : 4;
-    return bn == 16 ? 0 : bn == 32 ? 1 : bn == 64 ? 2 : 3;
+    const int t = bn == 16 ? 0 : bn == 32 ? 1 : bn == 64 ? 2 : 3;
+    if (!conv_aligned(p)) return 10 + t;
+    return (p.nsrc > 1 ? 6 : 0) + t;
 }
 
 const char* cp_conv_variant_name(int v) {
-    static const char* names[6] = {"igemm_f32_16x16x4_m256n16", "igemm_f32_32x32x2_m256n32", "igemm_f32_32x32x2_m128n64",
-                                   "igemm_f32_32x32x2_m128n128", "dcn_igemm_f32_32x32x2_m128n64",
-                                   "dcn_igemm_f32_32x32x2_m128n128"};
-    return (v >= 0 && v < 6) ? names[v] : "?";
+    static const char* names[14] = {
+        "igemm_f32_16x16x4_m256n16", "igemm_f32_32x32x2_m256n32", "igemm_f32_32x32x2_m128n64",
+        "igemm_f32_32x32x2_m128n128", "dcn_igemm_f32_32x32x2_m128n64", "dcn_igemm_f32_32x32x2_m128n128",
+        "igemm_cat_f32_16x16x4_m256n16", "igemm_cat_f32_32x32x2_m256n32", "igemm_cat_f32_32x32x2_m128n64",
+        "igemm_cat_f32_32x32x2_m128n128", "igemm_unaligned_f32_16x16x4_m256n16", "igemm_unaligned_f32_32x32x2_m256n32",
+        "igemm_unaligned_f32_32x32x2_m128n64", "igemm_unaligned_f32_32x32x2_m128n128"};
+    return (v >= 0 && v < 14) ? names[v] : "?";
 }
 
 int cp_launch_conv(const ConvParams& p, hipStream_t stream) {

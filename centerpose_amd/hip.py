@@ -228,7 +228,7 @@ class HipModel(object):
 
     def profile_read(self):
         """-> {kernel name: dict(launches, ms, flops, bytes)} accumulated since the last read."""
-        nv = 6
+        nv = 14
         buf = (ctypes.c_double * (nv * 4))()
         _check(lib().cp_model_profile_read(self._h, buf, nv), "cp_model_profile_read")
         out = OrderedDict()

@@ -1,0 +1,43 @@
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter CSVs -> profiles/pmc_traffic.json (HBM bytes per launch per
+kernel variant).  Correction per MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE counts 128-byte requests
+at 64 B, i.e. exactly half of the bytes of a wide (16 B/lane) coalesced read -> x2 (calibrated here on
+gn_stats_kernel, which reads a known 512 MiB tensor once: FETCH_SIZE reports 256 MiB); WRITE_SIZE is 1:1
+(calibrated on gn_apply_relu_kernel: 512 MiB written, 512 MiB reported).  Counter unit: KiB."""
+import collections
+import csv
+import json
+import re
+import sys
+
+fetch_csv, write_csv, out = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def variant(kname):
+    m = re.search(r"igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (true|false)>", kname)
+    if not m:
+        return re.sub(r"\(.*", "", kname.replace("(anonymous namespace)::", "").replace("void ", "")).strip()
+    frag, mt, nt, wm, wn = (int(m.group(i)) for i in range(1, 6))
+    dcn, aligned, cat = (m.group(i) == "true" for i in (6, 7, 8))
+    bm, bn = frag * mt * wm, frag * nt * wn
+    pre = "dcn_igemm" if dcn else "igemm_cat" if cat else "igemm" if aligned else "igemm_unaligned"
+    return "%s_f32_%s_m%dn%d" % (pre, "16x16x4" if frag == 16 else "32x32x2", bm, bn)
+
+
+def agg(path):
+    d = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        v = variant(r["Kernel_Name"])
+        d[v][0] += 1
+        d[v][1] += float(r["Counter_Value"])
+    return d
+
+
+f, w = agg(fetch_csv), agg(write_csv)
+res = {}
+for k in f:
+    fb = f[k][1] / f[k][0] * 1024 * 2.0
+    wb = (w[k][1] / w[k][0] * 1024) if k in w else 0.0
+    res[k] = {"launches_sampled": f[k][0], "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
+              "hbm_bytes_per_launch": round(fb + wb), "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE x1; KiB units"}
+json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+print("wrote", out, len(res), "kernels")
