@@ -56,6 +56,9 @@ struct ConvParams {
     int store;       // CpStore
     int ldo;         // NHWC: channel stride of out; NCHW: total channels of out tensor
     int coff;        // channel offset inside out
+    const void* w16_hi;    // split-f16 path: packed weights [CoutPad][Kpad16] binary16 (hi / lo), or nullptr
+    const void* w16_lo;
+    int Kpad16;
     const float* offmask;  // DCN mode: NHWC [B,H,W,32] = 18 offsets (dh,dw interleaved per tap) + 9 masks (already sigmoided) + 5 pad
 };
 
@@ -64,7 +67,15 @@ int cp_launch_conv(const ConvParams& p, hipStream_t stream);
 int cp_conv_tile_n(int cout);
 int cp_conv_variant(const ConvParams& p);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 14
+#define CP_NUM_CONV_VARIANTS 22
+// split-f16 ("f16x3") implicit GEMM (igemm16.hip)
+bool cp_conv16_supported(const ConvParams& p);
+int cp_launch_conv16(const ConvParams& p, hipStream_t stream);
+int cp_conv16_variant(const ConvParams& p);
+int cp_launch_pack_weight16(const float* w, void* hi, void* lo, int Cout, int Cin, int taps, int Kpad16, int coff,
+                            hipStream_t s);
+#define CP_PREC_F32 0
+#define CP_PREC_F16X3 1
 
 // ---- element-wise / data-movement kernels (ewise.hip) ----
 int cp_launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int Cpad, hipStream_t s);

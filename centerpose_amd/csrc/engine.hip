@@ -108,7 +108,12 @@ struct ConvW {
     float* scale = nullptr;  // [CoutPad] or nullptr
     float* shift = nullptr;  // [CoutPad] or nullptr
     int Cin = 0, CinP = 0, Cout = 0, CoutPad = 0, KH = 0, KW = 0, K = 0, Kpad = 0;
+    void* w16_hi = nullptr;  // split-f16 copies [CoutPad][K] (only when every K-step of 32 stays inside one tap)
+    void* w16_lo = nullptr;
+    int Kpad16 = 0;
 };
+
+int g_default_precision = CP_PREC_F32;
 
 struct DeformW {
     ConvW offset;  // conv_offset_mask (27 -> 32 padded), shift = bias
@@ -128,6 +133,7 @@ struct HeadW {
 struct cp_model {
     std::string arch;
     bool gru = false, tracking = false, finalized = false;
+    int precision = g_default_precision;
     int head_conv = 256;
     std::vector<std::pair<std::string, int>> heads;
     std::map<std::string, std::vector<float>> params;  // host copies until finalize
@@ -213,6 +219,13 @@ struct Packer {
         c.Kpad = (int)align_up(c.K, 16);
         c.wp = dev_alloc((size_t)c.Kpad * c.CoutPad);
         if (!c.wp) return c;
+        const bool want16 = (c.CinP == cin) && (cin % 32 == 0) && cp_conv_tile_n(c.Cout) >= 32 && kh * kw <= 32;
+        if (want16) {
+            c.Kpad16 = c.K;
+            const size_t halfs = (size_t)c.CoutPad * c.Kpad16;
+            c.w16_hi = dev_alloc((halfs + 1) / 2);
+            c.w16_lo = dev_alloc((halfs + 1) / 2);
+        }
         for (size_t i = 0; i < wnames.size(); ++i) {
             const auto* w = get(wnames[i], (size_t)cout_each * cin * kh * kw);
             if (!w) return c;
@@ -224,6 +237,9 @@ struct Packer {
             hipMemcpy(tmp, w->data(), w->size() * sizeof(float), hipMemcpyHostToDevice);
             int rc = cp_launch_pack_weight(tmp, c.wp, cout_each, cin, kh * kw, c.CinP, c.CoutPad, (int)i * cout_each,
                                            nullptr);
+            if (rc == CP_OK && c.w16_hi && c.w16_lo)
+                rc = cp_launch_pack_weight16(tmp, c.w16_hi, c.w16_lo, cout_each, cin, kh * kw, c.Kpad16,
+                                             (int)i * cout_each, nullptr);
             hipDeviceSynchronize();
             hipFree(tmp);
             if (rc != CP_OK) status = rc;
@@ -424,6 +440,10 @@ struct Fwd {
         p.act = act;
         p.act_from = act_from;
         p.offmask = offmask ? offmask->ptr() : nullptr;
+        p.w16_hi = w.w16_hi;
+        p.w16_lo = w.w16_lo;
+        p.Kpad16 = w.Kpad16;
+        const bool use16 = m->precision == CP_PREC_F16X3 && cp_conv16_supported(p);
         Tensor out;
         if (out_nchw) {
             p.out = out_nchw;
@@ -442,7 +462,7 @@ struct Fwd {
         if (!m->dry) {
             if (m->profile) {
                 cp_model::ProfRec r;
-                r.variant = cp_conv_variant(p);
+                r.variant = use16 ? cp_conv16_variant(p) : cp_conv_variant(p);
                 const double M = (double)B * p.Ho * p.Wo;
                 const int cin_real = w.Cin;  // un-padded input channels
                 r.flops = 2.0 * M * w.Cout * (double)(w.KH * w.KW * cin_real);
@@ -454,11 +474,11 @@ struct Fwd {
                 r.e0 = m->get_event();
                 r.e1 = m->get_event();
                 (void)hipEventRecord(r.e0, s);
-                chk(cp_launch_conv(p, s));
+                chk(use16 ? cp_launch_conv16(p, s) : cp_launch_conv(p, s));
                 (void)hipEventRecord(r.e1, s);
                 m->prof.push_back(r);
             } else {
-                chk(cp_launch_conv(p, s));
+                chk(use16 ? cp_launch_conv16(p, s) : cp_launch_conv(p, s));
             }
         }
         return out;
@@ -721,6 +741,18 @@ int cp_model_finalize(cp_model* m) {
     return CP_OK;
 }
 
+int cp_set_default_precision(int precision) {
+    if (precision != CP_PREC_F32 && precision != CP_PREC_F16X3) return fail(CP_ERR_INVALID, "precision must be 0 or 1");
+    g_default_precision = precision;
+    return CP_OK;
+}
+
+int cp_model_set_precision(cp_model* m, int precision) {
+    if (!m || (precision != CP_PREC_F32 && precision != CP_PREC_F16X3)) return fail(CP_ERR_INVALID, "bad argument");
+    m->precision = precision;
+    return CP_OK;
+}
+
 int cp_model_profile(cp_model* m, int enable) {
     if (!m) return fail(CP_ERR_INVALID, "null model");
     m->profile = enable != 0;
@@ -800,7 +832,8 @@ int cp_model_forward_tap(cp_model* m, cp_stream_t stream, int B, int H, int W, c
 size_t cp_conv2d_workspace_bytes(int Cin, int Cout, int KH, int KW) {
     const size_t kpad = align_up((size_t)KH * KW * Cin, 16);
     const size_t cpad = align_up((size_t)Cout, cp_conv_tile_n(Cout));
-    return align_up(kpad * cpad * sizeof(float), 256);
+    // f32 packed weights + (split-f16 path) two binary16 copies
+    return align_up(kpad * cpad * sizeof(float), 256) + 2 * align_up(kpad * cpad * 2, 256);
 }
 
 int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const float* scale, const float* shift,
@@ -845,6 +878,17 @@ int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const flo
     p.out = out;
     p.store = CP_STORE_NHWC;
     p.ldo = Cout;
+    if (g_default_precision == CP_PREC_F16X3 && Cin % 32 == 0 && KH * KW <= 32 && bn >= 32) {
+        char* w16 = (char*)workspace + align_up((size_t)p.Kpad * p.CoutPad * sizeof(float), 256);
+        const size_t sz = align_up((size_t)p.Kpad * p.CoutPad * 2, 256);
+        if (hipMemsetAsync(w16, 0, 2 * sz, s) != hipSuccess) return CP_ERR_LAUNCH;
+        p.w16_hi = w16;
+        p.w16_lo = w16 + sz;
+        p.Kpad16 = p.K;
+        rc = cp_launch_pack_weight16(w, (void*)p.w16_hi, (void*)p.w16_lo, Cout, Cin, KH * KW, p.Kpad16, 0, s);
+        if (rc != CP_OK) return rc;
+        if (cp_conv16_supported(p)) return cp_launch_conv16(p, s);
+    }
     return cp_launch_conv(p, s);
 }
 
@@ -883,7 +927,7 @@ size_t cp_dcnv2_workspace_bytes(int B, int C, int H, int W, int Co) {
     const size_t px = (size_t)B * H * W;
     const size_t cpad = align_up((size_t)Co, cp_conv_tile_n(Co));
     return align_up(px * C * 4, 256) + align_up(px * 32 * 4, 256) + align_up(px * Co * 4, 256) +
-           align_up((size_t)9 * C * cpad * 4, 256) + align_up(cpad * 4, 256);
+           align_up((size_t)9 * C * cpad * 4, 256) + align_up(cpad * 4, 256) + 2 * align_up((size_t)9 * C * cpad * 2, 256);
 }
 
 }  // extern "C"
@@ -959,7 +1003,17 @@ extern "C" int cp_dcnv2_forward(cp_stream_t stream, const float* input, const fl
     p.store = CP_STORE_NHWC;
     p.ldo = Co;
     p.offmask = om;
-    rc = cp_launch_conv(p, s);
+    if (g_default_precision == CP_PREC_F16X3 && C % 32 == 0) {
+        char* w16 = (char*)shift + align_up((size_t)cpad * 4, 256);
+        const size_t sz = align_up((size_t)9 * C * cpad * 2, 256);
+        if (hipMemsetAsync(w16, 0, 2 * sz, s) != hipSuccess) return CP_ERR_LAUNCH;
+        p.w16_hi = w16;
+        p.w16_lo = w16 + sz;
+        p.Kpad16 = 9 * C;
+        rc = cp_launch_pack_weight16(weight, (void*)p.w16_hi, (void*)p.w16_lo, Co, C, 9, p.Kpad16, 0, s);
+        if (rc != CP_OK) return rc;
+    }
+    rc = (p.w16_hi && cp_conv16_supported(p)) ? cp_launch_conv16(p, s) : cp_launch_conv(p, s);
     if (rc != CP_OK) return rc;
     return cp_launch_nhwc_to_nchw(y_nhwc, output, B, Co, H, W, Co, s);
 }

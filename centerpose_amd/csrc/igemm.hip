@@ -17,38 +17,9 @@
 // the A slice is stored k-major in LDS (row stride padded so both the transposing ds_write_b32 and
 // the per-lane ds_read_b32 of the MFMA operand are bank-conflict free); global->register prefetch of
 // tile t+1 overlaps the MFMA block of tile t; two LDS buffers, one barrier per K-step.
-#include "cp_common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "igemm_common.h"
 
 namespace {
-
-constexpr int BK = 16;
-constexpr int NTHREADS = 256;
-
-template <int FRAG> struct Frag;
-template <> struct Frag<32> {
-    typedef f32x16 acc_t;
-    static constexpr int NACC = 16, KSTEP = 2;
-    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
-        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-    }
-    // C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    static __device__ __forceinline__ int row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
-};
-template <> struct Frag<16> {
-    typedef f32x4 acc_t;
-    static constexpr int NACC = 4, KSTEP = 4;
-    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
-        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-    }
-    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + r
-    static __device__ __forceinline__ int row(int r, int lane) { return (lane >> 4) * 4 + r; }
-};
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // Reference bilinear blend, evaluated in the reference's operation order without fused
 // multiply-adds (dcn_v2_im2col_cuda.cu:47-52: w1*v1 + w2*v2 + w3*v3 + w4*v4, then * mask :190).
@@ -88,12 +59,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void igemm_kernel(const ConvParams p, 
 
     // XCD-aware, bijective block -> tile map: block b runs on XCD b % 8; give every XCD a contiguous
     // run of tiles (n fastest) so neighbouring tiles share their input halo / weights in that XCD's L2.
-    int tile;
-    {
-        const int nt = tiles_m * tiles_n, bid = blockIdx.x;
-        const int q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    const int tile = tile_of_block(tiles_m, tiles_n);
     const int tn = tile % tiles_n, tm = tile / tiles_n;
 
     const int M = p.B * p.Ho * p.Wo;
@@ -320,58 +286,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void igemm_kernel(const ConvParams p, 
         __syncthreads();
     }
 
-    // ---- epilogue ----
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = tn * BN + wn * (NT * FRAG) + j * FRAG + lcol;
-        const float sc = p.scale ? p.scale[n] : 1.f;
-        const float sh = p.shift ? p.shift[n] : 0.f;
-        const bool n_ok = n < p.Cout;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int mbase = tm * BM + wm * (MT * FRAG) + i * FRAG;
-            float v[F::NACC];
-#pragma unroll
-            for (int r = 0; r < F::NACC; ++r) {
-                const int m = mbase + F::row(r, lane);
-                float y = acc[i][j][r] * sc + sh;
-                if (p.res && n_ok && m < M) y += p.res[(size_t)m * p.res_ld + n];
-                if (p.act == CP_ACT_RELU) y = fmaxf(y, 0.f);
-                else if (p.act == CP_ACT_SIGMOID || (p.act == CP_ACT_SIGMOID_FROM && n >= p.act_from))
-                    y = 1.f / (1.f + expf(-y));
-                v[r] = y;
-            }
-            if (!n_ok) continue;
-            if (p.store == CP_STORE_NHWC) {
-#pragma unroll
-                for (int r = 0; r < F::NACC; ++r) {
-                    const int m = mbase + F::row(r, lane);
-                    if (m < M) p.out[(size_t)m * p.ldo + p.coff + n] = v[r];
-                }
-            } else {
-                // NCHW: rows r..r+3 of one register quad are 4 consecutive pixels
-#pragma unroll
-                for (int r4 = 0; r4 < F::NACC; r4 += 4) {
-                    const int m = mbase + F::row(r4, lane);
-                    if (m >= M) continue;
-                    const int b = m / HWo, pix = m - b * HWo;
-                    float* o = p.out + ((size_t)b * p.ldo + p.coff + n) * HWo + pix;
-                    if ((HWo & 3) == 0 && m + 3 < M) {
-                        *reinterpret_cast<float4*>(o) = make_float4(v[r4], v[r4 + 1], v[r4 + 2], v[r4 + 3]);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int mq = m + q;
-                            if (mq < M) {
-                                const int bq = mq / HWo, pq = mq - bq * HWo;
-                                p.out[((size_t)bq * p.ldo + p.coff + n) * HWo + pq] = v[r4 + q];
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
+    igemm_epilogue<FRAG, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane);
 }
 
 template <int FRAG, int MT, int NT, int WM, int WN, bool DCN, bool ALIGNED, bool MULTISRC>
@@ -424,13 +339,16 @@ int cp_conv_variant(const ConvParams& p) {
 }
 
 const char* cp_conv_variant_name(int v) {
-    static const char* names[14] = {
+    static const char* names[22] = {
         "igemm_f32_16x16x4_m256n16", "igemm_f32_32x32x2_m256n32", "igemm_f32_32x32x2_m128n64",
         "igemm_f32_32x32x2_m128n128", "dcn_igemm_f32_32x32x2_m128n64", "dcn_igemm_f32_32x32x2_m128n128",
         "igemm_cat_f32_16x16x4_m256n16", "igemm_cat_f32_32x32x2_m256n32", "igemm_cat_f32_32x32x2_m128n64",
         "igemm_cat_f32_32x32x2_m128n128", "igemm_unaligned_f32_16x16x4_m256n16", "igemm_unaligned_f32_32x32x2_m256n32",
-        "igemm_unaligned_f32_32x32x2_m128n64", "igemm_unaligned_f32_32x32x2_m128n128"};
-    return (v >= 0 && v < 14) ? names[v] : "?";
+        "igemm_unaligned_f32_32x32x2_m128n64", "igemm_unaligned_f32_32x32x2_m128n128",
+        "igemm16_f16x3_m128n32", "igemm16_f16x3_m128n64", "igemm16_f16x3_m128n128", "dcn_igemm16_f16x3_m128n64",
+        "dcn_igemm16_f16x3_m128n128", "igemm16_cat_f16x3_m128n32", "igemm16_cat_f16x3_m128n64",
+        "igemm16_cat_f16x3_m128n128"};
+    return (v >= 0 && v < 22) ? names[v] : "?";
 }
 
 int cp_launch_conv(const ConvParams& p, hipStream_t stream) {

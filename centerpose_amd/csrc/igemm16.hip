@@ -1,0 +1,345 @@
+// Implicit-GEMM convolution / fused DCNv2 on the gfx950 f16 matrix cores with float32-class accuracy:
+// every float32 operand x is split into two binary16 numbers x = hi + lo (hi = rtz16(x), lo = rtz16(x - hi),
+// |lo| < 2^-10 |x|) and each product is evaluated as  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  with float32
+// accumulation inside v_mfma_f32_32x32x16_f16 (the dropped a_lo*b_lo term is < 2^-20 relative).  Three f16 MFMAs
+// replace one f32 MFMA that has 1/16 of the rate, so the matrix ceiling rises from 157 TFLOP/s (exact-f32
+// MFMA, igemm.hip) to 2.5 PFLOP/s / 3 = 833 TFLOP/s of algorithmic FLOPs, while activations, weights at the
+// boundary, accumulation and every epilogue stay float32.  Measured end-to-end error vs the reference graph is
+// reported by tests/ and DESIGN.md (budget 1e-3 on heat-maps).
+//
+// Same GEMM view, tile map, K-walk and epilogue as igemm.hip.  Differences that follow from the MFMA shape:
+//   * operand fragments are 8 consecutive k per lane (A[m = lane%32][k = 8*(lane/32) .. +7]), so both tiles live
+//     in LDS row-major with k contiguous ([m][k] / [n][k]); the NHWC float4 a lane loads IS 4 consecutive k of one
+//     pixel, so the A tile needs no transpose; rows are padded 64 -> 80 bytes which makes every ds_read_b128
+//     lane group hit 16 distinct 16-byte slots (conflict-free);
+//   * weights are split and packed once at model load as [co][tap][ci] binary16 pairs (hi / lo arrays);
+//   * BK = 32 (two 32x32x16 MFMA k-steps per LDS tile).
+// Requirements: every source's channel count % 32 == 0 (all DLA-34 layers except the 16-channel stem levels,
+// which stay on the exact-f32 kernel).
+#include "igemm_common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BK16 = 32;
+constexpr int LDH = 40;  // halfs per LDS row: 32 data + 8 pad (80 bytes)
+constexpr int NT16 = 256;
+
+struct Split2 {
+    uint32_t hi, lo;  // two binary16 values each
+};
+
+__device__ __forceinline__ uint32_t pk(float a, float b) {
+    fp16x2 v = __builtin_amdgcn_cvt_pkrtz(a, b);
+    return *reinterpret_cast<uint32_t*>(&v);
+}
+
+// (a, b) -> packed hi halves and packed lo halves
+__device__ __forceinline__ Split2 split2(float a, float b) {
+    Split2 s;
+    fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    s.hi = *reinterpret_cast<uint32_t*>(&h);
+    const float ra = a - (float)h.x, rb = b - (float)h.y;
+    s.lo = pk(ra, rb);
+    return s;
+}
+
+template <int MT, int NT, int WM, int WN, bool DCN, bool MULTISRC>
+__global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
+    typedef Frag<32> F;
+    typedef F::acc_t acc_t;
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+    static_assert(WM * WN * 64 == NT16, "4 waves");
+    constexpr int A_SLOTS = BM * BK16 / 4 / NT16;          // float4 per thread per K-step
+    constexpr int B_CHUNKS = BN * BK16 * 2 / 16;            // 16-byte chunks per array (hi or lo)
+    constexpr int B_SLOTS = (B_CHUNKS + NT16 - 1) / NT16;   // per array
+    constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;         // halfs per array per buffer
+    constexpr int BUF = 2 * A_SZ + 2 * B_SZ;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int tile = tile_of_block(tiles_m, tiles_n);
+    const int tn = tile % tiles_n, tm = tile / tiles_n;
+    const int M = p.B * p.Ho * p.Wo;
+    const int HWo = p.Ho * p.Wo;
+
+    // ---- per-thread A-slot geometry: slot j covers pixel row (tid / 8) + 32 * j, float4 column tid % 8 ----
+    const int k4 = tid & 7;
+    int a_b[A_SLOTS], a_h0[A_SLOTS], a_w0[A_SLOTS], a_pix0[A_SLOTS];
+    unsigned a_vmask[A_SLOTS];
+    bool a_ok[A_SLOTS];
+#pragma unroll
+    for (int j = 0; j < A_SLOTS; ++j) {
+        const int m = tm * BM + (tid >> 3) + j * 32;
+        a_ok[j] = m < M;
+        const int mm = a_ok[j] ? m : 0;
+        const int b = mm / HWo, rem = mm - b * HWo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        a_b[j] = b;
+        a_h0[j] = ho * p.stride - p.pad;
+        a_w0[j] = wo * p.stride - p.pad;
+        a_pix0[j] = (b * p.H + a_h0[j]) * p.W + a_w0[j];
+        unsigned vm = 0u;
+        if (!DCN && a_ok[j]) {
+            for (int kh = 0; kh < p.KH; ++kh)
+                for (int kw = 0; kw < p.KW; ++kw) {
+                    const int hi = a_h0[j] + kh, wi = a_w0[j] + kw;
+                    if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) vm |= 1u << (kh * p.KW + kw);
+                }
+        }
+        a_vmask[j] = vm;
+    }
+
+    float4 a_reg[A_SLOTS];
+    u32x4 bh_reg[B_SLOTS], bl_reg[B_SLOTS];
+    int u_tap = 0, u_kh = 0, u_kw = 0, u_c0 = 0, u_src = 0, u_cs = 0;
+    int d_idx[DCN ? A_SLOTS : 1][4];
+    float d_w[DCN ? A_SLOTS : 1][4];
+
+    // weights: [CoutPad][Kpad16] binary16, k contiguous; chunk f -> row n = f / 4, 16-byte column f % 4
+    const _Float16* wh = reinterpret_cast<const _Float16*>(p.w16_hi);
+    const _Float16* wl = reinterpret_cast<const _Float16*>(p.w16_lo);
+    size_t b_off[B_SLOTS];
+#pragma unroll
+    for (int j = 0; j < B_SLOTS; ++j) {
+        const int f = tid + j * NT16;
+        b_off[j] = (size_t)(tn * BN + f / 4) * p.Kpad16 + (f % 4) * 8;
+    }
+
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < B_SLOTS; ++j) {
+            const int f = tid + j * NT16;
+            if (B_CHUNKS % NT16 == 0 || f < B_CHUNKS) {
+                bh_reg[j] = *reinterpret_cast<const u32x4*>(wh + b_off[j]);
+                bl_reg[j] = *reinterpret_cast<const u32x4*>(wl + b_off[j]);
+                b_off[j] += BK16;
+            }
+        }
+        if (!DCN) {
+            const float* base = p.src[0];
+            int sc = p.src_c[0];
+            if (MULTISRC) {
+                if (u_src == 1) { base = p.src[1]; sc = p.src_c[1]; }
+                else if (u_src == 2) { base = p.src[2]; sc = p.src_c[2]; }
+                else if (u_src == 3) { base = p.src[3]; sc = p.src_c[3]; }
+            }
+            const int tap_pix = u_kh * p.W + u_kw;
+            const int coff = u_cs + k4 * 4;
+            const unsigned bit = 1u << u_tap;
+#pragma unroll
+            for (int j = 0; j < A_SLOTS; ++j) {
+                const long long off = (long long)(a_pix0[j] + tap_pix) * sc + coff;
+                a_reg[j] = (a_vmask[j] & bit) ? ld4(base + off) : zero4();
+            }
+        } else {
+            const float* base = p.src[0];
+            const int C = p.Cin;
+            if (u_c0 == 0) {
+#pragma unroll
+                for (int j = 0; j < A_SLOTS; ++j) {
+                    int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
+                    float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+                    if (a_ok[j]) {
+                        const size_t pix = (size_t)(a_b[j] * p.H + (a_h0[j] + p.pad)) * p.W + (a_w0[j] + p.pad);
+                        const float* om = p.offmask + pix * 32;
+                        const float dh = om[2 * u_tap], dw = om[2 * u_tap + 1], mk = om[18 + u_tap];
+                        const float h_im = (float)(a_h0[j] + u_kh) + dh;
+                        const float w_im = (float)(a_w0[j] + u_kw) + dw;
+                        if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
+                            const int h_lo = (int)floorf(h_im), w_lo = (int)floorf(w_im);
+                            const int h_hi = h_lo + 1, w_hi = w_lo + 1;
+                            const float lh = h_im - (float)h_lo, lw = w_im - (float)w_lo;
+                            const float hh = 1.f - lh, hw = 1.f - lw;
+                            const int bb = a_b[j] * p.H;
+                            if (h_lo >= 0 && w_lo >= 0) i0 = (bb + h_lo) * p.W + w_lo;
+                            if (h_lo >= 0 && w_hi <= p.W - 1) i1 = (bb + h_lo) * p.W + w_hi;
+                            if (h_hi <= p.H - 1 && w_lo >= 0) i2 = (bb + h_hi) * p.W + w_lo;
+                            if (h_hi <= p.H - 1 && w_hi <= p.W - 1) i3 = (bb + h_hi) * p.W + w_hi;
+                            w1 = hh * hw * mk; w2 = hh * lw * mk; w3 = lh * hw * mk; w4 = lh * lw * mk;
+                        }
+                    }
+                    d_idx[j][0] = i0; d_idx[j][1] = i1; d_idx[j][2] = i2; d_idx[j][3] = i3;
+                    d_w[j][0] = w1; d_w[j][1] = w2; d_w[j][2] = w3; d_w[j][3] = w4;
+                }
+            }
+            const int coff = u_c0 + k4 * 4;
+#pragma unroll
+            for (int j = 0; j < A_SLOTS; ++j) {
+                float4 v1 = zero4(), v2 = zero4(), v3 = zero4(), v4 = zero4();
+                if (d_idx[j][0] >= 0) v1 = ld4(base + (long long)d_idx[j][0] * C + coff);
+                if (d_idx[j][1] >= 0) v2 = ld4(base + (long long)d_idx[j][1] * C + coff);
+                if (d_idx[j][2] >= 0) v3 = ld4(base + (long long)d_idx[j][2] * C + coff);
+                if (d_idx[j][3] >= 0) v4 = ld4(base + (long long)d_idx[j][3] * C + coff);
+                const float w1 = d_w[j][0], w2 = d_w[j][1], w3 = d_w[j][2], w4 = d_w[j][3];
+                float4 v;
+                v.x = fmaf(w4, v4.x, fmaf(w3, v3.x, fmaf(w2, v2.x, w1 * v1.x)));
+                v.y = fmaf(w4, v4.y, fmaf(w3, v3.y, fmaf(w2, v2.y, w1 * v1.y)));
+                v.z = fmaf(w4, v4.z, fmaf(w3, v3.z, fmaf(w2, v2.z, w1 * v1.z)));
+                v.w = fmaf(w4, v4.w, fmaf(w3, v3.w, fmaf(w2, v2.w, w1 * v1.w)));
+                a_reg[j] = v;
+            }
+        }
+        // advance the wave-uniform K walk by one 32-wide step
+        u_c0 += BK16;
+        u_cs += BK16;
+        if (u_c0 >= p.Cin) {
+            u_c0 = 0; u_cs = 0; u_src = 0;
+            ++u_tap;
+            if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
+        } else if (MULTISRC) {
+            const int cur = u_src == 0 ? p.src_c[0] : u_src == 1 ? p.src_c[1] : u_src == 2 ? p.src_c[2] : p.src_c[3];
+            if (u_cs >= cur) { u_cs = 0; ++u_src; }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        _Float16* Ah = lds + buf * BUF;
+        _Float16* Al = Ah + A_SZ;
+        _Float16* Bh = Al + A_SZ;
+        _Float16* Bl = Bh + B_SZ;
+#pragma unroll
+        for (int j = 0; j < A_SLOTS; ++j) {
+            const int row = (tid >> 3) + j * 32;
+            const Split2 s0 = split2(a_reg[j].x, a_reg[j].y), s1 = split2(a_reg[j].z, a_reg[j].w);
+            *reinterpret_cast<u32x2*>(Ah + row * LDH + k4 * 4) = u32x2{s0.hi, s1.hi};
+            *reinterpret_cast<u32x2*>(Al + row * LDH + k4 * 4) = u32x2{s0.lo, s1.lo};
+        }
+#pragma unroll
+        for (int j = 0; j < B_SLOTS; ++j) {
+            const int f = tid + j * NT16;
+            if (B_CHUNKS % NT16 == 0 || f < B_CHUNKS) {
+                const int n = f / 4, c = f % 4;
+                *reinterpret_cast<u32x4*>(Bh + n * LDH + c * 8) = bh_reg[j];
+                *reinterpret_cast<u32x4*>(Bl + n * LDH + c * 8) = bl_reg[j];
+            }
+        }
+    };
+
+    acc_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < F::NACC; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.Kpad16 / BK16;
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+
+    const int lrow = lane >> 5;  // which 8-wide k group of the 16-deep MFMA step
+    const int lcol = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile();
+        const _Float16* Ah = lds + buf * BUF + (wm * (MT * 32) + lcol) * LDH + lrow * 8;
+        const _Float16* Al = Ah + A_SZ;
+        const _Float16* Bh = lds + buf * BUF + 2 * A_SZ + (wn * (NT * 32) + lcol) * LDH + lrow * 8;
+        const _Float16* Bl = Bh + B_SZ;
+#pragma unroll
+        for (int ks = 0; ks < BK16 / 16; ++ks) {
+            h8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ah[i] = *reinterpret_cast<const h8*>(Ah + i * 32 * LDH + ks * 16);
+                al[i] = *reinterpret_cast<const h8*>(Al + i * 32 * LDH + ks * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bh[j] = *reinterpret_cast<const h8*>(Bh + j * 32 * LDH + ks * 16);
+                bl[j] = *reinterpret_cast<const h8*>(Bl + j * 32 * LDH + ks * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    igemm_epilogue<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane);
+}
+
+template <int MT, int NT, int WM, int WN, bool DCN, bool MULTISRC>
+int launch16(const ConvParams& p, hipStream_t stream) {
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+    const int M = p.B * p.Ho * p.Wo;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = p.CoutPad / BN;
+    if (p.CoutPad % BN != 0 || p.Kpad16 % BK16 != 0) return CP_ERR_INVALID;
+    hipLaunchKernelGGL((igemm16_kernel<MT, NT, WM, WN, DCN, MULTISRC>), dim3(tiles_m * tiles_n), dim3(NT16), 0, stream,
+                       p, tiles_m, tiles_n);
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}
+
+// pack PyTorch [Cout][Cin][taps] float32 weights into split binary16 [CoutPad][Kpad16] (k = tap*Cin + ci)
+__global__ void pack_weight16_kernel(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                     int Cout, int Cin, int taps, int Kpad16, int coff) {
+    const size_t total = (size_t)Cout * Cin * taps;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % taps);
+        const size_t r = i / taps;
+        const int ci = (int)(r % Cin), co = (int)(r / Cin);
+        const float x = w[i];
+        const Split2 s = split2(x, 0.f);
+        const size_t o = (size_t)(coff + co) * Kpad16 + (size_t)t * Cin + ci;
+        reinterpret_cast<uint16_t*>(hi)[o] = (uint16_t)(s.hi & 0xffffu);
+        reinterpret_cast<uint16_t*>(lo)[o] = (uint16_t)(s.lo & 0xffffu);
+    }
+}
+
+}  // namespace
+
+bool cp_conv16_supported(const ConvParams& p) {
+    if (!p.w16_hi || !p.w16_lo || p.Cin % BK16 != 0 || p.KH * p.KW > 32) return false;
+    for (int s = 0; s < p.nsrc; ++s)
+        if (p.src_c[s] % BK16 != 0) return false;
+    const int bn = cp_conv_tile_n(p.Cout);
+    if (bn < 32) return false;
+    if (p.offmask && bn < 64) return false;
+    return true;
+}
+
+int cp_launch_conv16(const ConvParams& p, hipStream_t stream) {
+    if (!cp_conv16_supported(p)) return CP_ERR_INVALID;
+    const int bn = cp_conv_tile_n(p.Cout);
+    const bool cat = p.nsrc > 1;
+    if (p.offmask) {
+        if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.nsrc != 1 || p.H != p.Ho || p.W != p.Wo)
+            return CP_ERR_INVALID;
+        return bn == 128 ? launch16<2, 2, 2, 2, true, false>(p, stream) : launch16<2, 1, 2, 2, true, false>(p, stream);
+    }
+    if (bn == 128) return cat ? launch16<2, 2, 2, 2, false, true>(p, stream) : launch16<2, 2, 2, 2, false, false>(p, stream);
+    if (bn == 64) return cat ? launch16<2, 1, 2, 2, false, true>(p, stream) : launch16<2, 1, 2, 2, false, false>(p, stream);
+    return cat ? launch16<1, 1, 4, 1, false, true>(p, stream) : launch16<1, 1, 4, 1, false, false>(p, stream);
+}
+
+// kernel-variant ids continue after the exact-f32 ones (cp_conv_variant): 14.. = split-f16 instantiations
+int cp_conv16_variant(const ConvParams& p) {
+    const int bn = cp_conv_tile_n(p.Cout);
+    if (p.offmask) return bn == 128 ? 18 : 17;
+    const int t = bn == 32 ? 0 : bn == 64 ? 1 : 2;
+    return (p.nsrc > 1 ? 19 : 14) + t;
+}
+
+int cp_launch_pack_weight16(const float* w, void* hi, void* lo, int Cout, int Cin, int taps, int Kpad16, int coff,
+                            hipStream_t s) {
+    const size_t n = (size_t)Cout * Cin * taps;
+    int g = (int)((n + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(pack_weight16_kernel, dim3(g), dim3(256), 0, s, w, (_Float16*)hi, (_Float16*)lo, Cout, Cin, taps,
+                       Kpad16, coff);
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}

@@ -57,6 +57,8 @@ def lib():
     _sig(L.cp_decode_workspace_bytes, c_size_t, c_int, c_int)
     _sig(L.cp_decode, c_int, c_void_p, c_int, c_int, c_int, *([c_void_p] * 11), c_int, c_int, c_int, ctypes.c_float,
          c_int, c_int, c_void_p, c_void_p, c_size_t)
+    _sig(L.cp_set_default_precision, c_int, c_int)
+    _sig(L.cp_model_set_precision, c_int, c_void_p, c_int)
     _sig(L.cp_model_profile, c_int, c_void_p, c_int)
     _sig(L.cp_model_profile_read, c_int, c_void_p, ctypes.POINTER(ctypes.c_double), c_int)
     _sig(L.cp_kernel_variant_name, c_char_p, c_int)
@@ -72,7 +74,7 @@ def exported_symbols():
             "cp_model_set_param", "cp_model_finalize", "cp_model_destroy", "cp_model_workspace_bytes",
             "cp_model_forward", "cp_model_forward_tap", "cp_conv2d_workspace_bytes", "cp_conv2d_nhwc",
             "cp_decode_workspace_bytes", "cp_decode", "cp_pnp_workspace_bytes", "cp_pnp_solve", "cp_model_profile", "cp_model_profile_read",
-            "cp_kernel_variant_name"]
+            "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision"]
 
 
 def _check(rc, what):
@@ -128,6 +130,14 @@ def conv2d_nhwc(x, w, scale=None, shift=None, residual=None, stride=1, pad=0, ac
                           B, H, W, Cin, Cout, KH, KW, stride, pad, act, _ptr(ws), nbytes)
     _check(rc, "cp_conv2d_nhwc")
     return out
+
+
+PRECISIONS = {"f32": 0, "f16x3": 1}
+
+
+def set_default_precision(name):
+    """'f32' (exact float32 MFMA) or 'f16x3' (split-binary16 MFMA, float32-class accuracy)."""
+    _check(lib().cp_set_default_precision(PRECISIONS[name]), "cp_set_default_precision")
 
 
 DET_FIELDS = OrderedDict([  # field -> (offset, width) inside a 118-float detection record (decode.py:347-361)
@@ -192,7 +202,7 @@ def pnp_solve(pts, scale, cam):
 class HipModel(object):
     """Device-resident DLA-34 / DLA-34+ConvGRU network built from a reference-format state dict."""
 
-    def __init__(self, arch, heads, state_dict, tracking_task=False, head_conv=256):
+    def __init__(self, arch, heads, state_dict, tracking_task=False, head_conv=256, precision=None):
         L = lib()
         self.arch = arch
         self.heads = OrderedDict(heads)
@@ -211,6 +221,8 @@ class HipModel(object):
             t = v.detach().cpu().contiguous().float()
             _check(L.cp_model_set_param(h, k.encode(), c_void_p(t.data_ptr()), t.numel()), "cp_model_set_param")
         _check(L.cp_model_finalize(h), "cp_model_finalize")
+        if precision is not None:
+            self.set_precision(precision)
         self._ws = None
         self._ws_key = None
 
@@ -222,13 +234,17 @@ class HipModel(object):
         except Exception:
             pass
 
+    def set_precision(self, name):
+        _check(lib().cp_model_set_precision(self._h, PRECISIONS[name]), "cp_model_set_precision")
+        self.precision = name
+
     def profile(self, enable=True):
         """Arm / disarm per-launch HIP-event timing of the implicit-GEMM kernels."""
         _check(lib().cp_model_profile(self._h, int(bool(enable))), "cp_model_profile")
 
     def profile_read(self):
         """-> {kernel name: dict(launches, ms, flops, bytes)} accumulated since the last read."""
-        nv = 14
+        nv = 22
         buf = (ctypes.c_double * (nv * 4))()
         _check(lib().cp_model_profile_read(self._h, buf, nv), "cp_model_profile_read")
         out = OrderedDict()

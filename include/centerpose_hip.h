@@ -86,13 +86,26 @@ int cp_model_forward_tap(cp_model* m, cp_stream_t stream, int B, int H, int W, c
                          int sigmoid_hm, void* workspace, size_t workspace_bytes, const char* tap_name,
                          float* tap_out, int* tap_dims);
 
+/* Arithmetic of the convolution / DCNv2 contractions (activations, weights at the boundary, accumulation and
+ * epilogues are float32 in both modes):
+ *   CP_PREC_F32   (0) exact float32 matrix instructions (v_mfma_f32_32x32x2_f32), 157 TFLOP/s ceiling
+ *   CP_PREC_F16X3 (1) every float32 operand split into two binary16 numbers, products evaluated as
+ *                     hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with float32 accumulation (relative product
+ *                     error < 2^-20), 833 TFLOP/s ceiling; layers whose channel counts are not multiples of 32
+ *                     (the 16-channel stem levels, final 1x1 heads) stay on the exact path.
+ * cp_set_default_precision affects models created afterwards and the stand-alone cp_conv2d_nhwc / cp_dcnv2_forward. */
+#define CP_PREC_F32 0
+#define CP_PREC_F16X3 1
+int cp_set_default_precision(int precision);
+int cp_model_set_precision(cp_model* m, int precision);
+
 /* Per-launch timing of the implicit-GEMM kernels with HIP events recorded on the launch stream
  * (replaces the reference's wall-clock `torch.cuda.synchronize()` fences, base_detector.py:466-498).
  * cp_model_profile(m, 1) arms it; every conv / DCN launch of later forwards is bracketed by an event
  * pair.  cp_model_profile_read drains them: out[v*4 + 0..3] = {launches, total milliseconds, total
  * algorithmic FLOPs (2*M*Cout*KH*KW*Cin), total algorithmic bytes (input + output + weights
  * [+ offsets/mask] [+ residual], float32)} per kernel variant v in [0, CP_NUM_KERNEL_VARIANTS). */
-#define CP_NUM_KERNEL_VARIANTS 14
+#define CP_NUM_KERNEL_VARIANTS 22
 int cp_model_profile(cp_model* m, int enable);
 int cp_model_profile_read(cp_model* m, double* out, int num_variants);
 const char* cp_kernel_variant_name(int v);

@@ -94,14 +94,52 @@ def test_dcn_rejects_unsupported(device):
                            3, 3, 1, 1, 1, 1, 1, 1, 2)  # deformable_group 2
 
 
+@pytest.fixture(params=["f32", "f16x3"])
+def precision(request):
+    """Both arithmetic modes of the contraction kernels (centerpose_hip.h: CP_PREC_*)."""
+    hip.set_default_precision(request.param)
+    yield request.param
+    hip.set_default_precision("f32")
+
+
+@pytest.mark.parametrize("Cin,Cout,k,s,res", [(32, 64, 3, 2, False), (64, 256, 3, 1, True), (128, 128, 3, 1, True),
+                                              (448, 128, 1, 1, False), (64, 27, 3, 1, False), (64, 192, 3, 1, False)])
+def test_conv_both_precisions_vs_float64(device, precision, Cin, Cout, k, s, res):
+    """Split-binary16 products must stay float32-class: error vs a float64 convolution <= 2e-5 of the output range
+    (observed ~3e-6 for f32, ~6e-6 for f16x3)."""
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(2, Cin, 20, 24, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    y = F.conv2d(x.double(), w.double(), None, s, k // 2)
+    r = torch.randn(y.shape, generator=g) if res else None
+    ref = (y + r.double()) if res else y
+    out = hip.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(device), w.to(device), None, None,
+                          r.permute(0, 2, 3, 1).contiguous().to(device) if res else None, s, k // 2, 0)
+    err = float((out.permute(0, 3, 1, 2).cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err
+
+
+def test_dcn_both_precisions_vs_oracle(device, precision):
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(2, 64, 24, 20, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(128, generator=g)
+    off = torch.randn(2, 18, 24, 20, generator=g) * 2.5
+    mask = torch.rand(2, 9, 24, 20, generator=g)
+    ref = odcn.dcn_v2_forward_f64(x, w, b, off, mask)
+    out = hip.dcn_v2_forward(*(t.to(device) for t in (x, w, b, off, mask)), 3, 3, 1, 1, 1, 1, 1, 1, 1).cpu()
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("arch,tracking", CONFIGS)
-def test_backbone_vs_reference_golden(device, arch, tracking):
-    """Head tensors against the REFERENCE modules' outputs (tests/golden/backbone_*.npz)."""
+def test_backbone_vs_reference_golden(device, arch, tracking, prec):
+    """Head tensors against the REFERENCE modules' outputs (tests/golden/backbone_*.npz), both arithmetic modes."""
     heads = synth.HEADS_TRACK if tracking else synth.HEADS_POSE
     gold = np.load(os.path.join(GOLD, "backbone_%s.npz" % synth.config_key(arch, tracking)))
     sd = synth.make_state_dict(arch, heads, tracking)
     x, kw = mg.backbone_inputs(tracking)
-    model = hip.HipModel(arch, heads, sd, tracking_task=tracking)
+    model = hip.HipModel(arch, heads, sd, tracking_task=tracking, precision=prec)
     z = model(x.to(device), **{k: v.to(device) for k, v in kw.items()})
     for k in heads:
         ref = gold[k]
@@ -110,12 +148,13 @@ def test_backbone_vs_reference_golden(device, arch, tracking):
         np.testing.assert_allclose(torch.sigmoid(z[k]).cpu().numpy(), 1 / (1 + np.exp(-gold[k])), rtol=0, atol=1e-3)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("arch", ["dla_34", "dlav1_34"])
-def test_backbone_512_vs_oracle_and_batch_invariance(device, arch):
+def test_backbone_512_vs_oracle_and_batch_invariance(device, arch, prec):
     heads = synth.HEADS_POSE
     sd = synth.make_state_dict(arch, heads)
     x = synth.frames(3, seed=23)
-    model = hip.HipModel(arch, heads, sd)
+    model = hip.HipModel(arch, heads, sd, precision=prec)
     z = model(x.to(device), sigmoid_hm=True)
     zo = ob.dlaseg_forward(sd, x[1:2], heads, arch=arch.split("_")[0])
     assert float((z["hm"][1:2].cpu() - torch.sigmoid(zo["hm"])).abs().max()) < 1e-3

@@ -42,7 +42,7 @@ def test_argument_validation_without_gpu(built):
     # sizes are pure host arithmetic
     assert built.cp_decode_workspace_bytes(32, 100) >= 32 * 9 * 100 * 8
     assert built.cp_pnp_workspace_bytes(10) >= 10 * 288 * 8
-    assert built.cp_conv2d_workspace_bytes(64, 64, 3, 3) == 576 * 64 * 4
+    assert built.cp_conv2d_workspace_bytes(64, 64, 3, 3) >= 576 * 64 * 4
 
 
 def test_no_cpu_fallback(built):

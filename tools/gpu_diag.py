@@ -18,6 +18,7 @@ from oracle import dcn as odcn  # noqa: E402
 
 dev = torch.device("cuda:0")
 results = []
+CONV_TOL = 2e-5
 
 
 def report(name, got, ref, tol):
@@ -57,7 +58,22 @@ def conv_case(B, H, W, Cin, Cout, k, stride, pad, act=0, res=False, affine=True,
                           stride, pad, act)
     torch.cuda.synchronize()
     name = "conv B%d %dx%d %d->%d k%d s%d p%d act%d res%d aff%d" % (B, H, W, Cin, Cout, k, stride, pad, act, res, affine)
-    return report(name, out.permute(0, 3, 1, 2), y, 2e-5)
+    return report(name, out.permute(0, 3, 1, 2), y, CONV_TOL)
+
+
+def small_value_case():
+    """Activations of magnitude 1e-3 .. 1e-5: the binary16 'lo' halves become subnormal; checks they are not flushed."""
+    g = torch.Generator().manual_seed(5)
+    for mag in (1e-3, 1e-5):
+        x = torch.randn(1, 64, 16, 16, generator=g) * mag
+        w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+        y = F.conv2d(x.double(), w.double(), None, 1, 1).float()
+        out = hip.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), w.to(dev), None, None, None, 1, 1, 0)
+        torch.cuda.synchronize()
+        o = out.permute(0, 3, 1, 2).cpu()
+        rel = float((o - y).abs().max() / y.abs().max())
+        results.append(("small", rel, mag, rel > 1e-4))
+        print("%-58s rel err %.3e %s" % ("conv small activations |x|~%g" % mag, rel, "FAIL" if rel > 1e-4 else "ok"), flush=True)
 
 
 def dcn_case(B, C, Co, H, W, off_std, seed=0, kat=None):
@@ -73,10 +89,10 @@ def dcn_case(B, C, Co, H, W, off_std, seed=0, kat=None):
     ref = odcn.dcn_v2_forward(x, w, b, off, mask, 3, 3, 1, 1, 1, 1, 1, 1, 1)
     out = hip.dcn_v2_forward(x.to(dev), w.to(dev), b.to(dev), off.to(dev), mask.to(dev), 3, 3, 1, 1, 1, 1, 1, 1, 1)
     torch.cuda.synchronize()
-    ok = report("dcn B%d C%d->%d %dx%d off_std %.1f %s" % (B, C, Co, H, W, off_std, kat or ""), out, ref, 2e-5)
+    ok = report("dcn B%d C%d->%d %dx%d off_std %.1f %s" % (B, C, Co, H, W, off_std, kat or ""), out, ref, CONV_TOL)
     if kat == "zero_offset":
         ref2 = 0.5 * F.conv2d(x, w, None, 1, 1) + b.view(1, -1, 1, 1)
-        report("   ... vs 0.5*conv2d+bias KAT", out, ref2, 2e-5)
+        report("   ... vs 0.5*conv2d+bias KAT", out, ref2, CONV_TOL)
     return ok
 
 
@@ -225,6 +241,11 @@ def timing(model, B, res=512, iters=5):
 
 def main():
     full = "--full" in sys.argv
+    global CONV_TOL
+    if "--f16x3" in sys.argv:
+        hip.set_default_precision("f16x3")
+        CONV_TOL = 2e-5  # split-binary16 products: < 2^-20 relative each
+        print("precision: f16x3")
     print(hip.lib().cp_version().decode(), torch.cuda.get_device_name(0), flush=True)
     # --- implicit-GEMM conv: every tile config, strides, kernel sizes, ragged M, residual, acts ---
     conv_case(1, 8, 8, 16, 16, 3, 1, 1)             # FRAG16 path, tiny (ragged M)
@@ -239,6 +260,11 @@ def main():
     conv_case(1, 16, 16, 64, 27, 3, 1, 1, affine=False)   # offset-conv-like N=27 (padded to 32)
     conv_case(1, 16, 16, 256, 8, 1, 1, 0, affine=False)   # head-final-like N=8
     conv_case(1, 20, 20, 32, 16, 3, 1, 1, act=1)    # ragged M with FRAG16
+    conv_case(2, 16, 16, 32, 64, 3, 1, 1, act=1)    # Cin = 32 (one f16x3 K-step per tap)
+    conv_case(1, 16, 16, 128, 128, 3, 1, 1, act=1, res=True)
+    conv_case(1, 8, 8, 256, 512, 3, 2, 1)
+    conv_case(1, 16, 16, 64, 27, 3, 1, 1, affine=False, seed=3)
+    small_value_case()
     # --- DCNv2 ---
     dcn_case(2, 16, 64, 4, 4, 0.0, kat="zero_offset")
     dcn_case(2, 64, 64, 16, 16, 0.0, kat="zero_offset")
