@@ -48,7 +48,9 @@ __device__ __forceinline__ Split2 split2(float a, float b) {
     return s;
 }
 
-template <int MT, int NT, int WM, int WN, bool DCN, bool MULTISRC>
+// PF2: two register sets for the global->LDS staging, i.e. tile t+2 is in flight while tile t is multiplied (a
+// 32-deep K-step is only ~770 MFMA cycles per wave, shorter than an L2 round trip under load).
+template <int MT, int NT, int WM, int WN, bool DCN, bool MULTISRC, bool PF2>
 __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
@@ -97,8 +99,8 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
         a_vmask[j] = vm;
     }
 
-    float4 a_reg[A_SLOTS];
-    u32x4 bh_reg[B_SLOTS], bl_reg[B_SLOTS];
+    float4 a_reg0[A_SLOTS], a_reg1[PF2 ? A_SLOTS : 1];
+    u32x4 bh_reg0[B_SLOTS], bl_reg0[B_SLOTS], bh_reg1[PF2 ? B_SLOTS : 1], bl_reg1[PF2 ? B_SLOTS : 1];
     int u_tap = 0, u_kh = 0, u_kw = 0, u_c0 = 0, u_src = 0, u_cs = 0;
     int d_idx[DCN ? A_SLOTS : 1][4];
     float d_w[DCN ? A_SLOTS : 1][4];
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
         b_off[j] = (size_t)(tn * BN + f / 4) * p.Kpad16 + (f % 4) * 8;
     }
 
-    auto load_tile = [&]() {
+    auto load_tile = [&](float4* a_reg, u32x4* bh_reg, u32x4* bl_reg) {
 #pragma unroll
         for (int j = 0; j < B_SLOTS; ++j) {
             const int f = tid + j * NT16;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
         }
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const float4* a_reg, const u32x4* bh_reg, const u32x4* bl_reg) {
         _Float16* Ah = lds + buf * BUF;
         _Float16* Al = Ah + A_SZ;
         _Float16* Bh = Al + A_SZ;
@@ -232,15 +234,10 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
             for (int r = 0; r < F::NACC; ++r) acc[i][j][r] = 0.f;
 
     const int nk = p.Kpad16 / BK16;
-    load_tile();
-    store_tile(0);
-    __syncthreads();
-
     const int lrow = lane >> 5;  // which 8-wide k group of the 16-deep MFMA step
     const int lcol = lane & 31;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile();
+
+    auto mma_tile = [&](int buf) {
         const _Float16* Ah = lds + buf * BUF + (wm * (MT * 32) + lcol) * LDH + lrow * 8;
         const _Float16* Al = Ah + A_SZ;
         const _Float16* Bh = lds + buf * BUF + 2 * A_SZ + (wn * (NT * 32) + lcol) * LDH + lrow * 8;
@@ -267,20 +264,51 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+    };
+
+    if (!PF2) {
+        load_tile(a_reg0, bh_reg0, bl_reg0);
+        store_tile(0, a_reg0, bh_reg0, bl_reg0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_tile(a_reg0, bh_reg0, bl_reg0);
+            mma_tile(buf);
+            if (kt + 1 < nk) store_tile(buf ^ 1, a_reg0, bh_reg0, bl_reg0);
+            __syncthreads();
+        }
+    } else {
+        // tiles t+1 and t+2 are in registers / in flight while tile t is multiplied out of LDS
+        load_tile(a_reg0, bh_reg0, bl_reg0);
+        if (nk > 1) load_tile(a_reg1, bh_reg1, bl_reg1);
+        store_tile(0, a_reg0, bh_reg0, bl_reg0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            if (kt + 2 < nk) load_tile(a_reg0, bh_reg0, bl_reg0);           // tile kt+2 -> set 0
+            if (kt + 1 < nk) store_tile(1, a_reg1, bh_reg1, bl_reg1);       // tile kt+1 (loaded an iteration ago)
+            mma_tile(0);
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            if (kt + 3 < nk) load_tile(a_reg1, bh_reg1, bl_reg1);           // tile kt+3 -> set 1
+            if (kt + 2 < nk) store_tile(0, a_reg0, bh_reg0, bl_reg0);       // tile kt+2
+            mma_tile(1);
+            __syncthreads();
+        }
     }
     igemm_epilogue<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane);
 }
 
 template <int MT, int NT, int WM, int WN, bool DCN, bool MULTISRC>
 int launch16(const ConvParams& p, hipStream_t stream) {
+    // measured on MI355X (heads conv, B=32): PF2 233 vs 244 TFLOP/s without -> the loop is LDS-bound, not
+    // latency-bound (32 KB of ds_write + 64 KB of ds_read per 128x128x32 step); keep the single register set.
+    constexpr bool PF2 = false;
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = p.CoutPad / BN;
     if (p.CoutPad % BN != 0 || p.Kpad16 % BK16 != 0) return CP_ERR_INVALID;
-    hipLaunchKernelGGL((igemm16_kernel<MT, NT, WM, WN, DCN, MULTISRC>), dim3(tiles_m * tiles_n), dim3(NT16), 0, stream,
-                       p, tiles_m, tiles_n);
+    hipLaunchKernelGGL((igemm16_kernel<MT, NT, WM, WN, DCN, MULTISRC, PF2>), dim3(tiles_m * tiles_n), dim3(NT16), 0,
+                       stream, p, tiles_m, tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
