@@ -59,6 +59,14 @@ struct ConvParams {
     const void* w16_hi;    // split-f16 path: packed weights [CoutPad][Kpad16] binary16 (hi / lo), or nullptr
     const void* w16_lo;
     int Kpad16;
+    // GroupNorm fusion (dlav1 heads, GN.py:4-9): the producing conv accumulates per-(image, group) sum / sum of
+    // squares of its biased output into gn_stats[B][groups][2] (doubles, zeroed by the caller); the consuming 1x1
+    // conv normalises + affine + ReLU on load from gn_in_mr[B][groups] = (mean, rstd).
+    double* gn_stats;
+    int gn_groups, gn_cpg;
+    const float* gn_in_mr;
+    const float* gn_in_gamma;
+    const float* gn_in_beta;
     const float* offmask;  // DCN mode: NHWC [B,H,W,32] = 18 offsets (dh,dw interleaved per tap) + 9 masks (already sigmoided) + 5 pad
 };
 
@@ -91,6 +99,8 @@ int cp_launch_gru_gate(const float* x3, const float* h3, const float* hprev, flo
 // GroupNorm(32 groups) over NHWC [B, HW, C]: stats then in-place normalise + affine + ReLU
 int cp_launch_groupnorm_relu(float* x, const float* gamma, const float* beta, double* stats_ws, int B, int HW, int C,
                              int groups, float eps, hipStream_t s);
+// (sum, sumsq) doubles -> (mean, rstd) floats per (image, group)
+int cp_launch_gn_finalize(const double* stats, float* mr, int n, double count, float eps, hipStream_t s);
 // PyTorch [Cout][Cin][taps] weights -> packed GEMM operand (buffer must be pre-zeroed for padding)
 int cp_launch_pack_weight(const float* w, float* wp, int Cout, int Cin, int taps, int CinP, int CoutPad, int coff,
                           hipStream_t s);

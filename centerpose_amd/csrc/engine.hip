@@ -376,6 +376,11 @@ struct Fwd {
     cp_model* m;
     int B;
     hipStream_t s;
+    // GroupNorm fusion hooks for the next conv() call (reset after use)
+    double* gn_stats_out = nullptr;
+    const float* gn_in_mr = nullptr;
+    const float* gn_in_gamma = nullptr;
+    const float* gn_in_beta = nullptr;
 
     void chk(int rc) {
         if (rc != CP_OK && m->status == CP_OK) m->status = rc;
@@ -440,6 +445,15 @@ struct Fwd {
         p.act = act;
         p.act_from = act_from;
         p.offmask = offmask ? offmask->ptr() : nullptr;
+        p.gn_stats = gn_stats_out;
+        p.gn_groups = 32;
+        p.gn_cpg = w.Cout / 32 > 0 ? w.Cout / 32 : 1;
+        if (gn_in_mr) {
+            p.gn_in_mr = gn_in_mr;
+            p.gn_in_gamma = gn_in_gamma;
+            p.gn_in_beta = gn_in_beta;
+            p.gn_cpg = w.Cin / 32;
+        }
         p.w16_hi = w.w16_hi;
         p.w16_lo = w.w16_lo;
         p.Kpad16 = w.Kpad16;
@@ -481,6 +495,8 @@ struct Fwd {
                 chk(use16 ? cp_launch_conv16(p, s) : cp_launch_conv(p, s));
             }
         }
+        gn_stats_out = nullptr;
+        gn_in_mr = nullptr;
         return out;
     }
     const ConvW& cw(const std::string& k) { return m->convs.at(k); }
@@ -669,13 +685,34 @@ struct Fwd {
                 if (r < 0) continue;  // the reference leaves such heads out of z (:545-563)
                 src = &gru_out[r];
             }
-            Tensor hid = conv(hw.c0, {src}, 1, 1, m->gru ? CP_ACT_NONE : CP_ACT_RELU);
+            Tensor stats, mr;
+            const bool fuse_gn = m->gru && ((src->H * src->W) % 32 == 0) && hw.c0.Cout % 32 == 0 && (hw.c0.Cout / 32) % 4 == 0;
             if (m->gru) {
                 // GroupNorm statistics: 32 groups x (sum, sumsq) doubles per image = 128 floats per image
-                Tensor stats = make(128, 1, 1);
-                if (!m->dry)
+                stats = make(128, 1, 1);
+                mr = make(64, 1, 1);
+                if (fuse_gn) {
+                    if (!m->dry) {
+                        if (hipMemsetAsync(stats.ptr(), 0, sizeof(double) * 64 * B, s) != hipSuccess) chk(CP_ERR_LAUNCH);
+                        gn_stats_out = (double*)stats.ptr();
+                    }
+                }
+            }
+            Tensor hid = conv(hw.c0, {src}, 1, 1, m->gru ? CP_ACT_NONE : CP_ACT_RELU);
+            if (m->gru) {
+                if (fuse_gn) {
+                    // statistics came out of the conv epilogue; normalise + affine + ReLU happens in the 1x1 loader
+                    if (!m->dry) {
+                        chk(cp_launch_gn_finalize((const double*)stats.ptr(), mr.ptr(), B * 32,
+                                                  (double)hid.H * hid.W * (hid.C / 32), 1e-5f, s));
+                        gn_in_mr = mr.ptr();
+                        gn_in_gamma = hw.gn_gamma;
+                        gn_in_beta = hw.gn_beta;
+                    }
+                } else if (!m->dry) {
                     chk(cp_launch_groupnorm_relu(hid.ptr(), hw.gn_gamma, hw.gn_beta, (double*)stats.ptr(), B,
                                                  hid.H * hid.W, hid.C, 32, 1e-5f, s));
+                }
             }
             const bool sg = sigmoid_hm && (hw.name == "hm" || hw.name == "hm_hp");
             conv(hw.c1, {&hid}, 1, 0, sg ? CP_ACT_SIGMOID : CP_ACT_NONE, nullptr, nullptr, 0,

@@ -88,35 +88,43 @@ __global__ void maxpool2_kernel(const float* __restrict__ in, float* __restrict_
 __global__ void upsample_add_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                     const float* __restrict__ add, float* __restrict__ out, int B, int H, int W, int C,
                                     int f) {
-    const int k = 2 * f, p = f / 2, Ho = H * f, Wo = W * f, C4 = C >> 2;
-    const size_t total = (size_t)B * Ho * Wo * C4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        size_t t = i / C4;
-        const int x = (int)(t % Wo);
-        t /= Wo;
-        const int y = (int)(t % Ho);
-        const int b = (int)(t / Ho);
+    // per-channel kernels staged once per workgroup as [tap][channel] so a lane's 4 channels are one ds_read_b128
+    extern __shared__ float wt[];
+    const int k = 2 * f, kk = k * k;
+    for (int i = threadIdx.x; i < C * kk; i += blockDim.x) {
+        const int c = i / kk, t = i - c * kk;
+        wt[t * C + c] = w[i];
+    }
+    __syncthreads();
+    // 32-bit index math throughout (B*Ho*Wo*C/4 < 2^31 for every supported shape)
+    const int p = f / 2, Ho = H * f, Wo = W * f, C4 = C >> 2;
+    const unsigned total = (unsigned)B * Ho * Wo * C4;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned c4 = i % (unsigned)C4;
+        unsigned t = i / (unsigned)C4;
+        const int x = (int)(t % (unsigned)Wo);
+        t /= (unsigned)Wo;
+        const int y = (int)(t % (unsigned)Ho);
+        const int b = (int)(t / (unsigned)Ho);
         float4 acc = add ? reinterpret_cast<const float4*>(add)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         // ky ranges over { (y+p) % f, (y+p) % f + f }
         const int ky0 = (y + p) % f, kx0 = (x + p) % f;
+        const int iy0 = (y + p - ky0) / f, ix0 = (x + p - kx0) / f;  // source of tap (ky0, kx0); the other tap is one less
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const int ky = ky0 + a * f;
-            const int iy = (y + p - ky) / f;
+            const int ky = ky0 + a * f, iy = iy0 - a;
             if (iy < 0 || iy >= H) continue;
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
-                const int kx = kx0 + bb * f;
-                const int ix = (x + p - kx) / f;
+                const int kx = kx0 + bb * f, ix = ix0 - bb;
                 if (ix < 0 || ix >= W) continue;
-                const float4 v = reinterpret_cast<const float4*>(in)[(((size_t)b * H + iy) * W + ix) * C4 + c4];
-                const float* wc = w + (size_t)(c4 * 4) * k * k + ky * k + kx;
-                s.x += v.x * wc[0];
-                s.y += v.y * wc[(size_t)k * k];
-                s.z += v.z * wc[(size_t)2 * k * k];
-                s.w += v.w * wc[(size_t)3 * k * k];
+                const float4 v = reinterpret_cast<const float4*>(in)[((unsigned)(b * H + iy) * W + ix) * C4 + c4];
+                const float4 wv = *reinterpret_cast<const float4*>(wt + (ky * k + kx) * C + c4 * 4);
+                s.x += v.x * wv.x;
+                s.y += v.y * wv.y;
+                s.z += v.z * wv.z;
+                s.w += v.w * wv.w;
             }
         }
         acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
@@ -241,6 +249,17 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
     }
 }
 
+__global__ void gn_finalize_kernel(const double* __restrict__ stats, float* __restrict__ mr, int n, double count,
+                                   float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double mean = stats[2 * i] / count;
+    double var = stats[2 * i + 1] / count - mean * mean;
+    if (var < 0) var = 0;
+    mr[2 * i] = (float)mean;
+    mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 inline int check() { return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH; }
 
 }  // namespace
@@ -272,8 +291,11 @@ int cp_launch_maxpool2(const float* in, float* out, int B, int H, int W, int C, 
 int cp_launch_upsample_add(const float* in, const float* w, const float* add, float* out, int B, int H, int W, int C,
                            int f, hipStream_t s) {
     if (C % 4 || f < 2 || (f & 1)) return CP_ERR_INVALID;
-    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for((size_t)B * H * f * W * f * (C / 4))), dim3(TPB), 0, s, in,
-                       w, add, out, B, H, W, C, f);
+    if ((size_t)B * H * f * W * f * (C / 4) >= ((size_t)1 << 31)) return CP_ERR_INVALID;
+    const size_t lds = (size_t)C * 4 * f * f * sizeof(float);
+    if (lds > 64 * 1024) return CP_ERR_INVALID;
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for((size_t)B * H * f * W * f * (C / 4), 256 * 8)), dim3(TPB), lds,
+                       s, in, w, add, out, B, H, W, C, f);
     return check();
 }
 
@@ -306,5 +328,10 @@ int cp_launch_pack_weight(const float* w, float* wp, int Cout, int Cin, int taps
                           hipStream_t s) {
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((size_t)Cout * Cin * taps)), dim3(TPB), 0, s, w, wp, Cout, Cin,
                        taps, CinP, CoutPad, coff);
+    return check();
+}
+
+int cp_launch_gn_finalize(const double* stats, float* mr, int n, double count, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, stats, mr, n, count, eps);
     return check();
 }

@@ -137,6 +137,24 @@ __global__ __launch_bounds__(NTHREADS, 3) void igemm_kernel(const ConvParams p, 
                 const long long off = (long long)(a_pix0[j] + tap_pix) * sc + coff;
                 a_reg[j] = (a_vmask[j] & bit) ? ld4(base + off) : zero4();
             }
+            if (!MULTISRC && p.gn_in_mr) {
+                // fused GroupNorm + affine + ReLU of the producer's raw output (pose_dla_dcn.py:499-503)
+                const float4 ga = ld4(p.gn_in_gamma + coff), be = ld4(p.gn_in_beta + coff);
+                const int g = coff / p.gn_cpg;
+#pragma unroll
+                for (int j = 0; j < A_SLOTS; ++j) {
+                    if (a_vmask[j] & bit) {
+                        const float mu = p.gn_in_mr[(a_b[j] * p.gn_groups + g) * 2];
+                        const float rs = p.gn_in_mr[(a_b[j] * p.gn_groups + g) * 2 + 1];
+                        float4 v = a_reg[j];
+                        v.x = fmaxf((v.x - mu) * rs * ga.x + be.x, 0.f);
+                        v.y = fmaxf((v.y - mu) * rs * ga.y + be.y, 0.f);
+                        v.z = fmaxf((v.z - mu) * rs * ga.z + be.z, 0.f);
+                        v.w = fmaxf((v.w - mu) * rs * ga.w + be.w, 0.f);
+                        a_reg[j] = v;
+                    }
+                }
+            }
         } else if (!DCN) {
             const int kk = kt * BK + k4 * 4;
             const int tap = kk / p.Cin;

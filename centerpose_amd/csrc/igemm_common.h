@@ -71,6 +71,26 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, typename Fra
                     y = 1.f / (1.f + expf(-y));
                 v[r] = y;
             }
+            if (p.gn_stats) {
+                // GroupNorm statistics of this 32-row x 32-channel fragment: rows live in registers, the 8 channels
+                // of a group in 8 neighbouring lanes (and the other 16 rows in lane ^ 32)
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < F::NACC; ++r) {
+                    const int m = mbase + F::row(r, lane);
+                    if (n_ok && m < M) { s1 += v[r]; s2 += v[r] * v[r]; }
+                }
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (FRAG == 32) { s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); }
+                else { s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64); s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); }
+                if ((lane & 7) == 0 && lane < FRAG && n_ok && mbase < M) {
+                    const int b = mbase / HWo;  // launcher guarantees HWo % FRAG == 0: one image per fragment
+                    double* st = p.gn_stats + ((size_t)b * p.gn_groups + n / p.gn_cpg) * 2;
+                    atomicAdd(st, (double)s1);
+                    atomicAdd(st + 1, (double)s2);
+                }
+            }
             if (!n_ok) continue;
             if (p.store == CP_STORE_NHWC) {
 #pragma unroll
