@@ -159,6 +159,7 @@ struct cp_model {
         int M, N, K, kh, stride;
         hipEvent_t e0, e1;
     };
+    std::map<std::vector<uint64_t>, hipGraphExec_t> graphs;  // captured detect() launches, keyed by every argument
     bool profile = false;
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> event_pool;
@@ -831,6 +832,7 @@ void cp_model_destroy(cp_model* m) {
         (void)hipEventDestroy(r.e1);
     }
     for (auto e : m->event_pool) (void)hipEventDestroy(e);
+    for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : m->device_allocs) hipFree(p);
     delete m;
 }
@@ -849,6 +851,72 @@ int cp_model_forward(cp_model* m, cp_stream_t stream, int B, int H, int W, const
     m->tap_name = nullptr;
     return forward_impl(m, (hipStream_t)stream, B, H, W, images, pre_img, pre_hm, pre_hm_hp, head_out, sigmoid_hm,
                         workspace, workspace_bytes, false);
+}
+
+size_t cp_model_detect_workspace_bytes(cp_model* m, int B, int H, int W, int K) {
+    const size_t a = cp_model_workspace_bytes(m, B, H, W);
+    return a ? align_up(a, 256) + cp_decode_ws_bytes(B, 8, K) : 0;
+}
+
+// backbone + heads + sigmoid + decode in one call (what ObjectPoseDetector.process does, object_pose.py:131-165),
+// optionally replayed from a captured hipGraph (the ~120 launches of a frame become one graph launch).
+int cp_model_detect(cp_model* m, cp_stream_t stream, int B, int H, int W, const float* images, const float* pre_img,
+                    const float* pre_hm, const float* pre_hm_hp, float* const* head_out, int K, int rep_mode,
+                    int fit_gaussian, float balance, int legacy_bool_mask, float* det, void* workspace,
+                    size_t workspace_bytes, int use_graph) {
+    if (!m || !images || !head_out || !det || !workspace) return fail(CP_ERR_INVALID, "null argument");
+    if (!m->finalized) return fail(CP_ERR_STATE, "model not finalized");
+    const size_t model_ws = align_up(cp_model_workspace_bytes(m, B, H, W), 256);
+    if (model_ws == 0) return CP_ERR_INVALID;
+    if (workspace_bytes < model_ws + cp_decode_ws_bytes(B, 8, K)) return fail(CP_ERR_INVALID, "workspace too small");
+    // decode inputs by head name (opts.py:394-426)
+    float* hp[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const char* names[11] = {"hm", "hps", "wh", "hps_uncertainty", "scale", "scale_uncertainty", "reg", "hm_hp",
+                             "hp_offset", "tracking", "tracking_hp"};
+    for (size_t i = 0; i < m->headw.size(); ++i)
+        for (int j = 0; j < 11; ++j)
+            if (m->headw[i].name == names[j]) hp[j] = head_out[i];
+    if (!hp[0] || !hp[1] || !hp[2] || !hp[7]) return fail(CP_ERR_INVALID, "detect needs the hm, hps, wh and hm_hp heads");
+    hipStream_t s = (hipStream_t)stream;
+    auto enqueue = [&]() -> int {
+        m->tap_name = nullptr;
+        int rc = forward_impl(m, s, B, H, W, images, pre_img, pre_hm, pre_hm_hp, head_out, 1, workspace, model_ws, false);
+        if (rc != CP_OK) return rc;
+        return cp_launch_decode(s, B, 8, H / 4, W / 4, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7], hp[8],
+                                hp[9], hp[10], K, rep_mode, fit_gaussian, balance, legacy_bool_mask, 0, det,
+                                (char*)workspace + model_ws);
+    };
+    if (!use_graph || m->profile) return enqueue();
+    std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)H, (uint64_t)W, (uint64_t)images, (uint64_t)pre_img,
+                                 (uint64_t)pre_hm, (uint64_t)pre_hm_hp, (uint64_t)K, (uint64_t)rep_mode,
+                                 (uint64_t)fit_gaussian, (uint64_t)legacy_bool_mask, (uint64_t)det, (uint64_t)workspace,
+                                 (uint64_t)m->precision, (uint64_t)(balance * 1e6f), (uint64_t)s};
+    for (size_t i = 0; i < m->headw.size(); ++i) key.push_back((uint64_t)head_out[i]);
+    auto it = m->graphs.find(key);
+    if (it == m->graphs.end()) {
+        if (s == nullptr) return fail(CP_ERR_INVALID, "graph capture needs a non-default stream");
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
+            return fail(CP_ERR_LAUNCH, "hipStreamBeginCapture failed");
+        const int rc = enqueue();
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(s, &g);
+        if (rc != CP_OK || e != hipSuccess || !g) {
+            if (g) (void)hipGraphDestroy(g);
+            return rc != CP_OK ? rc : fail(CP_ERR_LAUNCH, "hipStreamEndCapture failed");
+        }
+        hipGraphExec_t ex = nullptr;
+        if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGraphDestroy(g);
+            return fail(CP_ERR_LAUNCH, "hipGraphInstantiate failed");
+        }
+        (void)hipGraphDestroy(g);
+        if (m->graphs.size() >= 16) {  // bound the cache
+            for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+            m->graphs.clear();
+        }
+        it = m->graphs.emplace(key, ex).first;
+    }
+    return hipGraphLaunch(it->second, s) == hipSuccess ? CP_OK : fail(CP_ERR_LAUNCH, "hipGraphLaunch failed");
 }
 
 int cp_model_forward_tap(cp_model* m, cp_stream_t stream, int B, int H, int W, const float* images,

@@ -57,6 +57,9 @@ def lib():
     _sig(L.cp_decode_workspace_bytes, c_size_t, c_int, c_int)
     _sig(L.cp_decode, c_int, c_void_p, c_int, c_int, c_int, *([c_void_p] * 11), c_int, c_int, c_int, ctypes.c_float,
          c_int, c_int, c_void_p, c_void_p, c_size_t)
+    _sig(L.cp_model_detect_workspace_bytes, c_size_t, c_void_p, c_int, c_int, c_int, c_int)
+    _sig(L.cp_model_detect, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+         ctypes.POINTER(c_void_p), c_int, c_int, c_int, ctypes.c_float, c_int, c_void_p, c_void_p, c_size_t, c_int)
     _sig(L.cp_set_default_precision, c_int, c_int)
     _sig(L.cp_model_set_precision, c_int, c_void_p, c_int)
     _sig(L.cp_model_profile, c_int, c_void_p, c_int)
@@ -74,7 +77,7 @@ def exported_symbols():
             "cp_model_set_param", "cp_model_finalize", "cp_model_destroy", "cp_model_workspace_bytes",
             "cp_model_forward", "cp_model_forward_tap", "cp_conv2d_workspace_bytes", "cp_conv2d_nhwc",
             "cp_decode_workspace_bytes", "cp_decode", "cp_pnp_workspace_bytes", "cp_pnp_solve", "cp_model_profile", "cp_model_profile_read",
-            "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision"]
+            "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect"]
 
 
 def _check(rc, what):
@@ -299,5 +302,36 @@ class HipModel(object):
         if C == 0:
             raise RuntimeError("unknown tap %r" % tap)
         return outs, tap_buf[: B * C * h * w].view(B, C, h, w)
+
+    def detect(self, images, pre_img=None, pre_hm=None, pre_hm_hp=None, K=100, rep_mode=1, fit_gaussian=False,
+               balance=2.0, legacy_bool_mask=False, graph=True):
+        """backbone + heads + sigmoid + decode in one library call -> (heads dict, det [B,K,118]).
+        Output tensors are owned by the model and REUSED by the next call with the same batch shape (that is what lets
+        the launch sequence be replayed from a hipGraph).  With ``graph`` the caller must run on a non-default stream
+        and pass the same input tensors (copy new frames into them)."""
+        L = lib()
+        B, _, H, W = images.shape
+        key = ("det", B, H, W, str(images.device), K)
+        st = getattr(self, "_det_state", None)
+        if st is None or st[0] != key:
+            outs = OrderedDict((k, torch.empty(B, c, H // 4, W // 4, device=images.device, dtype=torch.float32))
+                               for k, c in self.heads.items())
+            det = torch.empty(B, K, DET_STRIDE, device=images.device, dtype=torch.float32)
+            n = L.cp_model_detect_workspace_bytes(self._h, B, H, W, K)
+            if n == 0:
+                raise RuntimeError("cp_model_detect_workspace_bytes failed: " + L.cp_last_error().decode())
+            ws = torch.empty(n, dtype=torch.uint8, device=images.device)
+            ptrs = (c_void_p * len(outs))(*[t.data_ptr() for t in outs.values()])
+            st = (key, outs, det, ws, ptrs)
+            self._det_state = st
+        _, outs, det, ws, ptrs = st
+        for t in (images, pre_img, pre_hm, pre_hm_hp):
+            if t is not None and not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                raise RuntimeError("detect: inputs must be contiguous float32 device tensors")
+        rc = L.cp_model_detect(self._h, _stream(), B, H, W, _ptr(images), _ptr(pre_img), _ptr(pre_hm), _ptr(pre_hm_hp),
+                               ptrs, int(K), int(rep_mode), int(bool(fit_gaussian)), float(balance),
+                               int(bool(legacy_bool_mask)), _ptr(det), _ptr(ws), ws.numel(), int(bool(graph)))
+        _check(rc, "cp_model_detect")
+        return outs, det
 
     __call__ = forward

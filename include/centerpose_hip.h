@@ -78,6 +78,18 @@ int cp_model_forward(cp_model* m, cp_stream_t stream, int B, int H, int W, const
                      const float* pre_img, const float* pre_hm, const float* pre_hm_hp, float* const* head_out,
                      int sigmoid_hm, void* workspace, size_t workspace_bytes);
 
+/* One frame batch end to end on the device: backbone + heads + sigmoid(hm, hm_hp) + decode — what
+ * `ObjectPoseDetector.process` does (detectors/object_pose.py:131-165) — in ONE call.  Arguments as in
+ * cp_model_forward and cp_decode; head_out[] receives the head tensors (hm / hm_hp post-sigmoid), det the
+ * [B,K,118] records.  With use_graph != 0 the launch sequence is captured into a hipGraph on first use (keyed
+ * by every pointer / size argument, so buffers must be reused) and replayed afterwards: a frame costs one graph
+ * launch instead of ~120 kernel launches.  Needs a non-default stream; ignored while profiling is armed. */
+size_t cp_model_detect_workspace_bytes(cp_model* m, int B, int H, int W, int K);
+int cp_model_detect(cp_model* m, cp_stream_t stream, int B, int H, int W, const float* images, const float* pre_img,
+                    const float* pre_hm, const float* pre_hm_hp, float* const* head_out, int K, int rep_mode,
+                    int fit_gaussian, float balance, int legacy_bool_mask, float* det, void* workspace,
+                    size_t workspace_bytes, int use_graph);
+
 /* Debug/parity aid: same as cp_model_forward but additionally copies the named intermediate
  * activation (names follow the reference module paths, e.g. "base.level3", "dla_up.ida_2.node_3",
  * "feat", "convGRU.step1") to tap_out as NCHW.  tap_dims receives {C,H,W}. */

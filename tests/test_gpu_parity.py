@@ -319,3 +319,32 @@ def test_pnp_status_codes(device):
     out = hip.pnp_solve(torch.from_numpy(pts).to(device), torch.from_numpy(scale).to(device),
                         torch.from_numpy(cam).to(device)).cpu().numpy()
     assert list(out[:, 0]) == [-1, -2, -3, 1]
+
+
+def test_detect_one_call_and_graph_replay(device):
+    """cp_model_detect == cp_model_forward + cp_decode, eagerly and replayed from a hipGraph on fresh frames."""
+    heads = synth.HEADS_POSE
+    sd = synth.make_state_dict("dlav1_34", heads)
+    model = hip.HipModel("dlav1_34", heads, sd)
+    x = synth.frames(2, seed=41, h=128, w=128).to(device)
+    z = model(x, sigmoid_hm=True)
+    det_ref = hip.decode_raw(z["hm"].clone(), z["hps"], z["wh"], z["hm_hp"].clone(), None, z["scale"], None, z["reg"],
+                             z["hp_offset"], None, None, K=100, rep_mode=1)
+    side = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(side):
+        outs, det = model.detect(x, graph=False)
+        side.synchronize()
+        assert torch.equal(det, det_ref)
+        for k in heads:
+            assert torch.equal(outs[k], z[k])
+        outs, det = model.detect(x, graph=True)      # capture + first replay
+        side.synchronize()
+        assert torch.equal(det, det_ref)
+        x2 = synth.frames(2, seed=42, h=128, w=128).to(device)
+        z2 = model(x2, sigmoid_hm=True)
+        det2_ref = hip.decode_raw(z2["hm"].clone(), z2["hps"], z2["wh"], z2["hm_hp"].clone(), None, z2["scale"], None,
+                                  z2["reg"], z2["hp_offset"], None, None, K=100, rep_mode=1)
+        x.copy_(x2)                                   # new frame into the captured input buffer
+        outs, det = model.detect(x, graph=True)      # pure replay
+        side.synchronize()
+        assert torch.equal(det, det2_ref)
