@@ -67,6 +67,11 @@ struct ConvParams {
     const float* gn_in_mr;
     const float* gn_in_gamma;
     const float* gn_in_beta;
+    // deterministic split-K (few output tiles, long K: low-resolution layers at small batch): blockIdx.y = K slice,
+    // raw accumulators go to partial[slice][M][CoutPad]; cp_launch_splitk_epilogue sums the slices in order and
+    // applies the usual epilogue.
+    int splitk;
+    float* partial;
     const float* offmask;  // DCN mode: NHWC [B,H,W,32] = 18 offsets (dh,dw interleaved per tap) + 9 masks (already sigmoided) + 5 pad
 };
 
@@ -74,6 +79,9 @@ int cp_launch_conv(const ConvParams& p, hipStream_t stream);
 // Tile N-width the launcher will pick for `cout` (weights must be padded to a multiple of it).
 int cp_conv_tile_n(int cout);
 int cp_conv_variant(const ConvParams& p);
+int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream);
+// K steps (of 16 for the f32 kernels, 32 for f16x3) and output tiles of the launch cp_launch_conv[16] would make
+void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk);
 const char* cp_conv_variant_name(int v);
 #define CP_NUM_CONV_VARIANTS 22
 // split-f16 ("f16x3") implicit GEMM (igemm16.hip)

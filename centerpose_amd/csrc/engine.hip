@@ -474,6 +474,33 @@ struct Fwd {
             p.ldo = cstore;
             p.coff = 0;
         }
+        // deterministic split-K for launches with too few output tiles to fill 256 CUs (low-resolution layers at
+        // small batch): slices write slabs, a small epilogue kernel sums them in order
+        Tensor partial;
+        p.splitk = 1;
+        {
+            int tiles = 0, nk = 0;
+            cp_conv_geometry(p, use16, &tiles, &nk);
+            if (tiles > 0 && tiles < 128 && nk >= 8 && !p.gn_stats) {
+                int want = (384 + tiles - 1) / tiles;
+                if (want > nk / 2) want = nk / 2;
+                if (want > 32) want = 32;
+                if (want > 1) {
+                    const int per = (nk + want - 1) / want;
+                    const int sk = (nk + per - 1) / per;
+                    if (sk > 1) {
+                        p.splitk = sk;
+                        partial = make(sk * p.CoutPad, p.Ho, p.Wo);
+                        p.partial = partial.ptr();
+                    }
+                }
+            }
+        }
+        auto launch = [&]() -> int {
+            int rc = use16 ? cp_launch_conv16(p, s) : cp_launch_conv(p, s);
+            if (rc == CP_OK && p.splitk > 1) rc = cp_launch_splitk_epilogue(p, s);
+            return rc;
+        };
         if (!m->dry) {
             if (m->profile) {
                 cp_model::ProfRec r;
@@ -489,11 +516,11 @@ struct Fwd {
                 r.e0 = m->get_event();
                 r.e1 = m->get_event();
                 (void)hipEventRecord(r.e0, s);
-                chk(use16 ? cp_launch_conv16(p, s) : cp_launch_conv(p, s));
+                chk(launch());
                 (void)hipEventRecord(r.e1, s);
                 m->prof.push_back(r);
             } else {
-                chk(use16 ? cp_launch_conv16(p, s) : cp_launch_conv(p, s));
+                chk(launch());
             }
         }
         gn_stats_out = nullptr;

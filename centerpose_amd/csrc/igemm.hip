@@ -96,8 +96,26 @@ __global__ __launch_bounds__(NTHREADS, 3) void igemm_kernel(const ConvParams p, 
     float4 a_reg[A_SLOTS];
     float4 b_reg[B_SLOTS];
 
+    const int nk = p.Kpad / BK;
+    int kt0, kt1;
+    splitk_range(p, nk, &kt0, &kt1);
     // wave-uniform K-walk state (ALIGNED): advanced once per K-step, lives in SGPRs
     int u_tap = 0, u_kh = 0, u_kw = 0, u_c0 = 0, u_src = 0, u_cs = 0;
+    bool u_first = true;
+    if (ALIGNED && kt0 > 0) {
+        const int k0 = kt0 * BK;
+        u_tap = k0 / p.Cin;
+        u_c0 = k0 - u_tap * p.Cin;
+        u_kh = u_tap / p.KW;
+        u_kw = u_tap - u_kh * p.KW;
+        u_cs = u_c0;
+        if (MULTISRC) {
+            for (int q = 0; q < 3; ++q) {
+                const int cur = q == 0 ? p.src_c[0] : q == 1 ? p.src_c[1] : p.src_c[2];
+                if (u_src == q && u_cs >= cur) { u_cs -= cur; ++u_src; }
+            }
+        }
+    }
     // DCN: per-slot bilinear taps of the current kernel tap, recomputed only when the tap changes
     int d_idx[DCN ? A_SLOTS : 1][4];
     float d_w[DCN ? A_SLOTS : 1][4];
@@ -107,7 +125,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void igemm_kernel(const ConvParams p, 
     for (int j = 0; j < B_SLOTS; ++j) {
         const int f = tid + j * NTHREADS;
         const int row = f / (BN / 4), c4 = f % (BN / 4);
-        b_ptr[j] = p.wp + (size_t)row * p.CoutPad + tn * BN + c4 * 4;
+        b_ptr[j] = p.wp + (size_t)(kt0 * BK + row) * p.CoutPad + tn * BN + c4 * 4;
     }
 
     auto load_tile = [&](int kt) {
@@ -172,7 +190,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void igemm_kernel(const ConvParams p, 
         } else {
             const float* base = p.src[0];
             const int C = p.Cin;
-            if (u_c0 == 0) {
+            if (u_c0 == 0 || u_first) {
+                u_first = false;
                 // new kernel tap: sample positions and (mask-folded) bilinear weights per slot
 #pragma unroll
                 for (int j = 0; j < A_SLOTS; ++j) {
@@ -263,16 +282,15 @@ __global__ __launch_bounds__(NTHREADS, 3) void igemm_kernel(const ConvParams p, 
 #pragma unroll
             for (int r = 0; r < F::NACC; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.Kpad / BK;
-    load_tile(0);
+    load_tile(kt0);
     store_tile(0);
     __syncthreads();
 
     const int lrow = lane / FRAG;  // k index inside a KSTEP
     const int lcol = lane % FRAG;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1) load_tile(kt + 1);
         const float* A = As + buf * A_SZ + wm * (MT * FRAG) + lcol;
         const float* Bt = Bs + buf * B_SZ + wn * (NT * FRAG) + lcol;
         // fragment reads for k-step s+1 are issued before the MFMAs of step s (register double buffer), so
@@ -300,11 +318,12 @@ __global__ __launch_bounds__(NTHREADS, 3) void igemm_kernel(const ConvParams p, 
                 for (int j = 0; j < NT; ++j) acc[i][j] = F::mfma(a[cur][i], b[cur][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+        if (kt + 1 < kt1) store_tile(buf ^ 1);
         __syncthreads();
     }
 
-    igemm_epilogue<FRAG, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane);
+    if (p.splitk > 1) igemm_store_partial<FRAG, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane, blockIdx.y);
+    else igemm_epilogue<FRAG, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane);
 }
 
 template <int FRAG, int MT, int NT, int WM, int WN, bool DCN, bool ALIGNED, bool MULTISRC>
@@ -314,8 +333,8 @@ int launch_a(const ConvParams& p, hipStream_t stream) {
     const int tiles_m = (M + BM - 1) / BM;
     const int tiles_n = p.CoutPad / BN;
     if (p.CoutPad % BN != 0 || p.Kpad % BK != 0) return CP_ERR_INVALID;
-    hipLaunchKernelGGL((igemm_kernel<FRAG, MT, NT, WM, WN, DCN, ALIGNED, MULTISRC>), dim3(tiles_m * tiles_n),
-                       dim3(NTHREADS), 0, stream, p, tiles_m, tiles_n);
+    hipLaunchKernelGGL((igemm_kernel<FRAG, MT, NT, WM, WN, DCN, ALIGNED, MULTISRC>),
+                       dim3(tiles_m * tiles_n, p.splitk > 1 ? p.splitk : 1), dim3(NTHREADS), 0, stream, p, tiles_m, tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
@@ -367,6 +386,46 @@ const char* cp_conv_variant_name(int v) {
         "dcn_igemm16_f16x3_m128n128", "igemm16_cat_f16x3_m128n32", "igemm16_cat_f16x3_m128n64",
         "igemm16_cat_f16x3_m128n128"};
     return (v >= 0 && v < 22) ? names[v] : "?";
+}
+
+void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk) {
+    const int bn = cp_conv_tile_n(p.Cout);
+    const int bm = f16x3 ? 128 : (bn <= 32 ? 256 : 128);
+    const int M = p.B * p.Ho * p.Wo;
+    *tiles = ((M + bm - 1) / bm) * (p.CoutPad / bn);
+    *nk = f16x3 ? p.Kpad16 / 32 : p.Kpad / BK;
+}
+
+namespace {
+// split-K epilogue: out = act((sum_slices partial) * scale + shift + residual), slices summed in index order
+__global__ void splitk_epilogue_kernel(const ConvParams p) {
+    const int M = p.B * p.Ho * p.Wo, HWo = p.Ho * p.Wo;
+    const size_t total = (size_t)M * p.Cout;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int m, n;
+        if (p.store == CP_STORE_NHWC) { m = (int)(i / p.Cout); n = (int)(i - (size_t)m * p.Cout); }
+        else { n = (int)(i / M); m = (int)(i - (size_t)n * M); }
+        float acc = 0.f;
+        for (int z = 0; z < p.splitk; ++z) acc += p.partial[((size_t)z * M + m) * p.CoutPad + n];
+        float y = acc * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
+        if (p.res) y += p.res[(size_t)m * p.res_ld + n];
+        if (p.act == CP_ACT_RELU) y = fmaxf(y, 0.f);
+        else if (p.act == CP_ACT_SIGMOID || (p.act == CP_ACT_SIGMOID_FROM && n >= p.act_from)) y = 1.f / (1.f + expf(-y));
+        if (p.store == CP_STORE_NHWC) p.out[(size_t)m * p.ldo + p.coff + n] = y;
+        else {
+            const int b = m / HWo, pix = m - b * HWo;
+            p.out[((size_t)b * p.ldo + p.coff + n) * HWo + pix] = y;
+        }
+    }
+}
+}  // namespace
+
+int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream) {
+    const size_t total = (size_t)p.B * p.Ho * p.Wo * p.Cout;
+    int g = (int)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(g), dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
 int cp_launch_conv(const ConvParams& p, hipStream_t stream) {

@@ -101,7 +101,25 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
 
     float4 a_reg0[A_SLOTS], a_reg1[PF2 ? A_SLOTS : 1];
     u32x4 bh_reg0[B_SLOTS], bl_reg0[B_SLOTS], bh_reg1[PF2 ? B_SLOTS : 1], bl_reg1[PF2 ? B_SLOTS : 1];
+    const int nk = p.Kpad16 / BK16;
+    int kt0, kt1;
+    splitk_range(p, nk, &kt0, &kt1);
     int u_tap = 0, u_kh = 0, u_kw = 0, u_c0 = 0, u_src = 0, u_cs = 0;
+    bool u_first = true;
+    if (kt0 > 0) {
+        const int k0 = kt0 * BK16;
+        u_tap = k0 / p.Cin;
+        u_c0 = k0 - u_tap * p.Cin;
+        u_kh = u_tap / p.KW;
+        u_kw = u_tap - u_kh * p.KW;
+        u_cs = u_c0;
+        if (MULTISRC) {
+            for (int q = 0; q < 3; ++q) {
+                const int cur = q == 0 ? p.src_c[0] : q == 1 ? p.src_c[1] : p.src_c[2];
+                if (u_src == q && u_cs >= cur) { u_cs -= cur; ++u_src; }
+            }
+        }
+    }
     int d_idx[DCN ? A_SLOTS : 1][4];
     float d_w[DCN ? A_SLOTS : 1][4];
 
@@ -112,7 +130,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
 #pragma unroll
     for (int j = 0; j < B_SLOTS; ++j) {
         const int f = tid + j * NT16;
-        b_off[j] = (size_t)(tn * BN + f / 4) * p.Kpad16 + (f % 4) * 8;
+        b_off[j] = (size_t)(tn * BN + f / 4) * p.Kpad16 + (f % 4) * 8 + (size_t)kt0 * BK16;
     }
 
     auto load_tile = [&](float4* a_reg, u32x4* bh_reg, u32x4* bl_reg) {
@@ -144,7 +162,8 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
         } else {
             const float* base = p.src[0];
             const int C = p.Cin;
-            if (u_c0 == 0) {
+            if (u_c0 == 0 || u_first) {
+                u_first = false;
 #pragma unroll
                 for (int j = 0; j < A_SLOTS; ++j) {
                     int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
@@ -233,7 +252,6 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
 #pragma unroll
             for (int r = 0; r < F::NACC; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.Kpad16 / BK16;
     const int lrow = lane >> 5;  // which 8-wide k group of the 16-deep MFMA step
     const int lcol = lane & 31;
 
@@ -270,15 +288,16 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
         load_tile(a_reg0, bh_reg0, bl_reg0);
         store_tile(0, a_reg0, bh_reg0, bl_reg0);
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) load_tile(a_reg0, bh_reg0, bl_reg0);
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            if (kt + 1 < kt1) load_tile(a_reg0, bh_reg0, bl_reg0);
             mma_tile(buf);
-            if (kt + 1 < nk) store_tile(buf ^ 1, a_reg0, bh_reg0, bl_reg0);
+            if (kt + 1 < kt1) store_tile(buf ^ 1, a_reg0, bh_reg0, bl_reg0);
             __syncthreads();
         }
     } else {
         // tiles t+1 and t+2 are in registers / in flight while tile t is multiplied out of LDS
+        const int nk = kt1 - kt0;
         load_tile(a_reg0, bh_reg0, bl_reg0);
         if (nk > 1) load_tile(a_reg1, bh_reg1, bl_reg1);
         store_tile(0, a_reg0, bh_reg0, bl_reg0);
@@ -295,7 +314,8 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
             __syncthreads();
         }
     }
-    igemm_epilogue<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane);
+    if (p.splitk > 1) igemm_store_partial<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane, blockIdx.y);
+    else igemm_epilogue<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane);
 }
 
 template <int MT, int NT, int WM, int WN, bool DCN, bool MULTISRC>
@@ -307,8 +327,8 @@ int launch16(const ConvParams& p, hipStream_t stream) {
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = p.CoutPad / BN;
     if (p.CoutPad % BN != 0 || p.Kpad16 % BK16 != 0) return CP_ERR_INVALID;
-    hipLaunchKernelGGL((igemm16_kernel<MT, NT, WM, WN, DCN, MULTISRC, PF2>), dim3(tiles_m * tiles_n), dim3(NT16), 0,
-                       stream, p, tiles_m, tiles_n);
+    hipLaunchKernelGGL((igemm16_kernel<MT, NT, WM, WN, DCN, MULTISRC, PF2>),
+                       dim3(tiles_m * tiles_n, p.splitk > 1 ? p.splitk : 1), dim3(NT16), 0, stream, p, tiles_m, tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 

@@ -124,4 +124,35 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, typename Fra
     }
 }
 
+// split-K: raw accumulators of this K slice -> partial[slice][m][CoutPad]
+template <int FRAG, int MT, int NT, int WM, int WN>
+__device__ __forceinline__ void igemm_store_partial(const ConvParams& p, typename Frag<FRAG>::acc_t (&acc)[MT][NT], int tm,
+                                                    int tn, int wm, int wn, int lane, int slice) {
+    typedef Frag<FRAG> F;
+    constexpr int BM = FRAG * MT * WM, BN = FRAG * NT * WN;
+    const int M = p.B * p.Ho * p.Wo;
+    float* dst = p.partial + (size_t)slice * M * p.CoutPad;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = tn * BN + wn * (NT * FRAG) + j * FRAG + lane % FRAG;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mbase = tm * BM + wm * (MT * FRAG) + i * FRAG;
+#pragma unroll
+            for (int r = 0; r < F::NACC; ++r) {
+                const int m = mbase + F::row(r, lane);
+                if (m < M) dst[(size_t)m * p.CoutPad + n] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// K-step range of this block's slice
+__device__ __forceinline__ void splitk_range(const ConvParams& p, int nk, int* kt0, int* kt1) {
+    if (p.splitk <= 1) { *kt0 = 0; *kt1 = nk; return; }
+    const int per = (nk + p.splitk - 1) / p.splitk;
+    *kt0 = min(nk, (int)blockIdx.y * per);
+    *kt1 = min(nk, *kt0 + per);
+}
+
 }  // namespace

@@ -161,10 +161,15 @@ def test_backbone_512_vs_oracle_and_batch_invariance(device, arch, prec):
     assert float((z["hm_hp"][1:2].cpu() - torch.sigmoid(zo["hm_hp"])).abs().max()) < 1e-3
     for k in ("wh", "hps", "reg", "hp_offset", "scale"):
         assert float((z[k][1:2].cpu() - zo[k]).abs().max()) < 1e-3 * max(1.0, float(zo[k].abs().max())), k
-    # size-independent property: images are independent -> the batch is a pure stack (bit-exact)
+    # size-independent property: images are independent -> the batch is a pure stack.  Bit-exact when both runs
+    # use the same K partition; at batch 1 the low-resolution layers switch to split-K (different summation
+    # order), so the comparison across batch sizes is to float32 round-off.
     z1 = model(x[1:2].to(device), sigmoid_hm=True)
     for k in heads:
-        assert torch.equal(z1[k], z[k][1:2]), k
+        assert float((z1[k] - z[k][1:2]).abs().max()) < 2e-4 * max(1.0, float(z[k].abs().max())), k
+    z3 = model(x.to(device), sigmoid_hm=True)
+    for k in heads:
+        assert torch.equal(z3[k], z[k]), k   # same shape twice: deterministic, bit-exact
 
 
 def test_model_missing_parameter_fails_loudly(device):
