@@ -26,7 +26,11 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int BK16 = 32;
-constexpr int LDH = 40;  // halfs per LDS row: 32 data + 8 pad (80 bytes)
+constexpr int LDH = 32;  // halfs per LDS row: 64 bytes, no padding; 16-byte chunks are XOR-swizzled by the row
+// chunk c of row r lives at chunk position c ^ ((r >> 2) & 3): every ds_read_b128 lane group ({0-3,12-15,20-27}, ...)
+// then hits 16 distinct 16-byte slots of the 256-byte bank row, and two consecutive rows written by a ds_write_b64 /
+// b128 lane group cover 32 distinct banks (measured before the swizzle: 33 % of LDS cycles were bank conflicts).
+__device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
 constexpr int NT16 = 256;
 
 struct Split2 {
@@ -230,16 +234,17 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
         for (int j = 0; j < A_SLOTS; ++j) {
             const int row = (tid >> 3) + j * 32;
             const Split2 s0 = split2(a_reg[j].x, a_reg[j].y), s1 = split2(a_reg[j].z, a_reg[j].w);
-            *reinterpret_cast<u32x2*>(Ah + row * LDH + k4 * 4) = u32x2{s0.hi, s1.hi};
-            *reinterpret_cast<u32x2*>(Al + row * LDH + k4 * 4) = u32x2{s0.lo, s1.lo};
+            const int col = ((((k4 >> 1) ^ swz(row)) << 1) | (k4 & 1)) * 4;  // halfs
+            *reinterpret_cast<u32x2*>(Ah + row * LDH + col) = u32x2{s0.hi, s1.hi};
+            *reinterpret_cast<u32x2*>(Al + row * LDH + col) = u32x2{s0.lo, s1.lo};
         }
 #pragma unroll
         for (int j = 0; j < B_SLOTS; ++j) {
             const int f = tid + j * NT16;
             if (B_CHUNKS % NT16 == 0 || f < B_CHUNKS) {
                 const int n = f / 4, c = f % 4;
-                *reinterpret_cast<u32x4*>(Bh + n * LDH + c * 8) = bh_reg[j];
-                *reinterpret_cast<u32x4*>(Bl + n * LDH + c * 8) = bl_reg[j];
+                *reinterpret_cast<u32x4*>(Bh + n * LDH + (c ^ swz(n)) * 8) = bh_reg[j];
+                *reinterpret_cast<u32x4*>(Bl + n * LDH + (c ^ swz(n)) * 8) = bl_reg[j];
             }
         }
     };
@@ -256,22 +261,24 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
     const int lcol = lane & 31;
 
     auto mma_tile = [&](int buf) {
-        const _Float16* Ah = lds + buf * BUF + (wm * (MT * 32) + lcol) * LDH + lrow * 8;
+        // fragment rows are (tile base, a multiple of 32) + lcol, so the swizzle only depends on lcol
+        const _Float16* Ah = lds + buf * BUF + (wm * (MT * 32) + lcol) * LDH;
         const _Float16* Al = Ah + A_SZ;
-        const _Float16* Bh = lds + buf * BUF + 2 * A_SZ + (wn * (NT * 32) + lcol) * LDH + lrow * 8;
+        const _Float16* Bh = lds + buf * BUF + 2 * A_SZ + (wn * (NT * 32) + lcol) * LDH;
         const _Float16* Bl = Bh + B_SZ;
 #pragma unroll
         for (int ks = 0; ks < BK16 / 16; ++ks) {
+            const int co = (((ks * 2 + lrow) ^ swz(lcol)) * 8);
             h8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                ah[i] = *reinterpret_cast<const h8*>(Ah + i * 32 * LDH + ks * 16);
-                al[i] = *reinterpret_cast<const h8*>(Al + i * 32 * LDH + ks * 16);
+                ah[i] = *reinterpret_cast<const h8*>(Ah + i * 32 * LDH + co);
+                al[i] = *reinterpret_cast<const h8*>(Al + i * 32 * LDH + co);
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                bh[j] = *reinterpret_cast<const h8*>(Bh + j * 32 * LDH + ks * 16);
-                bl[j] = *reinterpret_cast<const h8*>(Bl + j * 32 * LDH + ks * 16);
+                bh[j] = *reinterpret_cast<const h8*>(Bh + j * 32 * LDH + co);
+                bl[j] = *reinterpret_cast<const h8*>(Bl + j * 32 * LDH + co);
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
