@@ -33,6 +33,18 @@ constexpr int LDH = 32;  // halfs per LDS row: 64 bytes, no padding; 16-byte chu
 __device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
 constexpr int NT16 = 256;
 
+// Raw buffer loads (SRD + 32-bit byte offset): an out-of-range offset returns 0, so halo / invalid taps need no
+// exec-mask branch around the load -- and without control flow between the loads the compiler can wait for tile
+// t+1 with a counted s_waitcnt vmcnt(N) while tile t+2 stays in flight.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+constexpr unsigned OOB = 0xffffffffu;
+
 struct Split2 {
     uint32_t hi, lo;  // two binary16 values each
 };
@@ -65,7 +77,10 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
     constexpr int B_SLOTS = (B_CHUNKS + NT16 - 1) / NT16;   // per array
     constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;         // halfs per array per buffer
     constexpr int BUF = 2 * A_SZ + 2 * B_SZ;
-    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * BUF];
+    // two distinct LDS objects (not one array): in the fused steady state the stores go to one buffer and the
+    // fragment reads to the other, and the compiler may only interleave them if it can prove they do not alias
+    __shared__ __attribute__((aligned(16))) _Float16 lds0[BUF];
+    __shared__ __attribute__((aligned(16))) _Float16 lds1[BUF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -130,11 +145,18 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
     // weights: [CoutPad][Kpad16] binary16, k contiguous; chunk f -> row n = f / 4, 16-byte column f % 4
     const _Float16* wh = reinterpret_cast<const _Float16*>(p.w16_hi);
     const _Float16* wl = reinterpret_cast<const _Float16*>(p.w16_lo);
-    size_t b_off[B_SLOTS];
+    const unsigned w_bytes = (unsigned)((size_t)p.CoutPad * p.Kpad16 * 2);
+    const __amdgpu_buffer_rsrc_t r_wh = make_rsrc(wh, w_bytes), r_wl = make_rsrc(wl, w_bytes);
+    const unsigned img_px = (unsigned)p.B * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t r_s0 = make_rsrc(p.src[0], img_px * p.src_c[0] * 4u);
+    const __amdgpu_buffer_rsrc_t r_s1 = make_rsrc(MULTISRC ? p.src[1] : p.src[0], MULTISRC ? img_px * p.src_c[1] * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t r_s2 = make_rsrc(MULTISRC && p.nsrc > 2 ? p.src[2] : p.src[0], MULTISRC && p.nsrc > 2 ? img_px * p.src_c[2] * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t r_s3 = make_rsrc(MULTISRC && p.nsrc > 3 ? p.src[3] : p.src[0], MULTISRC && p.nsrc > 3 ? img_px * p.src_c[3] * 4u : 0u);
+    unsigned b_off[B_SLOTS];  // byte offsets into the packed binary16 weights
 #pragma unroll
     for (int j = 0; j < B_SLOTS; ++j) {
         const int f = tid + j * NT16;
-        b_off[j] = (size_t)(tn * BN + f / 4) * p.Kpad16 + (f % 4) * 8 + (size_t)kt0 * BK16;
+        b_off[j] = (unsigned)(((size_t)(tn * BN + f / 4) * p.Kpad16 + (f % 4) * 8 + (size_t)kt0 * BK16) * 2);
     }
 
     auto load_tile = [&](float4* a_reg, u32x4* bh_reg, u32x4* bl_reg) {
@@ -142,29 +164,28 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
         for (int j = 0; j < B_SLOTS; ++j) {
             const int f = tid + j * NT16;
             if (B_CHUNKS % NT16 == 0 || f < B_CHUNKS) {
-                bh_reg[j] = *reinterpret_cast<const u32x4*>(wh + b_off[j]);
-                bl_reg[j] = *reinterpret_cast<const u32x4*>(wl + b_off[j]);
-                b_off[j] += BK16;
+                bh_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(r_wh, (int)b_off[j], 0, 0);
+                bl_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)b_off[j], 0, 0);
+                b_off[j] += BK16 * 2;
             }
         }
         if (!DCN) {
-            const float* base = p.src[0];
+            __amdgpu_buffer_rsrc_t rs = r_s0;
             int sc = p.src_c[0];
             if (MULTISRC) {
-                if (u_src == 1) { base = p.src[1]; sc = p.src_c[1]; }
-                else if (u_src == 2) { base = p.src[2]; sc = p.src_c[2]; }
-                else if (u_src == 3) { base = p.src[3]; sc = p.src_c[3]; }
+                if (u_src == 1) { rs = r_s1; sc = p.src_c[1]; }
+                else if (u_src == 2) { rs = r_s2; sc = p.src_c[2]; }
+                else if (u_src == 3) { rs = r_s3; sc = p.src_c[3]; }
             }
             const int tap_pix = u_kh * p.W + u_kw;
             const int coff = u_cs + k4 * 4;
             const unsigned bit = 1u << u_tap;
 #pragma unroll
             for (int j = 0; j < A_SLOTS; ++j) {
-                const long long off = (long long)(a_pix0[j] + tap_pix) * sc + coff;
-                a_reg[j] = (a_vmask[j] & bit) ? ld4(base + off) : zero4();
+                const unsigned off = (unsigned)((a_pix0[j] + tap_pix) * sc + coff) * 4u;
+                a_reg[j] = buf_ld4(rs, (a_vmask[j] & bit) ? off : OOB);
             }
         } else {
-            const float* base = p.src[0];
             const int C = p.Cin;
             if (u_c0 == 0 || u_first) {
                 u_first = false;
@@ -198,11 +219,10 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
             const int coff = u_c0 + k4 * 4;
 #pragma unroll
             for (int j = 0; j < A_SLOTS; ++j) {
-                float4 v1 = zero4(), v2 = zero4(), v3 = zero4(), v4 = zero4();
-                if (d_idx[j][0] >= 0) v1 = ld4(base + (long long)d_idx[j][0] * C + coff);
-                if (d_idx[j][1] >= 0) v2 = ld4(base + (long long)d_idx[j][1] * C + coff);
-                if (d_idx[j][2] >= 0) v3 = ld4(base + (long long)d_idx[j][2] * C + coff);
-                if (d_idx[j][3] >= 0) v4 = ld4(base + (long long)d_idx[j][3] * C + coff);
+                const float4 v1 = buf_ld4(r_s0, d_idx[j][0] >= 0 ? (unsigned)(d_idx[j][0] * C + coff) * 4u : OOB);
+                const float4 v2 = buf_ld4(r_s0, d_idx[j][1] >= 0 ? (unsigned)(d_idx[j][1] * C + coff) * 4u : OOB);
+                const float4 v3 = buf_ld4(r_s0, d_idx[j][2] >= 0 ? (unsigned)(d_idx[j][2] * C + coff) * 4u : OOB);
+                const float4 v4 = buf_ld4(r_s0, d_idx[j][3] >= 0 ? (unsigned)(d_idx[j][3] * C + coff) * 4u : OOB);
                 const float w1 = d_w[j][0], w2 = d_w[j][1], w3 = d_w[j][2], w4 = d_w[j][3];
                 float4 v;
                 v.x = fmaf(w4, v4.x, fmaf(w3, v3.x, fmaf(w2, v2.x, w1 * v1.x)));
@@ -226,7 +246,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
     };
 
     auto store_tile = [&](int buf, const float4* a_reg, const u32x4* bh_reg, const u32x4* bl_reg) {
-        _Float16* Ah = lds + buf * BUF;
+        _Float16* Ah = buf ? lds1 : lds0;
         _Float16* Al = Ah + A_SZ;
         _Float16* Bh = Al + A_SZ;
         _Float16* Bl = Bh + B_SZ;
@@ -262,9 +282,10 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
 
     auto mma_tile = [&](int buf) {
         // fragment rows are (tile base, a multiple of 32) + lcol, so the swizzle only depends on lcol
-        const _Float16* Ah = lds + buf * BUF + (wm * (MT * 32) + lcol) * LDH;
+        const _Float16* base = buf ? lds1 : lds0;
+        const _Float16* Ah = base + (wm * (MT * 32) + lcol) * LDH;
         const _Float16* Al = Ah + A_SZ;
-        const _Float16* Bh = lds + buf * BUF + 2 * A_SZ + (wn * (NT * 32) + lcol) * LDH;
+        const _Float16* Bh = base + 2 * A_SZ + (wn * (NT * 32) + lcol) * LDH;
         const _Float16* Bl = Bh + B_SZ;
 #pragma unroll
         for (int ks = 0; ks < BK16 / 16; ++ks) {
@@ -280,14 +301,23 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
                 bh[j] = *reinterpret_cast<const h8*>(Bh + j * 32 * LDH + co);
                 bl[j] = *reinterpret_cast<const h8*>(Bl + j * 32 * LDH + co);
             }
+            // term-major order: an accumulator is reused only after the MT*NT-1 other fragments' MFMAs, so no
+            // MFMA waits on the result of the one issued just before it
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
+                for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
         }
     };
 
@@ -303,20 +333,44 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
             __syncthreads();
         }
     } else {
-        // tiles t+1 and t+2 are in registers / in flight while tile t is multiplied out of LDS
-        const int nk = kt1 - kt0;
+        // tiles t+1 and t+2 are in registers / in flight while tile t is multiplied out of LDS.  In the steady state
+        // the conversion + LDS store of tile t+1 is issued in the same basic block as the MFMAs of tile t and the
+        // scheduler is told to interleave them (one MFMA, a few VALU, an LDS op, ...): the in-order wave then
+        // converts and stores under the 32-cycle shadow of each MFMA instead of after all of them.
+        const int n = kt1 - kt0;
         load_tile(a_reg0, bh_reg0, bl_reg0);
-        if (nk > 1) load_tile(a_reg1, bh_reg1, bl_reg1);
+        if (n > 1) load_tile(a_reg1, bh_reg1, bl_reg1);
         store_tile(0, a_reg0, bh_reg0, bl_reg0);
         __syncthreads();
-        for (int kt = 0; kt < nk; kt += 2) {
-            if (kt + 2 < nk) load_tile(a_reg0, bh_reg0, bl_reg0);           // tile kt+2 -> set 0
-            if (kt + 1 < nk) store_tile(1, a_reg1, bh_reg1, bl_reg1);       // tile kt+1 (loaded an iteration ago)
+        auto fused = [&](int bufc, const float4* a_reg, const u32x4* bh_reg, const u32x4* bl_reg) {
+            store_tile(bufc ^ 1, a_reg, bh_reg, bl_reg);
+            mma_tile(bufc);
+#pragma unroll
+            for (int g = 0; g < MT * NT * 6; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // three VALU (conversion)
+                if (g & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS write
+                else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // an LDS read (next fragments)
+            }
+        };
+        int kt = 0;
+        while (kt + 3 < n) {
+            load_tile(a_reg0, bh_reg0, bl_reg0);      // tile kt+2 -> set 0
+            fused(0, a_reg1, bh_reg1, bl_reg1);       // store tile kt+1 (set 1) into buffer 1, multiply buffer 0
+            __syncthreads();
+            load_tile(a_reg1, bh_reg1, bl_reg1);      // tile kt+3 -> set 1
+            fused(1, a_reg0, bh_reg0, bl_reg0);       // store tile kt+2 (set 0) into buffer 0, multiply buffer 1
+            __syncthreads();
+            kt += 2;
+        }
+        for (; kt < n; kt += 2) {  // tail: same order with the loads / stores guarded
+            if (kt + 2 < n) load_tile(a_reg0, bh_reg0, bl_reg0);
+            if (kt + 1 < n) store_tile(1, a_reg1, bh_reg1, bl_reg1);
             mma_tile(0);
             __syncthreads();
-            if (kt + 1 >= nk) break;
-            if (kt + 3 < nk) load_tile(a_reg1, bh_reg1, bl_reg1);           // tile kt+3 -> set 1
-            if (kt + 2 < nk) store_tile(0, a_reg0, bh_reg0, bl_reg0);       // tile kt+2
+            if (kt + 1 >= n) break;
+            if (kt + 3 < n) load_tile(a_reg1, bh_reg1, bl_reg1);
+            if (kt + 2 < n) store_tile(0, a_reg0, bh_reg0, bl_reg0);
             mma_tile(1);
             __syncthreads();
         }
@@ -327,9 +381,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
 
 template <int MT, int NT, int WM, int WN, bool DCN, bool MULTISRC>
 int launch16(const ConvParams& p, hipStream_t stream) {
-    // measured on MI355X (heads conv, B=32): PF2 233 vs 244 TFLOP/s without -> the loop is LDS-bound, not
-    // latency-bound (32 KB of ds_write + 64 KB of ds_read per 128x128x32 step); keep the single register set.
-    constexpr bool PF2 = false;
+    constexpr bool PF2 = !DCN;
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = p.CoutPad / BN;
@@ -364,6 +416,10 @@ bool cp_conv16_supported(const ConvParams& p) {
     const int bn = cp_conv_tile_n(p.Cout);
     if (bn < 32) return false;
     if (p.offmask && bn < 64) return false;
+    // 32-bit byte offsets of the buffer loads
+    for (int s = 0; s < p.nsrc; ++s)
+        if ((size_t)p.B * p.H * p.W * p.src_c[s] * 4 >= ((size_t)1 << 32)) return false;
+    if ((size_t)p.CoutPad * p.Kpad16 * 2 >= ((size_t)1 << 32)) return false;
     return true;
 }
 
