@@ -195,6 +195,7 @@ def main():
                     "launches_per_step": r["launches"] // args.steps,
                     "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
                     "flops_per_launch": r["flops"] / r["launches"],
+                    "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
                     "share_of_conv_time": round(r["ms"] / total_ms, 4),
                     "all_conv_kernels": {k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                              "ms_per_step": round(v["ms"] / args.steps, 3),
@@ -204,7 +205,10 @@ def main():
             tr = os.path.join(REPO, "profiles", "pmc_traffic.json")
             if os.path.exists(tr):
                 with open(tr) as f:
-                    roof["traffic"] = json.load(f).get(name)
+                    t = json.load(f).get(name)
+                if t:  # HBM-side bytes per launch from the rocprofv3 PMC passes of profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
+                    roof["traffic"] = t["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         lat = None
         if not args.no_latency:
             # per-frame latency at batch 1: frame already in HBM -> detections in HBM, replayed from a hipGraph

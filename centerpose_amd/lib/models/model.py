@@ -86,8 +86,11 @@ class HipPoseNet(object):
 
     def _engine(self):
         if self._hip is None:
+            # arithmetic of the contractions: opt.precision, else $CENTERPOSE_PRECISION, else exact float32
+            import os
+            prec = getattr(self.opt, 'precision', None) or os.environ.get('CENTERPOSE_PRECISION', 'f32')
             self._hip = _hip.HipModel(self.arch, self.heads, self._sd, tracking_task=self.tracking_task,
-                                      head_conv=self.head_conv)
+                                      head_conv=self.head_conv, precision=prec)
         return self._hip
 
     def __call__(self, x, pre_img=None, pre_hm=None, pre_hm_hp=None):

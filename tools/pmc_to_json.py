@@ -13,6 +13,12 @@ fetch_csv, write_csv, out = sys.argv[1], sys.argv[2], sys.argv[3]
 
 
 def variant(kname):
+    m16 = re.search(r"igemm16_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (true|false)>", kname)
+    if m16:
+        mt, nt, wm, wn = (int(m16.group(i)) for i in range(1, 5))
+        dcn, cat = m16.group(5) == "true", m16.group(6) == "true"
+        pre = "dcn_igemm16" if dcn else "igemm16_cat" if cat else "igemm16"
+        return "%s_f16x3_m%dn%d" % (pre, 32 * mt * wm, 32 * nt * wn)
     m = re.search(r"igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (true|false)>", kname)
     if not m:
         return re.sub(r"\(.*", "", kname.replace("(anonymous namespace)::", "").replace("void ", "")).strip()
