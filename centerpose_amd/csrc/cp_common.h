@@ -72,6 +72,7 @@ struct ConvParams {
     // applies the usual epilogue.
     int splitk;
     float* partial;
+    int dbg;  // tuning ablations (tools/conv_bench.py --dbg): 1 skip A loads, 2 skip B loads, 4 skip LDS stores, 8 skip MFMA
     const float* offmask;  // DCN mode: NHWC [B,H,W,32] = 18 offsets (dh,dw interleaved per tap) + 9 masks (already sigmoided) + 5 pad
 };
 

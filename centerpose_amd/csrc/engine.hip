@@ -806,6 +806,12 @@ int cp_model_finalize(cp_model* m) {
     return CP_OK;
 }
 
+int g_dbg = 0;
+int cp_set_debug(int flags) {
+    g_dbg = flags;
+    return CP_OK;
+}
+
 int cp_set_default_precision(int precision) {
     if (precision != CP_PREC_F32 && precision != CP_PREC_F16X3) return fail(CP_ERR_INVALID, "precision must be 0 or 1");
     g_default_precision = precision;
@@ -1010,6 +1016,7 @@ int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const flo
     p.out = out;
     p.store = CP_STORE_NHWC;
     p.ldo = Cout;
+    p.dbg = g_dbg;
     if (g_default_precision == CP_PREC_F16X3 && Cin % 32 == 0 && KH * KW <= 32 && bn >= 32) {
         char* w16 = (char*)workspace + align_up((size_t)p.Kpad * p.CoutPad * sizeof(float), 256);
         const size_t sz = align_up((size_t)p.Kpad * p.CoutPad * 2, 256);

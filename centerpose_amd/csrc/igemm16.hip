@@ -44,6 +44,7 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned vof
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 constexpr unsigned OOB = 0xffffffffu;
+constexpr unsigned OOB_BASE = 0xf0000000u;  // + any channel offset (< 64 KiB) is still beyond every supported tensor
 
 struct Split2 {
     uint32_t hi, lo;  // two binary16 values each
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
     // ---- per-thread A-slot geometry: slot j covers pixel row (tid / 8) + 32 * j, float4 column tid % 8 ----
     const int k4 = tid & 7;
     int a_b[A_SLOTS], a_h0[A_SLOTS], a_w0[A_SLOTS], a_pix0[A_SLOTS];
-    unsigned a_vmask[A_SLOTS];
+    unsigned a_vmask[A_SLOTS], a_byte0[A_SLOTS];
     bool a_ok[A_SLOTS];
 #pragma unroll
     for (int j = 0; j < A_SLOTS; ++j) {
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
         a_h0[j] = ho * p.stride - p.pad;
         a_w0[j] = wo * p.stride - p.pad;
         a_pix0[j] = (b * p.H + a_h0[j]) * p.W + a_w0[j];
+        a_byte0[j] = (unsigned)(a_pix0[j] * p.src_c[0] + k4 * 4) * 4u;  // single-source fast path (wraps for halo; masked)
         unsigned vm = 0u;
         if (!DCN && a_ok[j]) {
             for (int kh = 0; kh < p.KH; ++kh)
@@ -159,10 +161,14 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
         b_off[j] = (unsigned)(((size_t)(tn * BN + f / 4) * p.Kpad16 + (f % 4) * 8 + (size_t)kt0 * BK16) * 2);
     }
 
+    bool dbg_first = true;
     auto load_tile = [&](float4* a_reg, u32x4* bh_reg, u32x4* bl_reg) {
+        const bool skipA = (p.dbg & 1) && !dbg_first, skipB = (p.dbg & 2) && !dbg_first;
+        dbg_first = false;
 #pragma unroll
         for (int j = 0; j < B_SLOTS; ++j) {
             const int f = tid + j * NT16;
+            if (skipB) break;
             if (B_CHUNKS % NT16 == 0 || f < B_CHUNKS) {
                 bh_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(r_wh, (int)b_off[j], 0, 0);
                 bl_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)b_off[j], 0, 0);
@@ -180,10 +186,18 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
             const int tap_pix = u_kh * p.W + u_kw;
             const int coff = u_cs + k4 * 4;
             const unsigned bit = 1u << u_tap;
+            if (skipA) {
+            } else if (MULTISRC) {
 #pragma unroll
-            for (int j = 0; j < A_SLOTS; ++j) {
-                const unsigned off = (unsigned)((a_pix0[j] + tap_pix) * sc + coff) * 4u;
-                a_reg[j] = buf_ld4(rs, (a_vmask[j] & bit) ? off : OOB);
+                for (int j = 0; j < A_SLOTS; ++j) {
+                    const unsigned off = (unsigned)((a_pix0[j] + tap_pix) * sc + coff) * 4u;
+                    a_reg[j] = buf_ld4(rs, (a_vmask[j] & bit) ? off : OOB);
+                }
+            } else {
+                // per-slot byte base is fixed; the (tap, channel) part is wave-uniform scalar arithmetic
+                const unsigned uoff = (unsigned)(tap_pix * sc + u_cs) * 4u;
+#pragma unroll
+                for (int j = 0; j < A_SLOTS; ++j) a_reg[j] = buf_ld4(rs, (a_vmask[j] & bit) ? a_byte0[j] + uoff : OOB);
             }
         } else {
             const int C = p.Cin;
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
                 u_first = false;
 #pragma unroll
                 for (int j = 0; j < A_SLOTS; ++j) {
-                    int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
+                    int i0 = (int)OOB_BASE, i1 = (int)OOB_BASE, i2 = (int)OOB_BASE, i3 = (int)OOB_BASE;
                     float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
                     if (a_ok[j]) {
                         const size_t pix = (size_t)(a_b[j] * p.H + (a_h0[j] + p.pad)) * p.W + (a_w0[j] + p.pad);
@@ -204,11 +218,14 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
                             const int h_hi = h_lo + 1, w_hi = w_lo + 1;
                             const float lh = h_im - (float)h_lo, lw = w_im - (float)w_lo;
                             const float hh = 1.f - lh, hw = 1.f - lw;
+                            // byte offsets of the 4 corners' channel vectors (invalid corners keep OOB_BASE, which
+                            // stays out of range after the small per-K-step channel offset is added)
                             const int bb = a_b[j] * p.H;
-                            if (h_lo >= 0 && w_lo >= 0) i0 = (bb + h_lo) * p.W + w_lo;
-                            if (h_lo >= 0 && w_hi <= p.W - 1) i1 = (bb + h_lo) * p.W + w_hi;
-                            if (h_hi <= p.H - 1 && w_lo >= 0) i2 = (bb + h_hi) * p.W + w_lo;
-                            if (h_hi <= p.H - 1 && w_hi <= p.W - 1) i3 = (bb + h_hi) * p.W + w_hi;
+                            const int cb = C * 4;
+                            if (h_lo >= 0 && w_lo >= 0) i0 = ((bb + h_lo) * p.W + w_lo) * cb;
+                            if (h_lo >= 0 && w_hi <= p.W - 1) i1 = ((bb + h_lo) * p.W + w_hi) * cb;
+                            if (h_hi <= p.H - 1 && w_lo >= 0) i2 = ((bb + h_hi) * p.W + w_lo) * cb;
+                            if (h_hi <= p.H - 1 && w_hi <= p.W - 1) i3 = ((bb + h_hi) * p.W + w_hi) * cb;
                             w1 = hh * hw * mk; w2 = hh * lw * mk; w3 = lh * hw * mk; w4 = lh * lw * mk;
                         }
                     }
@@ -216,13 +233,13 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
                     d_w[j][0] = w1; d_w[j][1] = w2; d_w[j][2] = w3; d_w[j][3] = w4;
                 }
             }
-            const int coff = u_c0 + k4 * 4;
+            const unsigned coff = (unsigned)(u_c0 + k4 * 4) * 4u;
 #pragma unroll
             for (int j = 0; j < A_SLOTS; ++j) {
-                const float4 v1 = buf_ld4(r_s0, d_idx[j][0] >= 0 ? (unsigned)(d_idx[j][0] * C + coff) * 4u : OOB);
-                const float4 v2 = buf_ld4(r_s0, d_idx[j][1] >= 0 ? (unsigned)(d_idx[j][1] * C + coff) * 4u : OOB);
-                const float4 v3 = buf_ld4(r_s0, d_idx[j][2] >= 0 ? (unsigned)(d_idx[j][2] * C + coff) * 4u : OOB);
-                const float4 v4 = buf_ld4(r_s0, d_idx[j][3] >= 0 ? (unsigned)(d_idx[j][3] * C + coff) * 4u : OOB);
+                const float4 v1 = buf_ld4(r_s0, (unsigned)d_idx[j][0] + coff);
+                const float4 v2 = buf_ld4(r_s0, (unsigned)d_idx[j][1] + coff);
+                const float4 v3 = buf_ld4(r_s0, (unsigned)d_idx[j][2] + coff);
+                const float4 v4 = buf_ld4(r_s0, (unsigned)d_idx[j][3] + coff);
                 const float w1 = d_w[j][0], w2 = d_w[j][1], w3 = d_w[j][2], w4 = d_w[j][3];
                 float4 v;
                 v.x = fmaf(w4, v4.x, fmaf(w3, v3.x, fmaf(w2, v2.x, w1 * v1.x)));
@@ -245,7 +262,10 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
         }
     };
 
+    bool dbg_first_store = true;
     auto store_tile = [&](int buf, const float4* a_reg, const u32x4* bh_reg, const u32x4* bl_reg) {
+        if ((p.dbg & 4) && !dbg_first_store) return;
+        dbg_first_store = false;
         _Float16* Ah = buf ? lds1 : lds0;
         _Float16* Al = Ah + A_SZ;
         _Float16* Bh = Al + A_SZ;
@@ -281,6 +301,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
     const int lcol = lane & 31;
 
     auto mma_tile = [&](int buf) {
+        if (p.dbg & 8) return;
         // fragment rows are (tile base, a multiple of 32) + lcol, so the swizzle only depends on lcol
         const _Float16* base = buf ? lds1 : lds0;
         const _Float16* Ah = base + (wm * (MT * 32) + lcol) * LDH;
@@ -418,7 +439,7 @@ bool cp_conv16_supported(const ConvParams& p) {
     if (p.offmask && bn < 64) return false;
     // 32-bit byte offsets of the buffer loads
     for (int s = 0; s < p.nsrc; ++s)
-        if ((size_t)p.B * p.H * p.W * p.src_c[s] * 4 >= ((size_t)1 << 32)) return false;
+        if ((size_t)p.B * p.H * p.W * p.src_c[s] * 4 >= (size_t)0xf0000000u) return false;
     if ((size_t)p.CoutPad * p.Kpad16 * 2 >= ((size_t)1 << 32)) return false;
     return true;
 }

@@ -61,6 +61,7 @@ def lib():
     _sig(L.cp_model_detect, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
          ctypes.POINTER(c_void_p), c_int, c_int, c_int, ctypes.c_float, c_int, c_void_p, c_void_p, c_size_t, c_int)
     _sig(L.cp_set_default_precision, c_int, c_int)
+    _sig(L.cp_set_debug, c_int, c_int)
     _sig(L.cp_model_set_precision, c_int, c_void_p, c_int)
     _sig(L.cp_model_profile, c_int, c_void_p, c_int)
     _sig(L.cp_model_profile_read, c_int, c_void_p, ctypes.POINTER(ctypes.c_double), c_int)
@@ -77,7 +78,7 @@ def exported_symbols():
             "cp_model_set_param", "cp_model_finalize", "cp_model_destroy", "cp_model_workspace_bytes",
             "cp_model_forward", "cp_model_forward_tap", "cp_conv2d_workspace_bytes", "cp_conv2d_nhwc",
             "cp_decode_workspace_bytes", "cp_decode", "cp_pnp_workspace_bytes", "cp_pnp_solve", "cp_model_profile", "cp_model_profile_read",
-            "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect"]
+            "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug"]
 
 
 def _check(rc, what):

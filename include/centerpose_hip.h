@@ -109,6 +109,8 @@ int cp_model_forward_tap(cp_model* m, cp_stream_t stream, int B, int H, int W, c
 #define CP_PREC_F32 0
 #define CP_PREC_F16X3 1
 int cp_set_default_precision(int precision);
+/* Kernel-tuning ablation switches for cp_conv2d_nhwc (tools/conv_bench.py --dbg); results are wrong when non-zero. */
+int cp_set_debug(int flags);
 int cp_model_set_precision(cp_model* m, int precision);
 
 /* Per-launch timing of the implicit-GEMM kernels with HIP events recorded on the launch stream

@@ -20,9 +20,11 @@ ap.add_argument("--k", type=int, default=3)
 ap.add_argument("--stride", type=int, default=1)
 ap.add_argument("--prec", default="f16x3")
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--dbg", type=int, default=0, help="ablation flags: 1 skip A loads, 2 skip B loads, 4 skip LDS stores, 8 skip MFMA")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 hip.set_default_precision(a.prec)
+hip.lib().cp_set_debug(a.dbg)
 x = torch.randn(a.B, a.H, a.W, a.cin, device=dev)
 w = torch.randn(a.cout, a.cin, a.k, a.k, device=dev) / (a.cin * a.k * a.k) ** 0.5
 for _ in range(3):
@@ -34,4 +36,5 @@ for _ in range(a.iters):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.iters
 fl = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * a.cout * a.cin * a.k * a.k
+print("dbg=%d " % a.dbg, end="")
 print("%s B%d %dx%d %d->%d k%d: %.3f ms  %.1f TFLOP/s (incl. weight pack)" % (a.prec, a.B, a.H, a.W, a.cin, a.cout, a.k, dt * 1e3, fl / dt / 1e12))
