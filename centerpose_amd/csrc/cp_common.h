@@ -141,3 +141,6 @@ int cp_launch_decode(hipStream_t s, int B, int J, int H, int W, float* hm, const
 size_t cp_pnp_ws_bytes(int N);
 int cp_launch_pnp(hipStream_t s, const float* pts, const float* scale, const double* cam, int N, int npts, double* out,
                   void* ws);
+
+int cp_launch_preprocess(const unsigned char* img, int H, int W, const float* minv6, const float* mean3,
+                         const float* std3, float* out, int OH, int OW, hipStream_t s);

@@ -1031,6 +1031,14 @@ int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const flo
     return cp_launch_conv(p, s);
 }
 
+int cp_preprocess(cp_stream_t stream, const unsigned char* image_hwc_bgr, int H, int W, const float* inv_trans6,
+                  const float* mean3, const float* std3, float* out_chw, int out_h, int out_w) {
+    if (!image_hwc_bgr || !inv_trans6 || !mean3 || !std3 || !out_chw || H < 1 || W < 1 || out_h < 1 || out_w < 1)
+        return fail(CP_ERR_INVALID, "bad argument");
+    return cp_launch_preprocess(image_hwc_bgr, H, W, inv_trans6, mean3, std3, out_chw, out_h, out_w,
+                                (hipStream_t)stream);
+}
+
 size_t cp_pnp_workspace_bytes(int N) { return cp_pnp_ws_bytes(N); }
 
 int cp_pnp_solve(cp_stream_t stream, const float* pts, const float* scale, const double* cam, int N, int npts,

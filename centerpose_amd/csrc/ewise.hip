@@ -260,6 +260,41 @@ __global__ void gn_finalize_kernel(const double* __restrict__ stats, float* __re
     mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// BaseDetector.pre_process on device (base_detector.py:127-134): warpAffine(INTER_LINEAR, constant 0 border) of an
+// 8-bit HWC BGR frame to the network input size, then (x / 255 - mean) / std, written NCHW float32.  `minv` maps
+// output pixel (x, y) to source coordinates (the inverse of trans_input).  Float bilinear weights (cv2 uses 5-bit
+// fixed-point weights, so values can differ from cv2 by a few 1/255 steps).
+struct PreParams {
+    float m[6];
+    float mean[3], inv_std[3];
+};
+
+__global__ void preprocess_kernel(const unsigned char* __restrict__ img, int H, int W, float* __restrict__ out, int OH,
+                                  int OW, PreParams pp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= OH * OW) return;
+    const int y = i / OW, x = i - y * OW;
+    const float sx = pp.m[0] * x + pp.m[1] * y + pp.m[2];
+    const float sy = pp.m[3] * x + pp.m[4] * y + pp.m[5];
+    const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+    const float fx = sx - x0, fy = sy - y0;
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int xx = x0 + dx, yy = y0 + dy;
+            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+            const float wgt = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy);
+            const unsigned char* px = img + ((size_t)yy * W + xx) * 3;
+            acc[0] += wgt * px[0];
+            acc[1] += wgt * px[1];
+            acc[2] += wgt * px[2];
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[(size_t)c * OH * OW + i] = (acc[c] / 255.f - pp.mean[c]) * pp.inv_std[c];
+}
+
 inline int check() { return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH; }
 
 }  // namespace
@@ -333,5 +368,17 @@ int cp_launch_pack_weight(const float* w, float* wp, int Cout, int Cin, int taps
 
 int cp_launch_gn_finalize(const double* stats, float* mr, int n, double count, float eps, hipStream_t s) {
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, stats, mr, n, count, eps);
+    return check();
+}
+
+int cp_launch_preprocess(const unsigned char* img, int H, int W, const float* minv6, const float* mean3,
+                         const float* std3, float* out, int OH, int OW, hipStream_t s) {
+    PreParams pp;
+    for (int i = 0; i < 6; ++i) pp.m[i] = minv6[i];
+    for (int i = 0; i < 3; ++i) {
+        pp.mean[i] = mean3[i];
+        pp.inv_std[i] = 1.f / std3[i];
+    }
+    hipLaunchKernelGGL(preprocess_kernel, dim3((OH * OW + 255) / 256), dim3(256), 0, s, img, H, W, out, OH, OW, pp);
     return check();
 }

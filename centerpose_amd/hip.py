@@ -62,6 +62,8 @@ def lib():
          ctypes.POINTER(c_void_p), c_int, c_int, c_int, ctypes.c_float, c_int, c_void_p, c_void_p, c_size_t, c_int)
     _sig(L.cp_set_default_precision, c_int, c_int)
     _sig(L.cp_set_debug, c_int, c_int)
+    _sig(L.cp_preprocess, c_int, c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_float),
+         ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_void_p, c_int, c_int)
     _sig(L.cp_model_set_precision, c_int, c_void_p, c_int)
     _sig(L.cp_model_profile, c_int, c_void_p, c_int)
     _sig(L.cp_model_profile_read, c_int, c_void_p, ctypes.POINTER(ctypes.c_double), c_int)
@@ -78,7 +80,7 @@ def exported_symbols():
             "cp_model_set_param", "cp_model_finalize", "cp_model_destroy", "cp_model_workspace_bytes",
             "cp_model_forward", "cp_model_forward_tap", "cp_conv2d_workspace_bytes", "cp_conv2d_nhwc",
             "cp_decode_workspace_bytes", "cp_decode", "cp_pnp_workspace_bytes", "cp_pnp_solve", "cp_model_profile", "cp_model_profile_read",
-            "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug"]
+            "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug", "cp_preprocess"]
 
 
 def _check(rc, what):
@@ -178,6 +180,25 @@ def decode_raw(hm, hps, wh, hm_hp, hps_uncertainty=None, scale=None, scale_uncer
 def split_detections(det):
     """[B,K,118] -> dict of the 13 reference keys (views)."""
     return OrderedDict((k, det[..., o:o + w]) for k, (o, w) in DET_FIELDS.items())
+
+
+def preprocess(image_u8_hwc, trans_input, mean, std, out_h, out_w):
+    """Device warp + normalise of one BGR uint8 frame [H,W,3] -> float32 [1,3,out_h,out_w]
+    (BaseDetector.pre_process, base_detector.py:127-134).  ``trans_input`` is the 2x3 source->input affine."""
+    import numpy as np
+
+    L = lib()
+    if not (image_u8_hwc.is_cuda and image_u8_hwc.dtype == torch.uint8 and image_u8_hwc.is_contiguous()):
+        raise RuntimeError("preprocess: image must be a contiguous uint8 device tensor [H,W,3]")
+    H, W = int(image_u8_hwc.shape[0]), int(image_u8_hwc.shape[1])
+    minv = np.linalg.inv(np.vstack([np.asarray(trans_input, np.float64), [0, 0, 1]]))[:2].astype(np.float32).reshape(-1)
+    f3 = ctypes.c_float * 3
+    out = torch.empty(1, 3, out_h, out_w, device=image_u8_hwc.device, dtype=torch.float32)
+    rc = L.cp_preprocess(_stream(), _ptr(image_u8_hwc), H, W, (ctypes.c_float * 6)(*minv.tolist()),
+                         f3(*[float(v) for v in np.asarray(mean).reshape(-1)]),
+                         f3(*[float(v) for v in np.asarray(std).reshape(-1)]), _ptr(out), out_h, out_w)
+    _check(rc, "cp_preprocess")
+    return out
 
 
 PNP_STRIDE = 40

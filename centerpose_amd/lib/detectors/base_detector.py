@@ -119,9 +119,15 @@ class BaseDetector(object):
         out_width = inp_width // self.opt.down_ratio
         trans_output = get_affine_transform(c, s, 0, [out_width, out_height])
         resized_image = _resize(image, new_width, new_height)
-        inp_image = warp_affine_bilinear(resized_image, trans_input, inp_width, inp_height)
-        inp_image = ((inp_image / 255. - self.mean) / self.std).astype(np.float32)
-        images = torch.from_numpy(inp_image.transpose(2, 0, 1).reshape(1, 3, inp_height, inp_width))
+        if self.opt.device.type == 'cuda' and resized_image.dtype == np.uint8 and resized_image.ndim == 3:
+            # warp + normalise on the device (cp_preprocess); the 8-bit frame is the only host->device copy
+            from centerpose_amd import hip as _hip
+            frame = torch.from_numpy(np.ascontiguousarray(resized_image)).to(self.opt.device)
+            images = _hip.preprocess(frame, trans_input, self.mean, self.std, inp_height, inp_width)
+        else:
+            inp_image = warp_affine_bilinear(resized_image, trans_input, inp_width, inp_height)
+            inp_image = ((inp_image / 255. - self.mean) / self.std).astype(np.float32)
+            images = torch.from_numpy(inp_image.transpose(2, 0, 1).reshape(1, 3, inp_height, inp_width))
         meta = {'c': c, 's': s, 'height': height, 'width': width, 'out_height': out_height, 'out_width': out_width,
                 'inp_height': inp_height, 'inp_width': inp_width, 'trans_input': trans_input,
                 'trans_output': trans_output}

@@ -167,6 +167,16 @@ int cp_decode(cp_stream_t stream, int B, int H, int W, float* hm, const float* h
               void* workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------
+ * Pre-process — replaces the warp + normalise part of `BaseDetector.pre_process`
+ *   (detectors/base_detector.py:127-134: cv2.warpAffine(..., INTER_LINEAR) then (x/255 - mean)/std, HWC->CHW).
+ * image_hwc_bgr: DEVICE uint8 [H,W,3] (BGR as cv2.imread gives); inv_trans6: HOST float[6], the row-major 2x3
+ * matrix mapping OUTPUT pixel (x,y) to source coordinates (inverse of `trans_input`); mean3/std3: HOST float[3]
+ * (opts.py:436-437); out_chw: DEVICE float32 [3,out_h,out_w].  Float bilinear weights (cv2 uses 5-bit fixed point).
+ * ------------------------------------------------------------------------------------------ */
+int cp_preprocess(cp_stream_t stream, const unsigned char* image_hwc_bgr, int H, int W, const float* inv_trans6,
+                  const float* mean3, const float* std3, float* out_chw, int out_h, int out_w);
+
+/* ------------------------------------------------------------------------------------------
  * Batched cuboid PnP — replaces the per-detection loop `pnp_shell` -> `CuboidPNPSolver.solve_pnp`
  *   -> `cv2.solvePnPGeneric(SOLVEPNP_ITERATIVE)` + `cv2.projectPoints`
  *   (utils/pnp/cuboid_pnp_shell.py:11-24, utils/pnp/cuboid_pnp_solver.py:141-239,

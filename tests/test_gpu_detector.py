@@ -94,7 +94,7 @@ def test_detector_run_and_run_batch_schema(device, tmp_path):
         assert keys <= set(r)
     # head tensors vs the CPU oracle on the same pre-processed frame (post-sigmoid heat-map <= 1e-3)
     images, meta = det.pre_process(img, 1.0, meta_inp)
-    zo = ob.dlaseg_forward(sd, images, opt.heads, arch="dlav1")
+    zo = ob.dlaseg_forward(sd, images.cpu(), opt.heads, arch="dlav1")
     assert float((ret["output"]["hm"].cpu() - torch.sigmoid(zo["hm"])).abs().max()) < 1e-3
     # batched path gives the same detections as the per-image path
     img2 = rng.randint(0, 255, (480, 640, 3)).astype(np.uint8)
@@ -122,3 +122,20 @@ def test_load_model_handles_reference_checkpoint_quirks(device, tmp_path):
     x = synth.frames(1, seed=3, h=64, w=64).to(device)
     z = m(x)[-1]
     assert z["hm"].shape == (1, 1, 16, 16) and torch.isfinite(z["hps"]).all()
+
+
+def test_device_preprocess_matches_host_restatement(device):
+    """cp_preprocess vs the float numpy warp + normalise (base_detector.py:127-134) on a 480x640 frame."""
+    from centerpose_amd.lib.utils.image import get_affine_transform, warp_affine_bilinear
+
+    rng = np.random.RandomState(3)
+    img = rng.randint(0, 256, (480, 640, 3)).astype(np.uint8)
+    c = np.array([320.0, 240.0], np.float32)
+    trans = get_affine_transform(c, 640.0, 0, [512, 512])
+    mean = np.array([0.408, 0.447, 0.470], np.float32)
+    std = np.array([0.289, 0.274, 0.278], np.float32)
+    ref = ((warp_affine_bilinear(img, trans, 512, 512) / 255.0 - mean.reshape(1, 1, 3)) / std.reshape(1, 1, 3))
+    ref = ref.astype(np.float32).transpose(2, 0, 1)
+    out = hip.preprocess(torch.from_numpy(img).to(device), trans, mean, std, 512, 512).cpu().numpy()[0]
+    np.testing.assert_allclose(out, ref, atol=2e-4)
+    assert out[:, 0, 0].tolist() == pytest.approx(((0 - mean) / std).tolist(), abs=1e-6)  # padding rows are "black"
