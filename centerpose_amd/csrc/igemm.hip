@@ -66,6 +66,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void igemm_kernel(const ConvParams p, 
     const int HWo = p.Ho * p.Wo;
 
     // ---- per-thread A-slot geometry (fixed over the K loop) ----
+    const float rcp_hwo = 1.f / (float)HWo, rcp_wo = 1.f / (float)p.Wo;
+    const bool big_m = M >= (1 << 24);
     const int k4 = tid & 3;
     int a_b[A_SLOTS], a_h0[A_SLOTS], a_w0[A_SLOTS];
     int a_pix0[A_SLOTS];       // (b*H + h0)*W + w0, may be negative (halo)
@@ -76,20 +78,15 @@ __global__ __launch_bounds__(NTHREADS, 3) void igemm_kernel(const ConvParams p, 
         const int m = tm * BM + (tid >> 2) + j * 64;
         a_ok[j] = m < M;
         const int mm = a_ok[j] ? m : 0;
-        const int b = mm / HWo, rem = mm - b * HWo;
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        int rem, wo;
+        const int b = div_small(mm, HWo, rcp_hwo, &rem, big_m);
+        const int ho = div_small(rem, p.Wo, rcp_wo, &wo, big_m);
         a_b[j] = b;
         a_h0[j] = ho * p.stride - p.pad;
         a_w0[j] = wo * p.stride - p.pad;
         a_pix0[j] = (b * p.H + a_h0[j]) * p.W + a_w0[j];
         unsigned vm = 0u;
-        if (ALIGNED && !DCN && a_ok[j]) {
-            for (int kh = 0; kh < p.KH; ++kh)
-                for (int kw = 0; kw < p.KW; ++kw) {
-                    const int hi = a_h0[j] + kh, wi = a_w0[j] + kw;
-                    if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) vm |= 1u << (kh * p.KW + kw);
-                }
-        }
+        if (ALIGNED && !DCN && a_ok[j]) vm = tap_valid_mask(a_h0[j], a_w0[j], p.H, p.W, p.KH, p.KW);
         a_vmask[j] = vm;
     }
 

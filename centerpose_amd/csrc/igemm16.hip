@@ -36,9 +36,6 @@ constexpr int NT16 = 256;
 // Raw buffer loads (SRD + 32-bit byte offset): an out-of-range offset returns 0, so halo / invalid taps need no
 // exec-mask branch around the load -- and without control flow between the loads the compiler can wait for tile
 // t+1 with a counted s_waitcnt vmcnt(N) while tile t+2 stays in flight.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
 __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
@@ -67,6 +64,13 @@ __device__ __forceinline__ Split2 split2(float a, float b) {
 
 // PF2: two register sets for the global->LDS staging, i.e. tile t+2 is in flight while tile t is multiplied (a
 // 32-deep K-step is only ~770 MFMA cycles per wave, shorter than an L2 round trip under load).
+// tuning ablation switches (cp_set_debug) are compiled in only with -DCP_TUNE_DBG: as run-time branches they split
+// the fused steady-state block and cost ~5%
+#ifdef CP_TUNE_DBG
+#define CP_DBG(p) ((p).dbg)
+#else
+#define CP_DBG(p) 0
+#endif
 template <int MT, int NT, int WM, int WN, bool DCN, bool MULTISRC, bool PF2>
 __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     typedef Frag<32> F;
@@ -91,6 +95,8 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
     const int tn = tile % tiles_n, tm = tile / tiles_n;
     const int M = p.B * p.Ho * p.Wo;
     const int HWo = p.Ho * p.Wo;
+    const float rcp_hwo = 1.f / (float)HWo, rcp_wo = 1.f / (float)p.Wo;
+    const bool big_m = M >= (1 << 24);
 
     // ---- per-thread A-slot geometry: slot j covers pixel row (tid / 8) + 32 * j, float4 column tid % 8 ----
     const int k4 = tid & 7;
@@ -102,22 +108,15 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
         const int m = tm * BM + (tid >> 3) + j * 32;
         a_ok[j] = m < M;
         const int mm = a_ok[j] ? m : 0;
-        const int b = mm / HWo, rem = mm - b * HWo;
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        int rem, wo;
+        const int b = div_small(mm, HWo, rcp_hwo, &rem, big_m);
+        const int ho = div_small(rem, p.Wo, rcp_wo, &wo, big_m);
         a_b[j] = b;
         a_h0[j] = ho * p.stride - p.pad;
         a_w0[j] = wo * p.stride - p.pad;
         a_pix0[j] = (b * p.H + a_h0[j]) * p.W + a_w0[j];
         a_byte0[j] = (unsigned)(a_pix0[j] * p.src_c[0] + k4 * 4) * 4u;  // single-source fast path (wraps for halo; masked)
-        unsigned vm = 0u;
-        if (!DCN && a_ok[j]) {
-            for (int kh = 0; kh < p.KH; ++kh)
-                for (int kw = 0; kw < p.KW; ++kw) {
-                    const int hi = a_h0[j] + kh, wi = a_w0[j] + kw;
-                    if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) vm |= 1u << (kh * p.KW + kw);
-                }
-        }
-        a_vmask[j] = vm;
+        a_vmask[j] = (!DCN && a_ok[j]) ? tap_valid_mask(a_h0[j], a_w0[j], p.H, p.W, p.KH, p.KW) : 0u;
     }
 
     float4 a_reg0[A_SLOTS], a_reg1[PF2 ? A_SLOTS : 1];
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
 
     bool dbg_first = true;
     auto load_tile = [&](float4* a_reg, u32x4* bh_reg, u32x4* bl_reg) {
-        const bool skipA = (p.dbg & 1) && !dbg_first, skipB = (p.dbg & 2) && !dbg_first;
+        const bool skipA = (CP_DBG(p) & 1) && !dbg_first, skipB = (CP_DBG(p) & 2) && !dbg_first;
         dbg_first = false;
 #pragma unroll
         for (int j = 0; j < B_SLOTS; ++j) {
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
 
     bool dbg_first_store = true;
     auto store_tile = [&](int buf, const float4* a_reg, const u32x4* bh_reg, const u32x4* bl_reg) {
-        if ((p.dbg & 4) && !dbg_first_store) return;
+        if ((CP_DBG(p) & 4) && !dbg_first_store) return;
         dbg_first_store = false;
         _Float16* Ah = buf ? lds1 : lds0;
         _Float16* Al = Ah + A_SZ;
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
     const int lcol = lane & 31;
 
     auto mma_tile = [&](int buf) {
-        if (p.dbg & 8) return;
+        if (CP_DBG(p) & 8) return;
         // fragment rows are (tile base, a multiple of 32) + lcol, so the swizzle only depends on lcol
         const _Float16* base = buf ? lds1 : lds0;
         const _Float16* Ah = base + (wm * (MT * 32) + lcol) * LDH;
@@ -400,6 +399,300 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
     else igemm_epilogue<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Software-pipelined K loop (non-DCN layers).  Same tiles, LDS layout, loaders and epilogue as igemm16_kernel, but the
+// order in which a wave issues its work is written out by hand and pinned with sched_barrier, because the wave is
+// in-order and the MFMA pipe is only busy while something else is NOT making the wave wait:
+//
+//   iteration t (tile t in LDS buffer t&1; fragment sets F0 = k-step 0, F1 = k-step 1; one register set G holds the
+//   global data of tile t+1):
+//     phase 1   MFMAs of (t, k-step 0) out of F0, and in their shadow:  ds_read F1 <- (t, k-step 1);
+//               convert + ds_write tile t+1 (G) into buffer (t+1)&1
+//     barrier   tile t+1 complete in LDS; every wave has read all of tile t  ->  buffer t&1 is free
+//     phase 2   MFMAs of (t, k-step 1) out of F1, and in their shadow:  buffer_load tile t+2 -> G;
+//               ds_read F0 <- (t+1, k-step 0)
+//   so every ds_read is issued >= 3*MT*NT/2 MFMAs before its first use, every global load half a tile (>= 12 MFMAs
+//   of this wave plus the co-resident wave's, > an L2 hit) before its conversion, the conversion VALU / LDS stores
+//   sit between MFMAs instead of after them, and there is one barrier per tile.  Tiles past the end of K are loaded with out-of-range offsets (zeros, no memory traffic) and stored
+//   into a buffer nobody reads, which keeps the loop body branch-free.
+// ---------------------------------------------------------------------------------------------------------------
+// build-time ablations for tuning (make EXP=<bitmask>; timing only, results are wrong): 1 no global loads in the
+// loop, 2 no conversion / LDS stores in the loop, 4 no barrier in the loop, 8 no MFMA, 16 no epilogue
+#ifndef CP_EXP
+#define CP_EXP 0
+#endif
+template <int MT, int NT, int WM, int WN, bool MULTISRC>
+__global__ __launch_bounds__(NT16, 2) void igemm16p_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
+    typedef Frag<32> F;
+    typedef F::acc_t acc_t;
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+    static_assert(WM * WN * 64 == NT16, "4 waves");
+    constexpr int A_SLOTS = BM * BK16 / 4 / NT16;
+    constexpr int B_CHUNKS = BN * BK16 * 2 / 16;
+    constexpr int B_SLOTS = (B_CHUNKS + NT16 - 1) / NT16;
+    constexpr bool B_PART = B_CHUNKS % NT16 != 0;
+    constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;
+    constexpr int BUF = 2 * A_SZ + 2 * B_SZ;
+    constexpr int NM = 3 * MT * NT;        // MFMAs per phase
+    constexpr int NR = 2 * MT + 2 * NT;    // fragment reads per phase
+    // one LDS object, the two tile buffers are selected by a run-time offset: the loop body exists once, so the
+    // accumulators / fragments / staging registers keep their allocation across the back edge (the order of the LDS
+    // reads and writes is pinned by hand below, no alias analysis needed)
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int tile = tile_of_block(tiles_m, tiles_n);
+    const int tn = tile % tiles_n, tm = tile / tiles_n;
+    const int M = p.B * p.Ho * p.Wo;
+    const int HWo = p.Ho * p.Wo;
+    const float rcp_hwo = 1.f / (float)HWo, rcp_wo = 1.f / (float)p.Wo;
+    const bool big_m = M >= (1 << 24);
+
+    const int k4 = tid & 7;
+    int a_pix0[A_SLOTS];
+    unsigned a_vmask[A_SLOTS], a_byte0[A_SLOTS];
+#pragma unroll
+    for (int j = 0; j < A_SLOTS; ++j) {
+        const int m = tm * BM + (tid >> 3) + j * 32;
+        const bool ok = m < M;
+        const int mm = ok ? m : 0;
+        int rem, wo;
+        const int b = div_small(mm, HWo, rcp_hwo, &rem, big_m);
+        const int ho = div_small(rem, p.Wo, rcp_wo, &wo, big_m);
+        const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+        a_pix0[j] = (b * p.H + h0) * p.W + w0;
+        a_byte0[j] = (unsigned)(a_pix0[j] * p.src_c[0] + k4 * 4) * 4u;
+        a_vmask[j] = ok ? tap_valid_mask(h0, w0, p.H, p.W, p.KH, p.KW) : 0u;
+    }
+
+    const int nk = p.Kpad16 / BK16;
+    int kt0, kt1;
+    splitk_range(p, nk, &kt0, &kt1);
+    const int n = kt1 - kt0;
+    if ((CP_EXP & 32) && blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < n / 4; ++i) __builtin_amdgcn_s_sleep(127);
+    int u_tap = 0, u_kh = 0, u_kw = 0, u_c0 = 0, u_src = 0, u_cs = 0;
+    if (kt0 > 0) {
+        const int k0 = kt0 * BK16;
+        u_tap = k0 / p.Cin;
+        u_c0 = k0 - u_tap * p.Cin;
+        u_kh = u_tap / p.KW;
+        u_kw = u_tap - u_kh * p.KW;
+        u_cs = u_c0;
+        if (MULTISRC) {
+            for (int q = 0; q < 3; ++q) {
+                const int cur = q == 0 ? p.src_c[0] : q == 1 ? p.src_c[1] : p.src_c[2];
+                if (u_src == q && u_cs >= cur) { u_cs -= cur; ++u_src; }
+            }
+        }
+    }
+
+    const unsigned w_bytes = (unsigned)((size_t)p.CoutPad * p.Kpad16 * 2);
+    const __amdgpu_buffer_rsrc_t r_wh = make_rsrc(p.w16_hi, w_bytes), r_wl = make_rsrc(p.w16_lo, w_bytes);
+    const unsigned img_px = (unsigned)p.B * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t r_s0 = make_rsrc(p.src[0], img_px * p.src_c[0] * 4u);
+    const __amdgpu_buffer_rsrc_t r_s1 = make_rsrc(MULTISRC ? p.src[1] : p.src[0], MULTISRC ? img_px * p.src_c[1] * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t r_s2 = make_rsrc(MULTISRC && p.nsrc > 2 ? p.src[2] : p.src[0], MULTISRC && p.nsrc > 2 ? img_px * p.src_c[2] * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t r_s3 = make_rsrc(MULTISRC && p.nsrc > 3 ? p.src[3] : p.src[0], MULTISRC && p.nsrc > 3 ? img_px * p.src_c[3] * 4u : 0u);
+    unsigned b_off[B_SLOTS];
+#pragma unroll
+    for (int j = 0; j < B_SLOTS; ++j) {
+        const int f = tid + j * NT16;
+        b_off[j] = (!B_PART || f < B_CHUNKS)
+                       ? (unsigned)(((size_t)(tn * BN + f / 4) * p.Kpad16 + (f % 4) * 8 + (size_t)kt0 * BK16) * 2)
+                       : OOB;
+    }
+    int b_soff = 0;      // bytes the weight loads have advanced along K (wave-uniform -> the instruction's soffset)
+    int tiles_left = n;  // tiles not yet issued; past the end every load goes out of range
+
+    // ---- loader pieces: A slot j / B slot j of the tile the K walk points at, then the walk step ----
+    auto issue_a = [&](float4(&ga)[A_SLOTS], int j) {
+        __amdgpu_buffer_rsrc_t rs = r_s0;
+        int sc = p.src_c[0];
+        if (MULTISRC) {
+            if (u_src == 1) { rs = r_s1; sc = p.src_c[1]; }
+            else if (u_src == 2) { rs = r_s2; sc = p.src_c[2]; }
+            else if (u_src == 3) { rs = r_s3; sc = p.src_c[3]; }
+        }
+        const int tap_pix = u_kh * p.W + u_kw;
+        const unsigned bit = tiles_left > 0 ? 1u << u_tap : 0u;
+        unsigned off;
+        if (MULTISRC) off = (unsigned)((a_pix0[j] + tap_pix) * sc + (u_cs + k4 * 4)) * 4u;
+        else off = a_byte0[j] + (unsigned)(tap_pix * sc + u_cs) * 4u;
+        ga[j] = buf_ld4(rs, (a_vmask[j] & bit) ? off : OOB);
+    };
+    auto issue_b = [&](u32x4(&gbh)[B_SLOTS], u32x4(&gbl)[B_SLOTS], int j) {
+        const int so = tiles_left > 0 ? b_soff : 0;
+        const unsigned vo = tiles_left > 0 ? b_off[j] : OOB;
+        gbh[j] = __builtin_amdgcn_raw_buffer_load_b128(r_wh, (int)vo, so, 0);
+        gbl[j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)vo, so, 0);
+    };
+    auto advance_k = [&]() {
+        --tiles_left;
+        b_soff += BK16 * 2;
+        u_c0 += BK16;
+        u_cs += BK16;
+        if (u_c0 >= p.Cin) {
+            u_c0 = 0; u_cs = 0; u_src = 0;
+            ++u_tap;
+            if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
+        } else if (MULTISRC) {
+            const int cur = u_src == 0 ? p.src_c[0] : u_src == 1 ? p.src_c[1] : u_src == 2 ? p.src_c[2] : p.src_c[3];
+            if (u_cs >= cur) { u_cs = 0; ++u_src; }
+        }
+    };
+    auto issue_tile = [&](float4(&ga)[A_SLOTS], u32x4(&gbh)[B_SLOTS], u32x4(&gbl)[B_SLOTS]) {
+        // same order as phase 2 of the loop (the compiler's vmcnt bookkeeping merges both at the loop header)
+#pragma unroll
+        for (int j = 0; j < A_SLOTS; ++j) issue_a(ga, j);
+#pragma unroll
+        for (int j = 0; j < B_SLOTS; ++j) issue_b(gbh, gbl, j);
+        advance_k();
+    };
+
+    // ---- conversion / LDS store pieces ----
+    Split2 cs0[A_SLOTS], cs1[A_SLOTS];
+    // piece q of A slot j: 0 split (x, y), 1 split (z, w), 2 store the hi halves, 3 store the lo halves
+    auto store_a_piece = [&](int buf, const float4(&ga)[A_SLOTS], int j, int q) {
+        _Float16* Ah = lds + buf * BUF;
+        _Float16* Al = Ah + A_SZ;
+        const int row = (tid >> 3) + j * 32;
+        const int col = ((((k4 >> 1) ^ swz(row)) << 1) | (k4 & 1)) * 4;
+        if (q == 0) cs0[j] = split2(ga[j].x, ga[j].y);
+        else if (q == 1) cs1[j] = split2(ga[j].z, ga[j].w);
+        else if (q == 2) *reinterpret_cast<u32x2*>(Ah + row * LDH + col) = u32x2{cs0[j].hi, cs1[j].hi};
+        else *reinterpret_cast<u32x2*>(Al + row * LDH + col) = u32x2{cs0[j].lo, cs1[j].lo};
+    };
+    // piece q of B slot j: 0 hi array, 1 lo array
+    auto store_b_piece = [&](int buf, const u32x4(&gbh)[B_SLOTS], const u32x4(&gbl)[B_SLOTS], int j, int q) {
+        _Float16* Bh = lds + buf * BUF + 2 * A_SZ;
+        _Float16* Bl = Bh + B_SZ;
+        const int f = tid + j * NT16;
+        if (!B_PART || f < B_CHUNKS) {
+            const int nn = f / 4, c = f % 4;
+            if (q == 0) *reinterpret_cast<u32x4*>(Bh + nn * LDH + (c ^ swz(nn)) * 8) = gbh[j];
+            else *reinterpret_cast<u32x4*>(Bl + nn * LDH + (c ^ swz(nn)) * 8) = gbl[j];
+        }
+    };
+    auto store_all = [&](int buf, const float4(&ga)[A_SLOTS], const u32x4(&gbh)[B_SLOTS], const u32x4(&gbl)[B_SLOTS],
+                         int) {
+#pragma unroll
+        for (int j = 0; j < A_SLOTS; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) store_a_piece(buf, ga, j, q);
+#pragma unroll
+        for (int j = 0; j < B_SLOTS; ++j) {
+            store_b_piece(buf, gbh, gbl, j, 0);
+            store_b_piece(buf, gbh, gbl, j, 1);
+        }
+    };
+
+    acc_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < F::NACC; ++r) acc[i][j][r] = 0.f;
+
+    const int lrow = lane >> 5, lcol = lane & 31;
+    const int a_frag = (wm * (MT * 32) + lcol) * LDH;
+    const int b_frag = 2 * A_SZ + (wn * (NT * 32) + lcol) * LDH;
+    const int co0 = ((0 * 2 + lrow) ^ swz(lcol)) * 8, co1 = ((1 * 2 + lrow) ^ swz(lcol)) * 8;
+
+    // fragment read r of k-step ks: order al[*], bh[*], ah[*], bl[*] = the order the MFMA terms need them
+    auto read_frag = [&](int buf, int ks, int r, h8(&ah)[MT], h8(&al)[MT], h8(&bh)[NT], h8(&bl)[NT]) {
+        const _Float16* base = lds + buf * BUF;
+        const int co = ks ? co1 : co0;
+        if (r < MT) al[r] = *reinterpret_cast<const h8*>(base + a_frag + A_SZ + r * 32 * LDH + co);
+        else if (r < MT + NT) bh[r - MT] = *reinterpret_cast<const h8*>(base + b_frag + (r - MT) * 32 * LDH + co);
+        else if (r < 2 * MT + NT) ah[r - MT - NT] = *reinterpret_cast<const h8*>(base + a_frag + (r - MT - NT) * 32 * LDH + co);
+        else bl[r - 2 * MT - NT] = *reinterpret_cast<const h8*>(base + b_frag + B_SZ + (r - 2 * MT - NT) * 32 * LDH + co);
+    };
+    auto mfma_slot = [&](int s, const h8(&ah)[MT], const h8(&al)[MT], const h8(&bh)[NT], const h8(&bl)[NT]) {
+        const int term = s / (MT * NT), idx = s % (MT * NT), i = idx / NT, j = idx % NT;
+        if (CP_EXP & 8) return;
+        if (term == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        else if (term == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    };
+
+    float4 ga[A_SLOTS];
+    u32x4 gbh[B_SLOTS], gbl[B_SLOTS];
+    h8 f0ah[MT], f0al[MT], f0bh[NT], f0bl[NT], f1ah[MT], f1al[MT], f1bh[NT], f1bl[NT];
+
+    // one iteration: `cur` = t & 1; the register set holds tile t+1 (stored in phase 1, refilled with tile t+2 in phase 2)
+    auto iteration = [&](int cur) {
+        // ---------------- phase 1 ----------------
+        constexpr int P1 = NR + 4 * A_SLOTS + 2 * B_SLOTS;
+        // the last MFMAs of a phase carry no side work: the LDS queue is then drained when the wave reaches the barrier
+        // (phase 1) and the next tile's first fragments have landed when phase 1 starts (phase 2)
+        constexpr int NS = NM > 4 ? NM - 2 : NM;
+#pragma unroll
+        for (int s = 0; s < NM; ++s) {
+            mfma_slot(s, f0ah, f0al, f0bh, f0bl);
+#pragma unroll
+            for (int q = s * P1 / NS; q < (s + 1) * P1 / NS && s < NS; ++q) {
+                // the k-step-1 fragment reads and the A conversion / store pieces alternate, the B stores come last
+                constexpr int NI = 2 * NR;  // interleaved prefix: read, piece, read, piece, ...
+                if (q < NI && (q & 1) == 0) read_frag(cur, 1, q / 2, f1ah, f1al, f1bh, f1bl);
+                else if (!(CP_EXP & 2)) {
+                    const int z = q < NI ? q / 2 : q - NR;  // index into the store pieces
+                    if (z < 4 * A_SLOTS) {
+                        store_a_piece(cur ^ 1, ga, z / 4, z % 4);
+                        if ((CP_EXP & 64) && z % 4 == 3) issue_a(ga, z / 4);
+                    } else {
+                        const int zb = z - 4 * A_SLOTS;
+                        store_b_piece(cur ^ 1, gbh, gbl, zb / 2, zb % 2);
+                        if ((CP_EXP & 64) && zb % 2 == 1) issue_b(gbh, gbl, zb / 2);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (CP_EXP & 64) advance_k();
+        if (!(CP_EXP & 4)) __syncthreads();
+        // ---------------- phase 2 ----------------
+        constexpr int NL = A_SLOTS + B_SLOTS + 1;
+        constexpr int P2 = NR + NL;
+#pragma unroll
+        for (int s = 0; s < NM; ++s) {
+            mfma_slot(s, f1ah, f1al, f1bh, f1bl);
+#pragma unroll
+            for (int q = s * P2 / NS; q < (s + 1) * P2 / NS && s < NS; ++q) {
+                // loader pieces and the next tile's k-step-0 fragment reads alternate
+                constexpr int NI = 2 * (NL < NR ? NL : NR);
+                const bool is_load = q < NI ? (q & 1) == 0 : NL > NR;
+                const int l = q < NI ? q / 2 : q - NR;   // loader piece index when is_load
+                const int r = q < NI ? q / 2 : q - NL;   // read index otherwise
+                if (is_load) {
+                    if (CP_EXP & (1 | 64)) {
+                    } else if (l < A_SLOTS) issue_a(ga, l);
+                    else if (l < A_SLOTS + B_SLOTS) issue_b(gbh, gbl, l - A_SLOTS);
+                    else advance_k();
+                } else read_frag(cur ^ 1, 0, r, f0ah, f0al, f0bh, f0bl);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- prologue: tile 0 in buffer 0, tile 1 in the register set ----
+    issue_tile(ga, gbh, gbl);
+    store_all(0, ga, gbh, gbl, 2);
+    issue_tile(ga, gbh, gbl);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) read_frag(0, 0, r, f0ah, f0al, f0bh, f0bl);
+
+    for (int t = 0; t < n; ++t) iteration(t & 1);
+    if ((CP_EXP & 16) && acc[0][0][0] != 12345.f) return;
+    if (p.splitk > 1) igemm_store_partial<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane, blockIdx.y);
+    else igemm_epilogue<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane);
+}
+
 template <int MT, int NT, int WM, int WN, bool DCN, bool MULTISRC>
 int launch16(const ConvParams& p, hipStream_t stream) {
     constexpr bool PF2 = !DCN;
@@ -407,8 +700,16 @@ int launch16(const ConvParams& p, hipStream_t stream) {
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = p.CoutPad / BN;
     if (p.CoutPad % BN != 0 || p.Kpad16 % BK16 != 0) return CP_ERR_INVALID;
-    hipLaunchKernelGGL((igemm16_kernel<MT, NT, WM, WN, DCN, MULTISRC, PF2>),
-                       dim3(tiles_m * tiles_n, p.splitk > 1 ? p.splitk : 1), dim3(NT16), 0, stream, p, tiles_m, tiles_n);
+    const dim3 grid(tiles_m * tiles_n, p.splitk > 1 ? p.splitk : 1);
+    if constexpr (!DCN) {
+        if (!(p.dbg & 16)) {
+            hipLaunchKernelGGL((igemm16p_kernel<MT, NT, WM, WN, MULTISRC>), grid, dim3(NT16), 0, stream, p, tiles_m,
+                               tiles_n);
+            return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL((igemm16_kernel<MT, NT, WM, WN, DCN, MULTISRC, PF2>), grid, dim3(NT16), 0, stream, p, tiles_m,
+                       tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 

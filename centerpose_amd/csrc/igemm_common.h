@@ -41,6 +41,44 @@ __device__ __forceinline__ int tile_of_block(int tiles_m, int tiles_n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Output-pixel index m -> (image b, row ho, column wo).  For m < 2^24 the quotient by float reciprocal is off by at
+// most two (|error| <= q * 1.5 * 2^-23), so two correction steps make it exact: ~12 VALU per division instead of the
+// ~35 of a 32-bit integer division (four slots x two divisions per thread were a fifth of the prologue).  `big`
+// (wave-uniform: the tensor has >= 2^24 output pixels) selects the integer division.
+__device__ __forceinline__ int div_small(int m, int d, float rcp_d, int* rem, bool big) {
+    if (big) {
+        const int q = m / d;
+        *rem = m - q * d;
+        return q;
+    }
+    int q = (int)((float)m * rcp_d);
+    int r = m - q * d;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        if (r < 0) { --q; r += d; }
+        else if (r >= d) { ++q; r -= d; }
+    }
+    *rem = r;
+    return q;
+}
+
+// Bit t = kh*KW + kw of the result: tap (kh, kw) of an output pixel whose window starts at (h0, w0) reads inside the
+// image.  Row and column validity are separable, so the KH*KW-deep double loop becomes KH + KW steps.
+__device__ __forceinline__ unsigned tap_valid_mask(int h0, int w0, int H, int W, int KH, int KW) {
+    unsigned wbits = 0u;
+    for (int kw = 0; kw < KW; ++kw)
+        if ((unsigned)(w0 + kw) < (unsigned)W) wbits |= 1u << kw;
+    unsigned vm = 0u;
+    for (int kh = 0; kh < KH; ++kh)
+        if ((unsigned)(h0 + kh) < (unsigned)H) vm |= wbits << (kh * KW);
+    return vm;
+}
+
+// Raw buffer resource (SRD) over `bytes` bytes at p: loads beyond it return 0, stores beyond it are dropped.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
 // Epilogue of every implicit-GEMM tile: y = acc*scale[n] + shift[n] (+ residual) -> ReLU / sigmoid -> NHWC or NCHW
 // store (folded eval-mode BatchNorm, conv bias, BasicBlock residual: pose_dla_dcn.py:48-62, DeformConv.actf :380-389).
 template <int FRAG, int MT, int NT, int WM, int WN>
@@ -51,27 +89,54 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, typename Fra
     const int M = p.B * p.Ho * p.Wo;
     const int HWo = p.Ho * p.Wo;
     const int lcol = lane % FRAG;
+    // every mode decision below is wave-uniform and taken once per fragment, outside the per-element loops (as
+    // per-element branches the epilogue was ~2000 instructions per wave -- more than ten K-steps of the main loop)
+    const int act = p.act;
+    const bool has_res = p.res != nullptr, has_gn = p.gn_stats != nullptr, nhwc = p.store == CP_STORE_NHWC;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = tn * BN + wn * (NT * FRAG) + j * FRAG + lcol;
         const float sc = p.scale ? p.scale[n] : 1.f;
         const float sh = p.shift ? p.shift[n] : 0.f;
         const bool n_ok = n < p.Cout;
+        const bool sig_lane = act == CP_ACT_SIGMOID || (act == CP_ACT_SIGMOID_FROM && n >= p.act_from);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int mbase = tm * BM + wm * (MT * FRAG) + i * FRAG;
+            // wave-uniform by construction (wm comes from threadIdx / 64): tell the compiler, or every buffer access below
+            // is wrapped in a waterfall loop over a 'divergent' resource
+            const int mbase = __builtin_amdgcn_readfirstlane(tm * BM + wm * (MT * FRAG) + i * FRAG);
+            const bool full = mbase + FRAG <= M;  // every fragment but the ragged last ones
             float v[F::NACC];
 #pragma unroll
-            for (int r = 0; r < F::NACC; ++r) {
-                const int m = mbase + F::row(r, lane);
-                float y = acc[i][j][r] * sc + sh;
-                if (p.res && n_ok && m < M) y += p.res[(size_t)m * p.res_ld + n];
-                if (p.act == CP_ACT_RELU) y = fmaxf(y, 0.f);
-                else if (p.act == CP_ACT_SIGMOID || (p.act == CP_ACT_SIGMOID_FROM && n >= p.act_from))
-                    y = 1.f / (1.f + expf(-y));
-                v[r] = y;
+            for (int r = 0; r < F::NACC; ++r) v[r] = acc[i][j][r] * sc + sh;
+            if (has_res) {
+                if (full) {
+                    // residual rows via buffer loads relative to the fragment's first row: per-lane offset once, the
+                    // row step rides in the scalar offset
+                    const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res + (size_t)mbase * p.res_ld, (unsigned)(FRAG * p.res_ld) * 4u);
+                    const unsigned vr = n_ok ? (unsigned)(F::row(0, lane) * p.res_ld + n) * 4u : 0x80000000u;
+                    float rv[F::NACC];
+#pragma unroll
+                    for (int r = 0; r < F::NACC; ++r)
+                        rv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, (int)vr, F::row(r, 0) * p.res_ld * 4, 0));
+#pragma unroll
+                    for (int r = 0; r < F::NACC; ++r) v[r] += rv[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < F::NACC; ++r) {
+                        const int m = mbase + F::row(r, lane);
+                        if (n_ok && m < M) v[r] += p.res[(size_t)m * p.res_ld + n];
+                    }
+                }
             }
-            if (p.gn_stats) {
+            if (act == CP_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < F::NACC; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (act == CP_ACT_SIGMOID || act == CP_ACT_SIGMOID_FROM) {
+#pragma unroll
+                for (int r = 0; r < F::NACC; ++r) v[r] = sig_lane ? 1.f / (1.f + expf(-v[r])) : v[r];
+            }
+            if (has_gn) {
                 // GroupNorm statistics of this 32-row x 32-channel fragment: rows live in registers, the 8 channels
                 // of a group in 8 neighbouring lanes (and the other 16 rows in lane ^ 32)
                 float s1 = 0.f, s2 = 0.f;
@@ -91,8 +156,20 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, typename Fra
                     atomicAdd(st + 1, (double)s2);
                 }
             }
+            if (nhwc && full) {
+                // buffer stores relative to the fragment's first row: no 64-bit address arithmetic and no bounds
+                // compare per element
+                float* frag_out = p.out + (size_t)mbase * p.ldo + p.coff;
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(frag_out, (unsigned)(FRAG * p.ldo) * 4u);
+                // a masked lane stays out of range with or without the scalar offset added
+                const unsigned vo = n_ok ? (unsigned)(F::row(0, lane) * p.ldo + n) * 4u : 0x80000000u;
+#pragma unroll
+                for (int r = 0; r < F::NACC; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, (int)vo, F::row(r, 0) * p.ldo * 4, 0);
+                continue;
+            }
             if (!n_ok) continue;
-            if (p.store == CP_STORE_NHWC) {
+            if (nhwc) {
 #pragma unroll
                 for (int r = 0; r < F::NACC; ++r) {
                     const int m = mbase + F::row(r, lane);

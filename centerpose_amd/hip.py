@@ -11,7 +11,8 @@ from collections import OrderedDict
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcenterpose_hip.so")
+# $CENTERPOSE_HIP_LIB selects another build of the same ABI (tuning variants: make -C csrc EXP=n)
+LIB_PATH = os.environ.get("CENTERPOSE_HIP_LIB") or os.path.join(_HERE, "libcenterpose_hip.so")
 
 _lib = None
 
