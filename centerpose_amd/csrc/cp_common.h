@@ -72,6 +72,15 @@ struct ConvParams {
     // applies the usual epilogue.
     int splitk;
     float* partial;
+    // Fused prediction head (dlav1 heads: conv3x3 -> ReLU -> conv1x1, pose_dla_dcn.py head Sequential): the 3x3 tile
+    // is multiplied by the 1x1 weights inside the kernel and only [slices = CoutPad/128][fuse_c2][M] partial sums of the
+    // final maps are written (fuse_out); cp_launch_head_reduce adds the slices + bias (+ sigmoid) into NCHW.  The
+    // 256-channel hidden tensor never exists in memory.  fuse_w2_*: 1x1 weights packed as MFMA fragments
+    // (cp_launch_pack_head_w2).
+    const void* fuse_w2_hi;
+    const void* fuse_w2_lo;
+    float* fuse_out;
+    int fuse_c2;
     int dbg;  // tuning ablations (tools/conv_bench.py --dbg): 1 skip A loads, 2 skip B loads, 4 skip LDS stores, 8 skip MFMA
     const float* offmask;  // DCN mode: NHWC [B,H,W,32] = 18 offsets (dh,dw interleaved per tap) + 9 masks (already sigmoided) + 5 pad
 };
@@ -84,13 +93,21 @@ int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream);
 // K steps (of 16 for the f32 kernels, 32 for f16x3) and output tiles of the launch cp_launch_conv[16] would make
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 22
+#define CP_NUM_CONV_VARIANTS 23
 // split-f16 ("f16x3") implicit GEMM (igemm16.hip)
 bool cp_conv16_supported(const ConvParams& p);
 int cp_launch_conv16(const ConvParams& p, hipStream_t stream);
 int cp_conv16_variant(const ConvParams& p);
 int cp_launch_pack_weight16(const float* w, void* hi, void* lo, int Cout, int Cin, int taps, int Kpad16, int coff,
                             hipStream_t s);
+// fused head (see ConvParams::fuse_*): is this 3x3 (+ReLU) -> 1x1 pair eligible; launch; 1x1 weight packing
+// (w1: [C2][Chid] float32 -> two arrays of Chid*32 binary16); slice reduction + bias (+ sigmoid) -> NCHW
+bool cp_head_fuse_supported(const ConvParams& p, int c2);
+int cp_launch_conv16_fused_head(const ConvParams& p, hipStream_t stream);
+int cp_launch_pack_head_w2(const float* w1, void* hi, void* lo, int C2, int Chid, hipStream_t s);
+int cp_launch_head_reduce(const float* slabs, const float* bias, float* out_nchw, int slices, int C2, int B, int HW,
+                          int sigmoid, hipStream_t s);
+#define CP_VARIANT_FUSED_HEAD 22
 #define CP_PREC_F32 0
 #define CP_PREC_F16X3 1
 

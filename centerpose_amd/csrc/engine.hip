@@ -114,6 +114,7 @@ struct ConvW {
 };
 
 int g_default_precision = CP_PREC_F32;
+int g_dbg = 0;  // cp_set_debug: 16 previous (non-pipelined) f16x3 kernel, 32 no head fusion
 
 struct DeformW {
     ConvW offset;  // conv_offset_mask (27 -> 32 padded), shift = bias
@@ -124,6 +125,8 @@ struct HeadW {
     std::string name;
     int classes = 0;
     ConvW c0, c1;
+    void* w2_hi = nullptr;  // fused-head form of c1 (cp_launch_pack_head_w2); null when the pair is not eligible
+    void* w2_lo = nullptr;
     float* gn_gamma = nullptr;
     float* gn_beta = nullptr;
 };
@@ -359,6 +362,19 @@ struct Packer {
             if (const auto* b = get(h.first + ".0.bias", hc)) set_affine(hw.c0, nullptr, *b);
             hw.c1 = pack({last + ".weight"}, h.second, hc, 1, 1);
             if (const auto* b = get(last + ".bias", h.second)) set_affine(hw.c1, nullptr, *b);
+            if (!m->gru && hc % 128 == 0 && h.second <= 32 && hw.c0.w16_hi) {
+                // conv3x3 -> ReLU -> conv1x1 head: keep the 1x1 weights as MFMA fragments for the fused kernel too
+                if (const auto* w1 = get(last + ".weight", (size_t)h.second * hc)) {
+                    float* tmp = upload(*w1);
+                    hw.w2_hi = dev_alloc((size_t)hc * 32 / 2);
+                    hw.w2_lo = dev_alloc((size_t)hc * 32 / 2);
+                    if (tmp && hw.w2_hi && hw.w2_lo) {
+                        const int rc = cp_launch_pack_head_w2(tmp, hw.w2_hi, hw.w2_lo, h.second, hc, nullptr);
+                        hipDeviceSynchronize();
+                        if (rc != CP_OK) status = rc;
+                    }
+                }
+            }
             if (m->gru) {
                 const auto* g = get(h.first + ".1.weight", hc);
                 const auto* be = get(h.first + ".1.bias", hc);
@@ -406,6 +422,79 @@ struct Fwd {
     }
     void tap(const std::string& name, const Tensor& t, int c_valid = 0) { tap(name.c_str(), t, c_valid); }
 
+    // conv3x3 (+bias, ReLU) -> conv1x1 (+bias, optional sigmoid) of a prediction head in one kernel + a slice reduction;
+    // returns false (nothing launched) when the launch would want split-K or the shapes are not eligible
+    bool fused_head(const HeadW& hw, const Tensor& x, bool sigmoid, float* out_nchw) {
+        const ConvW& w = hw.c0;
+        ConvParams p;
+        std::memset(&p, 0, sizeof(p));
+        p.nsrc = 1;
+        p.src[0] = x.ptr();
+        p.src_c[0] = x.C;
+        if (x.C != w.CinP) return false;
+        p.Cin = x.C;
+        p.B = B;
+        p.H = x.H;
+        p.W = x.W;
+        p.Ho = x.H + 2 - w.KH + 1;
+        p.Wo = x.W + 2 - w.KW + 1;
+        p.KH = w.KH;
+        p.KW = w.KW;
+        p.stride = 1;
+        p.pad = 1;
+        p.K = w.K;
+        p.Kpad = w.Kpad;
+        p.wp = w.wp;
+        p.Cout = w.Cout;
+        p.CoutPad = w.CoutPad;
+        p.scale = w.scale;
+        p.shift = w.shift;
+        p.act = CP_ACT_RELU;
+        p.w16_hi = w.w16_hi;
+        p.w16_lo = w.w16_lo;
+        p.Kpad16 = w.Kpad16;
+        p.splitk = 1;
+        p.dbg = g_dbg;
+        p.fuse_w2_hi = hw.w2_hi;
+        p.fuse_w2_lo = hw.w2_lo;
+        p.fuse_c2 = hw.classes;
+        if (w.KH != 3 || w.KW != 3 || !cp_head_fuse_supported(p, hw.classes)) return false;
+        int tiles = 0, nk = 0;
+        cp_conv_geometry(p, true, &tiles, &nk);
+        if (tiles < 128 && nk >= 8) return false;  // small launches keep the split-K path (conv())
+        const int slices = p.CoutPad / 128;
+        Tensor slabs = make(slices * hw.classes, p.Ho, p.Wo);
+        p.fuse_out = slabs.ptr();
+        auto launch = [&]() -> int {
+            int rc = cp_launch_conv16_fused_head(p, s);
+            if (rc == CP_OK)
+                rc = cp_launch_head_reduce(slabs.ptr(), hw.c1.shift, out_nchw, slices, hw.classes, B, p.Ho * p.Wo,
+                                           sigmoid ? 1 : 0, s);
+            return rc;
+        };
+        if (m->dry) return true;
+        if (m->profile) {
+            cp_model::ProfRec r;
+            r.variant = CP_VARIANT_FUSED_HEAD;
+            const double M = (double)B * p.Ho * p.Wo;
+            r.flops = 2.0 * M * w.Cout * (double)(w.KH * w.KW * w.Cin) + 2.0 * M * hw.classes * (double)w.Cout;
+            // algorithmic bytes: input once + final maps once + both weight sets (the hidden tensor is not counted:
+            // it is not part of the head's definition, only of the unfused implementation)
+            r.bytes = 4.0 * ((double)B * x.H * x.W * w.Cin + M * hw.classes + (double)w.KH * w.KW * w.Cin * w.Cout +
+                             (double)w.Cout * hw.classes);
+            r.M = (int)M; r.N = w.Cout; r.K = w.KH * w.KW * w.Cin; r.kh = w.KH; r.stride = 1;
+            r.e0 = m->get_event();
+            r.e1 = m->get_event();
+            (void)hipEventRecord(r.e0, s);
+            chk(launch());
+            (void)hipEventRecord(r.e1, s);
+            m->prof.push_back(r);
+        } else {
+            chk(launch());
+        }
+        return true;
+    }
+
     // generic conv into a fresh NHWC tensor (or into user NCHW memory when out_nchw != nullptr)
     Tensor conv(const ConvW& w, const std::vector<const Tensor*>& srcs, int stride, int pad, int act,
                 const Tensor* res = nullptr, const Tensor* offmask = nullptr, int act_from = 0,
@@ -446,6 +535,7 @@ struct Fwd {
         p.act = act;
         p.act_from = act_from;
         p.offmask = offmask ? offmask->ptr() : nullptr;
+        p.dbg = g_dbg;
         p.gn_stats = gn_stats_out;
         p.gn_groups = 32;
         p.gn_cpg = w.Cout / 32 > 0 ? w.Cout / 32 : 1;
@@ -726,6 +816,10 @@ struct Fwd {
                     }
                 }
             }
+            const bool sg = sigmoid_hm && (hw.name == "hm" || hw.name == "hm_hp");
+            if (!m->gru && hw.w2_hi && m->precision == CP_PREC_F16X3 && !m->tap_name && !(g_dbg & 32) &&
+                fused_head(hw, *src, sg, m->dry ? (float*)0x1000 : head_out[i]))
+                continue;
             Tensor hid = conv(hw.c0, {src}, 1, 1, m->gru ? CP_ACT_NONE : CP_ACT_RELU);
             if (m->gru) {
                 if (fuse_gn) {
@@ -742,7 +836,6 @@ struct Fwd {
                                                  hid.H * hid.W, hid.C, 32, 1e-5f, s));
                 }
             }
-            const bool sg = sigmoid_hm && (hw.name == "hm" || hw.name == "hm_hp");
             conv(hw.c1, {&hid}, 1, 0, sg ? CP_ACT_SIGMOID : CP_ACT_NONE, nullptr, nullptr, 0,
                  m->dry ? (float*)0x1000 : head_out[i], hw.classes);
         }
@@ -806,7 +899,6 @@ int cp_model_finalize(cp_model* m) {
     return CP_OK;
 }
 
-int g_dbg = 0;
 int cp_set_debug(int flags) {
     g_dbg = flags;
     return CP_OK;

@@ -373,7 +373,7 @@ int cp_conv_variant(const ConvParams& p) {
 }
 
 const char* cp_conv_variant_name(int v) {
-    static const char* names[22] = {
+    static const char* names[CP_NUM_CONV_VARIANTS] = {
         "igemm_f32_16x16x4_m256n16", "igemm_f32_32x32x2_m256n32", "igemm_f32_32x32x2_m128n64",
         "igemm_f32_32x32x2_m128n128", "dcn_igemm_f32_32x32x2_m128n64", "dcn_igemm_f32_32x32x2_m128n128",
         "igemm_cat_f32_16x16x4_m256n16", "igemm_cat_f32_32x32x2_m256n32", "igemm_cat_f32_32x32x2_m128n64",
@@ -381,8 +381,8 @@ const char* cp_conv_variant_name(int v) {
         "igemm_unaligned_f32_32x32x2_m128n64", "igemm_unaligned_f32_32x32x2_m128n128",
         "igemm16_f16x3_m128n32", "igemm16_f16x3_m128n64", "igemm16_f16x3_m128n128", "dcn_igemm16_f16x3_m128n64",
         "dcn_igemm16_f16x3_m128n128", "igemm16_cat_f16x3_m128n32", "igemm16_cat_f16x3_m128n64",
-        "igemm16_cat_f16x3_m128n128"};
-    return (v >= 0 && v < 22) ? names[v] : "?";
+        "igemm16_cat_f16x3_m128n128", "igemm16_head_f16x3_m128n128"};
+    return (v >= 0 && v < CP_NUM_CONV_VARIANTS) ? names[v] : "?";
 }
 
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk) {

@@ -421,8 +421,16 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
 #ifndef CP_EXP
 #define CP_EXP 0
 #endif
-template <int MT, int NT, int WM, int WN, bool MULTISRC>
+// FUSE (128x128 tiles only): fused prediction head.  The main MFMAs run with swapped operands, so a wave's accumulators
+// hold hidden^T -- rows = 32 hidden channels of a fragment spread over (register, lane half), columns = 32 pixels over
+// the lanes.  That is exactly the B-operand shape of a second MFMA whose k runs over hidden channels: 8 consecutive
+// registers of a lane are 8 k-values of its pixel.  After bias + ReLU the accumulators are split to binary16 hi/lo in
+// registers and multiplied by the 1x1 weights (A operand, pre-packed in the matching channel order) into a
+// [32 final channels][pixels] accumulator -- no LDS transpose, no hidden tensor in HBM.  The two waves of a pixel
+// range (hidden-channel halves) are summed through LDS, the N-tiles of the hidden dimension through fuse_out slices.
+template <int MT, int NT, int WM, int WN, bool MULTISRC, bool FUSE = false>
 __global__ __launch_bounds__(NT16, 2) void igemm16p_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
+    static_assert(!FUSE || (MT == 2 && NT == 2 && WM == 2 && WN == 2 && !MULTISRC), "fused head: 128x128 tiles");
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
@@ -615,6 +623,12 @@ __global__ __launch_bounds__(NT16, 2) void igemm16p_kernel(const ConvParams p, c
     auto mfma_slot = [&](int s, const h8(&ah)[MT], const h8(&al)[MT], const h8(&bh)[NT], const h8(&bl)[NT]) {
         const int term = s / (MT * NT), idx = s % (MT * NT), i = idx / NT, j = idx % NT;
         if (CP_EXP & 8) return;
+        if (FUSE) {  // transposed product: rows = output channels, columns = pixels
+            if (term == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+            else if (term == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+            return;
+        }
         if (term == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
         else if (term == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
@@ -689,6 +703,82 @@ __global__ __launch_bounds__(NT16, 2) void igemm16p_kernel(const ConvParams p, c
 
     for (int t = 0; t < n; ++t) iteration(t & 1);
     if ((CP_EXP & 16) && acc[0][0][0] != 12345.f) return;
+    if constexpr (FUSE) {
+        const int g = lane >> 5;
+        // 1x1 weight fragments of this wave's 64 hidden channels: [tn][wn][j][s][lane] x 8 halfs
+        const u32x4* w2h = reinterpret_cast<const u32x4*>(p.fuse_w2_hi) + (size_t)((tn * WN + wn) * 4) * 64 + lane;
+        const u32x4* w2l = reinterpret_cast<const u32x4*>(p.fuse_w2_lo) + (size_t)((tn * WN + wn) * 4) * 64 + lane;
+        h8 wh[2][2], wl[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const u32x4 a = w2h[(j * 2 + ks) * 64], b = w2l[(j * 2 + ks) * 64];
+                wh[j][ks] = *reinterpret_cast<const h8*>(&a);
+                wl[j][ks] = *reinterpret_cast<const h8*>(&b);
+            }
+        acc_t acc2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
+        const bool relu = p.act == CP_ACT_RELU;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float sc[16], sh[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = tn * BN + wn * 64 + j * 32 + F::row(r, lane);
+                sc[r] = p.scale ? p.scale[ch] : 1.f;
+                sh[r] = p.shift ? p.shift[ch] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    uint32_t hh[4], hl[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = ks * 8 + q * 2;
+                        float x0 = acc[i][j][r] * sc[r] + sh[r], x1 = acc[i][j][r + 1] * sc[r + 1] + sh[r + 1];
+                        if (relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+                        const Split2 sp = split2(x0, x1);
+                        hh[q] = sp.hi;
+                        hl[q] = sp.lo;
+                    }
+                    const u32x4 vh = {hh[0], hh[1], hh[2], hh[3]}, vl = {hl[0], hl[1], hl[2], hl[3]};
+                    const h8 bhh = *reinterpret_cast<const h8*>(&vh), bhl = *reinterpret_cast<const h8*>(&vl);
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j][ks], bhh, acc2[i], 0, 0, 0);
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j][ks], bhl, acc2[i], 0, 0, 0);
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j][ks], bhh, acc2[i], 0, 0, 0);
+                }
+            }
+        }
+        // sum the two hidden-channel halves (wn = 0 / 1) of each pixel range through LDS, in a fixed order
+        __syncthreads();  // every wave is done with the tile buffers
+        float* red = reinterpret_cast<float*>(lds);  // [wm][i][r][lane]
+        if (wn == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((wm * 2 + i) * 16 + r) * 64 + lane] = acc2[i][r];
+        }
+        __syncthreads();
+        if (wn == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = tm * BM + wm * 64 + i * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = F::row(r, lane);
+                    const float v = acc2[i][r] + red[((wm * 2 + i) * 16 + r) * 64 + lane];
+                    if (c < p.fuse_c2 && m < M) p.fuse_out[((size_t)tn * p.fuse_c2 + c) * M + m] = v;
+                }
+            }
+        }
+        (void)g;
+        return;
+    }
     if (p.splitk > 1) igemm_store_partial<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane, blockIdx.y);
     else igemm_epilogue<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane);
 }
@@ -711,6 +801,40 @@ int launch16(const ConvParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((igemm16_kernel<MT, NT, WM, WN, DCN, MULTISRC, PF2>), grid, dim3(NT16), 0, stream, p, tiles_m,
                        tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}
+
+// 1x1 head weights [C2][Chid] -> MFMA A-operand fragments in the channel order the fused epilogue's accumulators have:
+// fragment (tn, wn, j, ks), lane (c = lane % 32, g = lane / 32), element e holds hidden channel
+// tn*128 + wn*64 + j*32 + (e & 3) + 8 * (2*ks + (e >> 2)) + 4*g of final channel c (zero for c >= C2).
+__global__ void pack_head_w2_kernel(const float* __restrict__ w1, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                    int C2, int Chid) {
+    const int total = Chid * 32;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 7, lane = (idx >> 3) & 63, frag = idx >> 9;
+        const int ks = frag & 1, j = (frag >> 1) & 1, wave = frag >> 2;  // wave = tn * 2 + wn
+        const int c = lane & 31, g = lane >> 5;
+        const int ch = wave * 64 + j * 32 + (e & 3) + 8 * (2 * ks + (e >> 2)) + 4 * g;
+        const float x = c < C2 ? w1[(size_t)c * Chid + ch] : 0.f;
+        const Split2 sp = split2(x, 0.f);
+        reinterpret_cast<uint16_t*>(hi)[idx] = (uint16_t)(sp.hi & 0xffffu);
+        reinterpret_cast<uint16_t*>(lo)[idx] = (uint16_t)(sp.lo & 0xffffu);
+    }
+}
+
+// out[b][c][pix] = act(bias[c] + sum over slices (in index order) of slabs[slice][c][b*HW + pix])
+__global__ void head_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias,
+                                   float* __restrict__ out, int slices, int C2, int B, int HW, int sigmoid) {
+    const size_t M = (size_t)B * HW, total = M * C2;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i / M);
+        const size_t m = i - (size_t)c * M;
+        float acc = 0.f;
+        for (int z = 0; z < slices; ++z) acc += slabs[((size_t)z * C2 + c) * M + m];
+        float y = acc + (bias ? bias[c] : 0.f);
+        if (sigmoid) y = 1.f / (1.f + expf(-y));
+        const size_t b = m / HW, pix = m - b * HW;
+        out[(b * C2 + c) * HW + pix] = y;
+    }
 }
 
 // pack PyTorch [Cout][Cin][taps] float32 weights into split binary16 [CoutPad][Kpad16] (k = tap*Cin + ci)
@@ -774,5 +898,38 @@ int cp_launch_pack_weight16(const float* w, void* hi, void* lo, int Cout, int Ci
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(pack_weight16_kernel, dim3(g), dim3(256), 0, s, w, (_Float16*)hi, (_Float16*)lo, Cout, Cin, taps,
                        Kpad16, coff);
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}
+
+bool cp_head_fuse_supported(const ConvParams& p, int c2) {
+    return cp_conv16_supported(p) && !p.offmask && p.nsrc == 1 && p.CoutPad % 128 == 0 && p.Cout == p.CoutPad &&
+           c2 >= 1 && c2 <= 32 && !p.res && !p.gn_stats && !p.gn_in_mr &&
+           (p.act == CP_ACT_RELU || p.act == CP_ACT_NONE);
+}
+
+int cp_launch_conv16_fused_head(const ConvParams& p, hipStream_t stream) {
+    if (!cp_head_fuse_supported(p, p.fuse_c2) || !p.fuse_w2_hi || !p.fuse_w2_lo || !p.fuse_out || p.splitk > 1)
+        return CP_ERR_INVALID;
+    const int M = p.B * p.Ho * p.Wo;
+    const int tiles_m = (M + 127) / 128, tiles_n = p.CoutPad / 128;
+    hipLaunchKernelGGL((igemm16p_kernel<2, 2, 2, 2, false, true>), dim3(tiles_m * tiles_n), dim3(NT16), 0, stream, p,
+                       tiles_m, tiles_n);
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}
+
+int cp_launch_pack_head_w2(const float* w1, void* hi, void* lo, int C2, int Chid, hipStream_t s) {
+    if (Chid % 128 != 0 || C2 < 1 || C2 > 32) return CP_ERR_INVALID;
+    hipLaunchKernelGGL(pack_head_w2_kernel, dim3((Chid * 32 + 255) / 256), dim3(256), 0, s, w1, (_Float16*)hi,
+                       (_Float16*)lo, C2, Chid);
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}
+
+int cp_launch_head_reduce(const float* slabs, const float* bias, float* out_nchw, int slices, int C2, int B, int HW,
+                          int sigmoid, hipStream_t s) {
+    const size_t n = (size_t)B * HW * C2;
+    size_t g = (n + 255) / 256;
+    if (g > 65536) g = 65536;
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, slabs, bias, out_nchw, slices, C2, B, HW,
+                       sigmoid);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }

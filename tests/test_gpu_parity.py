@@ -172,6 +172,30 @@ def test_backbone_512_vs_oracle_and_batch_invariance(device, arch, prec):
         assert torch.equal(z3[k], z[k]), k   # same shape twice: deterministic, bit-exact
 
 
+def test_fused_head_matches_unfused_path(device):
+    """dla_34 heads (conv3x3 -> ReLU -> conv1x1, no GroupNorm) run as one fused kernel in f16x3 mode; the two-kernel
+    path (debug flag 32) must give the same maps to float32 round-off, and the fused path must be deterministic."""
+    heads = synth.HEADS_POSE
+    sd = synth.make_state_dict("dla_34", heads)
+    x = synth.frames(2, seed=29, h=256, w=256).to(device)
+    model = hip.HipModel("dla_34", heads, sd, precision="f16x3")
+    model.profile(True)
+    model(x, sigmoid_hm=True)
+    assert "igemm16_head_f16x3_m128n128" in model.profile_read()   # the fused kernel is what runs
+    model.profile(False)
+    z = {k: v.clone() for k, v in model(x, sigmoid_hm=True).items()}
+    z2 = model(x, sigmoid_hm=True)
+    hip.lib().cp_set_debug(32)
+    try:
+        zu = {k: v.clone() for k, v in model(x, sigmoid_hm=True).items()}
+    finally:
+        hip.lib().cp_set_debug(0)
+    for k in heads:
+        assert torch.equal(z[k], z2[k]), k
+        assert z[k].shape == zu[k].shape
+        assert float((z[k] - zu[k]).abs().max()) < 2e-5 * max(1.0, float(zu[k].abs().max())), k
+
+
 def test_model_missing_parameter_fails_loudly(device):
     sd = synth.make_state_dict("dla_34")
     del sd["base.level3.tree1.root.conv.weight"]
