@@ -155,7 +155,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     side = torch.cuda.Stream(device=device)  # a non-default stream (hipGraph capture needs one)
@@ -250,6 +250,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
+        barrier()  # rank 0 may still be measuring the batch-1 latency; leave together
         dist.destroy_process_group()
 
 

@@ -93,7 +93,7 @@ int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream);
 // K steps (of 16 for the f32 kernels, 32 for f16x3) and output tiles of the launch cp_launch_conv[16] would make
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 23
+#define CP_NUM_CONV_VARIANTS 26
 // split-f16 ("f16x3") implicit GEMM (igemm16.hip)
 bool cp_conv16_supported(const ConvParams& p);
 int cp_launch_conv16(const ConvParams& p, hipStream_t stream);
@@ -108,6 +108,13 @@ int cp_launch_pack_head_w2(const float* w1, void* hi, void* lo, int C2, int Chid
 int cp_launch_head_reduce(const float* slabs, const float* bias, float* out_nchw, int slices, int C2, int B, int HW,
                           int sigmoid, hipStream_t s);
 #define CP_VARIANT_FUSED_HEAD 22
+// direct low-channel convolutions of the network's first three layers in f16x3 mode (lowc.hip).
+// kind: 0 stem 7x7 (NCHW input, `planes` <= 4) -> 16; 1 level0 3x3 16->16; 2 level1 3x3 stride 2 16->32
+size_t cp_lowc_weight_halfs(int kind);
+int cp_launch_pack_lowc(int kind, const float* w, void* hi, void* lo, int cin, hipStream_t s);
+int cp_launch_lowc(int kind, const float* in, float* out, const void* w_hi, const void* w_lo, const float* scale,
+                   const float* shift, int B, int H, int W, int planes, hipStream_t s);
+#define CP_VARIANT_LOWC0 23
 #define CP_PREC_F32 0
 #define CP_PREC_F16X3 1
 

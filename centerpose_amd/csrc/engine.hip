@@ -114,7 +114,7 @@ struct ConvW {
 };
 
 int g_default_precision = CP_PREC_F32;
-int g_dbg = 0;  // cp_set_debug: 16 previous (non-pipelined) f16x3 kernel, 32 no head fusion
+int g_dbg = 0;  // cp_set_debug: 16 previous (non-pipelined) f16x3 kernel, 32 no head fusion, 64 no lowc kernels
 
 struct DeformW {
     ConvW offset;  // conv_offset_mask (27 -> 32 padded), shift = bias
@@ -144,6 +144,7 @@ struct cp_model {
     std::map<std::string, DeformW> deforms;
     std::map<std::string, float*> ups;
     std::vector<HeadW> headw;
+    std::map<std::string, std::pair<void*, void*>> lowc;  // hi / lo weight fragments of the lowc.hip layers
     ConvW gru_x, gru_h;
     std::vector<void*> device_allocs;
     Arena arena;
@@ -324,8 +325,29 @@ struct Packer {
             if (const auto* w = get(p + ".up_" + k + ".weight", (size_t)o * 4 * f * f)) m->ups[p + ".up_" + k] = upload(*w);
         }
     }
+    // weight fragments for the direct low-channel kernels (f16x3 mode); the folded BatchNorm comes from the ConvW
+    void lowc(const std::string& name, const std::string& wname, int kind, int cout, int cin, int k) {
+        const auto* w = get(wname + ".weight", (size_t)cout * cin * k * k);
+        if (!w) return;
+        float* tmp = upload(*w);
+        const size_t halfs = cp_lowc_weight_halfs(kind);
+        void* hi = dev_alloc(halfs / 2);
+        void* lo = dev_alloc(halfs / 2);
+        if (!tmp || !hi || !lo) return;
+        const int rc = cp_launch_pack_lowc(kind, tmp, hi, lo, cin, nullptr);
+        hipDeviceSynchronize();
+        if (rc != CP_OK) status = rc;
+        m->lowc[name] = {hi, lo};
+    }
     void run() {
         conv_bn("base.base_layer", "base.base_layer.0", "base.base_layer.1", 16, 3, 7, 4);
+        lowc("base.base_layer", "base.base_layer.0", 0, 16, 3, 7);
+        lowc("base.level0", "base.level0.0", 1, 16, 16, 3);
+        lowc("base.level1", "base.level1.0", 2, 32, 16, 3);
+        if (m->tracking) {
+            lowc("base.pre_img_layer", "base.pre_img_layer.0", 0, 16, 3, 7);
+            lowc("base.pre_hm_layer", "base.pre_hm_layer.0", 0, 16, 1, 7);
+        }
         if (m->tracking) {
             conv_bn("base.pre_img_layer", "base.pre_img_layer.0", "base.pre_img_layer.1", 16, 3, 7, 4);
             conv_bn("base.pre_hm_layer", "base.pre_hm_layer.0", "base.pre_hm_layer.1", 16, 1, 7, 4);
@@ -691,6 +713,38 @@ struct Fwd {
         }
     }
 
+    // the network's first layers through lowc.hip (f16x3 mode only); returns an invalid Tensor when not applicable
+    Tensor lowc(const std::string& name, int kind, const float* in, int H, int W, int planes) {
+        auto it = m->lowc.find(name);
+        if (m->precision != CP_PREC_F16X3 || it == m->lowc.end() || (g_dbg & 64)) return Tensor();
+        const ConvW& w = cw(name);
+        const int Ho = kind == 2 ? (H - 1) / 2 + 1 : H, Wo = kind == 2 ? (W - 1) / 2 + 1 : W;
+        const int cout = kind == 2 ? 32 : 16, cin = kind == 0 ? planes : 16, k = kind == 0 ? 7 : 3;
+        Tensor out = make(cout, Ho, Wo);
+        if (m->dry) return out;
+        auto launch = [&]() {
+            return cp_launch_lowc(kind, in, out.ptr(), it->second.first, it->second.second, w.scale, w.shift, B, H, W,
+                                  planes, s);
+        };
+        if (m->profile) {
+            cp_model::ProfRec r;
+            r.variant = CP_VARIANT_LOWC0 + kind;
+            const double M = (double)B * Ho * Wo;
+            r.flops = 2.0 * M * cout * (double)(k * k * cin);
+            r.bytes = 4.0 * ((double)B * H * W * cin + M * cout + (double)k * k * cin * cout);
+            r.M = (int)M; r.N = cout; r.K = k * k * cin; r.kh = k; r.stride = kind == 2 ? 2 : 1;
+            r.e0 = m->get_event();
+            r.e1 = m->get_event();
+            (void)hipEventRecord(r.e0, s);
+            chk(launch());
+            (void)hipEventRecord(r.e1, s);
+            m->prof.push_back(r);
+        } else {
+            chk(launch());
+        }
+        return out;
+    }
+
     Tensor to_nhwc(const float* nchw, int C, int Cpad, int H, int W) {
         Tensor t = make(Cpad, H, W);
         if (!m->dry) chk(cp_launch_nchw_to_nhwc(nchw, t.ptr(), B, C, H, W, Cpad, s));
@@ -699,20 +753,26 @@ struct Fwd {
 
     void run(int H, int W, const float* images, const float* pre_img, const float* pre_hm, const float* pre_hm_hp,
              float* const* head_out, int sigmoid_hm) {
-        Tensor x0;
-        {
+        Tensor x0 = lowc("base.base_layer", 0, images, H, W, 3);
+        if (!x0.valid()) {
             Tensor in = to_nhwc(images, 3, 4, H, W);
             x0 = conv(cw("base.base_layer"), {&in}, 1, 3, CP_ACT_RELU);
         }
         if (m->tracking && (pre_img || pre_hm || pre_hm_hp)) {
             Tensor a, b, c;
             if (pre_img) {
-                Tensor in = to_nhwc(pre_img, 3, 4, H, W);
-                a = conv(cw("base.pre_img_layer"), {&in}, 1, 3, CP_ACT_RELU);
+                a = lowc("base.pre_img_layer", 0, pre_img, H, W, 3);
+                if (!a.valid()) {
+                    Tensor in = to_nhwc(pre_img, 3, 4, H, W);
+                    a = conv(cw("base.pre_img_layer"), {&in}, 1, 3, CP_ACT_RELU);
+                }
             }
             if (pre_hm) {
-                Tensor in = to_nhwc(pre_hm, 1, 4, H, W);
-                b = conv(cw("base.pre_hm_layer"), {&in}, 1, 3, CP_ACT_RELU);
+                b = lowc("base.pre_hm_layer", 0, pre_hm, H, W, 1);
+                if (!b.valid()) {
+                    Tensor in = to_nhwc(pre_hm, 1, 4, H, W);
+                    b = conv(cw("base.pre_hm_layer"), {&in}, 1, 3, CP_ACT_RELU);
+                }
             }
             if (pre_hm_hp) {
                 Tensor in = to_nhwc(pre_hm_hp, 8, 8, H, W);
@@ -730,10 +790,12 @@ struct Fwd {
             x0 = sum;
         }
         tap("base.base_layer", x0);
-        Tensor l0 = conv(cw("base.level0"), {&x0}, 1, 1, CP_ACT_RELU);
+        Tensor l0 = lowc("base.level0", 1, x0.ptr(), H, W, 16);
+        if (!l0.valid()) l0 = conv(cw("base.level0"), {&x0}, 1, 1, CP_ACT_RELU);
         tap("base.level0", l0);
         x0 = Tensor();
-        Tensor l1 = conv(cw("base.level1"), {&l0}, 2, 1, CP_ACT_RELU);
+        Tensor l1 = lowc("base.level1", 2, l0.ptr(), H, W, 16);
+        if (!l1.valid()) l1 = conv(cw("base.level1"), {&l0}, 2, 1, CP_ACT_RELU);
         tap("base.level1", l1);
         l0 = Tensor();
         std::vector<Tensor> L(6);

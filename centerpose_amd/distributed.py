@@ -28,7 +28,14 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl":
+            # bind the communicator to this rank's GPU up front (no lazy device guess at the first barrier)
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        try:
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        except TypeError:  # older torch: no device_id argument
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world
 
 
