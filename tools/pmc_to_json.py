@@ -19,6 +19,15 @@ def variant(kname):
         dcn, cat = m16.group(5) == "true", m16.group(6) == "true"
         pre = "dcn_igemm16" if dcn else "igemm16_cat" if cat else "igemm16"
         return "%s_f16x3_m%dn%d" % (pre, 32 * mt * wm, 32 * nt * wn)
+    mp = re.search(r"igemm16p_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", kname)
+    if mp:
+        mt, nt, wm, wn = (int(mp.group(i)) for i in range(1, 5))
+        pre = "igemm16_head" if mp.group(6) == "true" else "igemm16_cat" if mp.group(5) == "true" else "igemm16"
+        return "%s_f16x3_m%dn%d" % (pre, 32 * mt * wm, 32 * nt * wn)
+    ml = re.search(r"lowc_kernel<(\d+), (\d+), (\d+), ", kname)
+    if ml:
+        return {("4", "1"): "lowc_stem7x7_f16x3", ("16", "1"): "lowc_3x3_c16_f16x3",
+                ("16", "2"): "lowc_3x3s2_c16_f16x3"}.get((ml.group(1), ml.group(3)), "lowc")
     m = re.search(r"igemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (true|false)>", kname)
     if not m:
         return re.sub(r"\(.*", "", kname.replace("(anonymous namespace)::", "").replace("void ", "")).strip()
