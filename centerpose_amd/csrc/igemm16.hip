@@ -10,12 +10,14 @@
 // Same GEMM view, tile map, K-walk and epilogue as igemm.hip.  Differences that follow from the MFMA shape:
 //   * operand fragments are 8 consecutive k per lane (A[m = lane%32][k = 8*(lane/32) .. +7]), so both tiles live
 //     in LDS row-major with k contiguous ([m][k] / [n][k]); the NHWC float4 a lane loads IS 4 consecutive k of one
-//     pixel, so the A tile needs no transpose; rows are padded 64 -> 80 bytes which makes every ds_read_b128
-//     lane group hit 16 distinct 16-byte slots (conflict-free);
+//     pixel, so the A tile needs no transpose; rows are 64 bytes, unpadded, with the 16-byte chunks XOR-swizzled by
+//     the row (see swz()) so that ds_read_b128 / ds_write_b64 lane groups are bank-conflict free;
 //   * weights are split and packed once at model load as [co][tap][ci] binary16 pairs (hi / lo arrays);
 //   * BK = 32 (two 32x32x16 MFMA k-steps per LDS tile).
-// Requirements: every source's channel count % 32 == 0 (all DLA-34 layers except the 16-channel stem levels,
-// which stay on the exact-f32 kernel).
+// Kernels: igemm16p_kernel (hand-pipelined K loop; all non-DCN layers, optional fused prediction head) and
+// igemm16_kernel (previous loop structure; DCN gather layers).  Requirements: every source's channel count % 32 == 0;
+// the 16-channel layers at the top of the network run in lowc.hip, the <= 16-wide GroupNorm'd final 1x1 heads on the
+// exact-f32 kernel.
 #include "igemm_common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -429,16 +431,17 @@ __global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, co
 // [32 final channels][pixels] accumulator -- no LDS transpose, no hidden tensor in HBM.  The two waves of a pixel
 // range (hidden-channel halves) are summed through LDS, the N-tiles of the hidden dimension through fuse_out slices.
 template <int MT, int NT, int WM, int WN, bool MULTISRC, bool FUSE = false>
-__global__ __launch_bounds__(NT16, 2) void igemm16p_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     static_assert(!FUSE || (MT == 2 && NT == 2 && WM == 2 && WN == 2 && !MULTISRC), "fused head: 128x128 tiles");
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
-    static_assert(WM * WN * 64 == NT16, "4 waves");
-    constexpr int A_SLOTS = BM * BK16 / 4 / NT16;
+    constexpr int NTH = WM * WN * 64;  // 4 waves (256 threads), or 8 for the high-occupancy 128x128 variant
+    constexpr int RPP = NTH / 8;       // A-tile rows covered by one pass of the block (8 float4 per 32-wide row)
+    constexpr int A_SLOTS = BM * BK16 / 4 / NTH;
     constexpr int B_CHUNKS = BN * BK16 * 2 / 16;
-    constexpr int B_SLOTS = (B_CHUNKS + NT16 - 1) / NT16;
-    constexpr bool B_PART = B_CHUNKS % NT16 != 0;
+    constexpr int B_SLOTS = (B_CHUNKS + NTH - 1) / NTH;
+    constexpr bool B_PART = B_CHUNKS % NTH != 0;
     constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;
     constexpr int BUF = 2 * A_SZ + 2 * B_SZ;
     constexpr int NM = 3 * MT * NT;        // MFMAs per phase
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16p_kernel(const ConvParams p, c
     unsigned a_vmask[A_SLOTS], a_byte0[A_SLOTS];
 #pragma unroll
     for (int j = 0; j < A_SLOTS; ++j) {
-        const int m = tm * BM + (tid >> 3) + j * 32;
+        const int m = tm * BM + (tid >> 3) + j * RPP;
         const bool ok = m < M;
         const int mm = ok ? m : 0;
         int rem, wo;
@@ -508,7 +511,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16p_kernel(const ConvParams p, c
     unsigned b_off[B_SLOTS];
 #pragma unroll
     for (int j = 0; j < B_SLOTS; ++j) {
-        const int f = tid + j * NT16;
+        const int f = tid + j * NTH;
         b_off[j] = (!B_PART || f < B_CHUNKS)
                        ? (unsigned)(((size_t)(tn * BN + f / 4) * p.Kpad16 + (f % 4) * 8 + (size_t)kt0 * BK16) * 2)
                        : OOB;
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16p_kernel(const ConvParams p, c
     auto store_a_piece = [&](int buf, const float4(&ga)[A_SLOTS], int j, int q) {
         _Float16* Ah = lds + buf * BUF;
         _Float16* Al = Ah + A_SZ;
-        const int row = (tid >> 3) + j * 32;
+        const int row = (tid >> 3) + j * RPP;
         const int col = ((((k4 >> 1) ^ swz(row)) << 1) | (k4 & 1)) * 4;
         if (q == 0) cs0[j] = split2(ga[j].x, ga[j].y);
         else if (q == 1) cs1[j] = split2(ga[j].z, ga[j].w);
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(NT16, 2) void igemm16p_kernel(const ConvParams p, c
     auto store_b_piece = [&](int buf, const u32x4(&gbh)[B_SLOTS], const u32x4(&gbl)[B_SLOTS], int j, int q) {
         _Float16* Bh = lds + buf * BUF + 2 * A_SZ;
         _Float16* Bl = Bh + B_SZ;
-        const int f = tid + j * NT16;
+        const int f = tid + j * NTH;
         if (!B_PART || f < B_CHUNKS) {
             const int nn = f / 4, c = f % 4;
             if (q == 0) *reinterpret_cast<u32x4*>(Bh + nn * LDH + (c ^ swz(nn)) * 8) = gbh[j];
