@@ -172,6 +172,22 @@ def test_backbone_512_vs_oracle_and_batch_invariance(device, arch, prec):
         assert torch.equal(z3[k], z[k]), k   # same shape twice: deterministic, bit-exact
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_backbone_non_square_ragged_tiles_vs_oracle(device, prec):
+    """96 x 160 input: the last tiles of lowc.hip (64/32-pixel wide), of the implicit GEMMs (M % 128 != 0 at the
+    deeper levels) and the split-K path are all ragged here."""
+    heads = synth.HEADS_POSE
+    sd = synth.make_state_dict("dla_34", heads)
+    x = synth.frames(2, seed=31, h=96, w=160)
+    model = hip.HipModel("dla_34", heads, sd, precision=prec)
+    z = model(x.to(device), sigmoid_hm=True)
+    zo = ob.dlaseg_forward(sd, x, heads, arch="dla")
+    assert z["hm"].shape == (2, 1, 24, 40)
+    assert float((z["hm"].cpu() - torch.sigmoid(zo["hm"])).abs().max()) < 1e-3
+    for k in ("wh", "hps", "reg", "hp_offset", "scale"):
+        assert float((z[k].cpu() - zo[k]).abs().max()) < 1e-3 * max(1.0, float(zo[k].abs().max())), k
+
+
 def test_fused_head_matches_unfused_path(device):
     """dla_34 heads (conv3x3 -> ReLU -> conv1x1, no GroupNorm) run as one fused kernel in f16x3 mode; the two-kernel
     path (debug flag 32) must give the same maps to float32 round-off, and the fused path must be deterministic."""
