@@ -34,7 +34,8 @@ from centerpose_amd import hip, synth  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, dense f32 matrix
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense f16/bf16 matrix
-GFLOP_PER_IMG = {"dlav1_34": 106.85, "dla_34": 85.11, "dla_34_track": 109.68}
+GFLOP_PER_IMG = {"dlav1_34": 106.85, "dla_34": 85.11, "dla_34_track": 109.68,
+                 "dlav1_34_track": 138.7}  # BASELINE.md section 2, SURVEY 8(f) N4
 
 
 def parse():
@@ -42,9 +43,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="decode", choices=["decode", "full", "track"],
+    ap.add_argument("--workload", default="decode", choices=["decode", "full", "track", "track_gru"],
                     help="decode: configs[1] (default); full: configs[2] dla_34 + PnP; track: dla_34 two-frame "
-                         "CenterPoseTrack inputs + Gaussian-moment decode + RCCL all-gather of detection records")
+                         "CenterPoseTrack inputs + Gaussian-moment decode + RCCL all-gather of detection records; "
+                         "track_gru: the same on dlav1_34 (two-frame input + ConvGRU heads = BASELINE configs[4] as "
+                         "the reference can actually run it, SURVEY 8(f) N4 option ii)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 / 64)")
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
                     help="f32: exact float32 MFMA; f16x3: split-binary16 MFMA (float32-class accuracy)")
@@ -58,8 +61,8 @@ class Pipeline(object):
 
     def __init__(self, workload, batch, device, seed, precision="f32"):
         self.workload = workload
-        self.arch = "dlav1_34" if workload == "decode" else "dla_34"
-        self.track = workload == "track"
+        self.arch = "dlav1_34" if workload in ("decode", "track_gru") else "dla_34"
+        self.track = workload in ("track", "track_gru")
         self.heads = synth.HEADS_TRACK if self.track else synth.HEADS_POSE
         self.batch = batch
         self.device = device
@@ -112,7 +115,7 @@ class Pipeline(object):
 
 def cpu_baseline(workload, arch, budget_s=12.0, max_imgs=16):
     """Oracle (CPU port of the reference graph) on a bounded sample of the same workload."""
-    if workload == "track":
+    if workload in ("track", "track_gru"):
         return None
     from oracle import backbone as ob
     from oracle import decode as odec
@@ -150,7 +153,7 @@ def main():
         import torch.distributed as dist
 
         cpd.init_from_env("nccl")
-    batch = args.batch or {"decode": 32, "full": 64, "track": 16}[args.workload]
+    batch = args.batch or {"decode": 32, "full": 64, "track": 16, "track_gru": 16}[args.workload]
     pipe = Pipeline(args.workload, batch, device, seed=317 + 1000 * rank, precision=args.precision)
 
     def barrier():

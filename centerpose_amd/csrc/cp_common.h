@@ -168,3 +168,7 @@ int cp_launch_pnp(hipStream_t s, const float* pts, const float* scale, const dou
 
 int cp_launch_preprocess(const unsigned char* img, int H, int W, const float* minv6, const float* mean3,
                          const float* std3, float* out, int OH, int OW, hipStream_t s);
+
+// device post-process + soft-NMS (post.hip); record layout CP_POST_* in include/centerpose_hip.h
+int cp_launch_postprocess(const float* det, int B, int K, const double* meta, float vis_thresh, int nms,
+                          float div_scale, double* out, int* count, double* ws, hipStream_t s);

@@ -1193,6 +1193,20 @@ int cp_preprocess(cp_stream_t stream, const unsigned char* image_hwc_bgr, int H,
                                 (hipStream_t)stream);
 }
 
+size_t cp_postprocess_workspace_bytes(int B, int K) {
+    return B > 0 && K > 0 ? (size_t)B * K * CP_POST_STRIDE * sizeof(double) : 0;
+}
+
+int cp_postprocess(cp_stream_t stream, const float* det, int B, int K, const double* meta, float vis_thresh, int nms,
+                   float div_scale, double* out, int* count, void* workspace, size_t workspace_bytes) {
+    if (!det || !meta || !out || !count || !workspace || B < 1) return fail(CP_ERR_INVALID, "bad argument");
+    if (K < 1 || K > 128) return fail(CP_ERR_INVALID, "K must be in [1, 128]");
+    if (workspace_bytes < cp_postprocess_workspace_bytes(B, K)) return fail(CP_ERR_INVALID, "workspace too small");
+    if (!(div_scale > 0.f)) return fail(CP_ERR_INVALID, "div_scale must be positive");
+    return cp_launch_postprocess(det, B, K, meta, vis_thresh, nms, div_scale, out, count, (double*)workspace,
+                                 (hipStream_t)stream);
+}
+
 size_t cp_pnp_workspace_bytes(int N) { return cp_pnp_ws_bytes(N); }
 
 int cp_pnp_solve(cp_stream_t stream, const float* pts, const float* scale, const double* cam, int N, int npts,

@@ -63,6 +63,9 @@ def lib():
          ctypes.POINTER(c_void_p), c_int, c_int, c_int, ctypes.c_float, c_int, c_void_p, c_void_p, c_size_t, c_int)
     _sig(L.cp_set_default_precision, c_int, c_int)
     _sig(L.cp_set_debug, c_int, c_int)
+    _sig(L.cp_postprocess_workspace_bytes, c_size_t, c_int, c_int)
+    _sig(L.cp_postprocess, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.c_float, c_int, ctypes.c_float,
+         c_void_p, c_void_p, c_void_p, c_size_t)
     _sig(L.cp_preprocess, c_int, c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_float),
          ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_void_p, c_int, c_int)
     _sig(L.cp_model_set_precision, c_int, c_void_p, c_int)
@@ -81,7 +84,7 @@ def exported_symbols():
             "cp_model_set_param", "cp_model_finalize", "cp_model_destroy", "cp_model_workspace_bytes",
             "cp_model_forward", "cp_model_forward_tap", "cp_conv2d_workspace_bytes", "cp_conv2d_nhwc",
             "cp_decode_workspace_bytes", "cp_decode", "cp_pnp_workspace_bytes", "cp_pnp_solve", "cp_model_profile", "cp_model_profile_read",
-            "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug", "cp_preprocess"]
+            "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug", "cp_preprocess", "cp_postprocess_workspace_bytes", "cp_postprocess"]
 
 
 def _check(rc, what):
@@ -200,6 +203,34 @@ def preprocess(image_u8_hwc, trans_input, mean, std, out_h, out_w):
                          f3(*[float(v) for v in np.asarray(std).reshape(-1)]), _ptr(out), out_h, out_w)
     _check(rc, "cp_preprocess")
     return out
+
+
+POST_STRIDE = 120
+POST_FIELDS = OrderedDict([  # field -> (offset, width) inside a post-processed record (post_process.py:21-58)
+    ("score", (0, 1)), ("cls", (1, 1)), ("obj_scale", (2, 3)), ("obj_scale_uncertainty", (5, 3)),
+    ("kps_displacement_std", (8, 16)), ("bbox", (24, 4)), ("ct", (28, 2)), ("kps", (30, 16)), ("tracking", (46, 2)),
+    ("tracking_hp", (48, 16)), ("kps_displacement_mean", (64, 16)), ("kps_heatmap_mean", (80, 16)),
+    ("kps_heatmap_std", (96, 16)), ("kps_heatmap_height", (112, 8))])
+
+
+def postprocess(det, meta, vis_thresh, nms=True, div_scale=1.0):
+    """Device post-process + Gaussian soft-NMS of a whole batch (object_pose.py:167-197).
+    det [B,K,118] float32 device; meta [B,8] float64 (inverse affine 6, ratio, pad) -> (records [B,K,120] float64
+    device, counts [B] int32 device); image b keeps records[b, :counts[b]] in the reference's final order."""
+    L = lib()
+    if not (det.is_cuda and det.dtype == torch.float32 and det.is_contiguous() and det.dim() == 3
+            and det.shape[2] == DET_STRIDE):
+        raise RuntimeError("postprocess: det must be a contiguous float32 device tensor [B,K,118]")
+    B, K = int(det.shape[0]), int(det.shape[1])
+    meta = torch.as_tensor(meta, dtype=torch.float64).reshape(B, 8).contiguous().to(det.device)
+    out = torch.empty(B, K, POST_STRIDE, dtype=torch.float64, device=det.device)
+    cnt = torch.empty(B, dtype=torch.int32, device=det.device)
+    n = L.cp_postprocess_workspace_bytes(B, K)
+    ws = torch.empty(n, dtype=torch.uint8, device=det.device)
+    rc = L.cp_postprocess(_stream(), _ptr(det), B, K, _ptr(meta), float(vis_thresh), int(bool(nms)), float(div_scale),
+                          _ptr(out), _ptr(cnt), _ptr(ws), n)
+    _check(rc, "cp_postprocess")
+    return out, cnt
 
 
 PNP_STRIDE = 40

@@ -264,15 +264,24 @@ class BaseDetector(object):
         for the whole batch."""
         t0 = time.time()
         images = images.to(self.opt.device)
-        output, dets = self.process(images, None, None, None, None)
+        on_device = self.opt.device.type == 'cuda' and hasattr(self, 'post_process_merge_device')
+        self._skip_host_dets = on_device  # the packed detections stay on the device
+        try:
+            output, dets = self.process(images, None, None, None, None)
+        finally:
+            self._skip_host_dets = False
         self._sync()
         t1 = time.time()
         outs = []
-        all_results = []
-        for b, meta in enumerate(metas):
-            d_b = {k: v[b:b + 1] for k, v in dets.items()}
-            results = self.merge_outputs([self.post_process(d_b, meta, 1)])
-            all_results.append(results)
+        if on_device:
+            # coordinate transform + threshold + soft-NMS of the whole batch in one launch (cp_postprocess)
+            all_results = self.post_process_merge_device(metas)
+        else:
+            all_results = []
+            for b, meta in enumerate(metas):
+                d_b = {k: v[b:b + 1] for k, v in dets.items()}
+                results = self.merge_outputs([self.post_process(d_b, meta, 1)])
+                all_results.append(results)
         t2 = time.time()
         if self.opt.use_pnp == True:  # noqa: E712
             flat = [(b, d) for b, rs in enumerate(all_results) for d in rs]

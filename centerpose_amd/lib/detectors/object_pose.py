@@ -4,7 +4,7 @@ import time
 import numpy as np
 import torch
 
-from ..models.decode import object_pose_decode
+from ..models.decode import object_pose_decode_raw
 from ..utils.post_process import object_pose_post_process
 from .base_detector import BaseDetector
 
@@ -87,12 +87,17 @@ class ObjectPoseDetector(BaseDetector):
             if images.is_cuda:
                 torch.cuda.synchronize()
             forward_time = time.time()
-            dets = object_pose_decode(output['hm'], output['hps'], wh=wh, kps_displacement_std=hps_unc,
-                                      obj_scale=obj_scale, obj_scale_uncertainty=obj_scale_unc, reg=reg, hm_hp=hm_hp,
-                                      hp_offset=hp_offset, tracking=tracking, tracking_hp=tracking_hp, opt=o,
-                                      Inference=True)
-            for k in dets:
-                dets[k] = dets[k].detach().cpu().numpy()
+            raw = object_pose_decode_raw(output['hm'], output['hps'], wh=wh, kps_displacement_std=hps_unc,
+                                         obj_scale=obj_scale, obj_scale_uncertainty=obj_scale_unc, reg=reg,
+                                         hm_hp=hm_hp, hp_offset=hp_offset, tracking=tracking, tracking_hp=tracking_hp,
+                                         opt=o, Inference=True)
+            self.raw_dets = raw  # packed [B,K,118] on the device, for the device post-process (run_batch)
+            if getattr(self, '_skip_host_dets', False):
+                dets = None
+            else:  # one device->host copy, then the reference's 13-key dict as numpy views
+                host = raw.detach().cpu().numpy()
+                from centerpose_amd import hip as _hip
+                dets = {k: host[..., off:off + w] for k, (off, w) in _hip.DET_FIELDS.items()}
         if return_time:
             return output, dets, forward_time
         return output, dets
@@ -114,6 +119,45 @@ class ObjectPoseDetector(BaseDetector):
             keep = soft_nms_nvidia(results, Nt=0.5, method=2, threshold=self.opt.vis_thresh)
             results = results[keep]
         return results
+
+    def post_process_merge_device(self, metas):
+        """post_process + merge_outputs of every image of the last ``process`` call in one device launch
+        (cp_postprocess); returns a list of per-image numpy arrays of detection dicts like ``merge_outputs``."""
+        from centerpose_amd import hip as _hip
+        from ..utils.image import get_affine_transform
+
+        B = len(metas)
+        arr = np.zeros((B, 8), np.float64)
+        for b, meta in enumerate(metas):
+            w, h = meta['out_width'], meta['out_height']
+            arr[b, :6] = get_affine_transform(meta['c'], meta['s'], 0, (w, h), inv=1).reshape(-1)
+            arr[b, 6] = meta['s'] / max(w, h)
+        use_nms = bool(self.opt.nms or len(self.opt.test_scales) > 1)
+        rec, cnt = _hip.postprocess(self.raw_dets, arr, self.opt.vis_thresh, use_nms)
+        rec = rec.cpu().numpy()
+        cnt = cnt.cpu().numpy()
+        f32_fields = ('obj_scale', 'obj_scale_uncertainty', 'kps_displacement_std', 'tracking', 'tracking_hp',
+                      'kps_heatmap_std', 'kps_heatmap_height')
+        out = []
+        for b in range(B):
+            items = []
+            for r in rec[b, :int(cnt[b])]:
+                item = {}
+                for k, (off, w) in _hip.POST_FIELDS.items():
+                    v = r[off:off + w]
+                    if k == 'score':
+                        item[k] = float(v[0])
+                    elif k == 'cls':
+                        item[k] = int(v[0])
+                    elif k == 'ct':
+                        item[k] = [v[0], v[1]]
+                    elif k in f32_fields:
+                        item[k] = v.astype(np.float32)
+                    else:
+                        item[k] = v.copy()
+                items.append(item)
+            out.append(np.array(items))
+        return out
 
     def show_results(self, debugger, image, results):
         print('[centerpose_hip] %d detection(s) (drawing is not part of this library)' % len(results))

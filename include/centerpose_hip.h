@@ -177,6 +177,27 @@ int cp_preprocess(cp_stream_t stream, const unsigned char* image_hwc_bgr, int H,
                   const float* mean3, const float* std3, float* out_chw, int out_h, int out_w);
 
 /* ------------------------------------------------------------------------------------------
+ * Post-process + soft-NMS — replaces `ObjectPoseDetector.post_process` + `merge_outputs`
+ *   (detectors/object_pose.py:167-197 -> utils/post_process.py:12-68 `object_pose_post_process`,
+ *    utils/image.py:23-32 `transform_preds`, object_pose.py:27-124 `soft_nms_nvidia` with Nt=0.5, method=2,
+ *    threshold=vis_thresh).
+ * det:   DEVICE float32 [B,K,118] from cp_decode.
+ * meta:  DEVICE float64 [B,8]: 0..5 = get_affine_transform(c, s, 0, (out_w,out_h), inv=1) row-major (image.py:35-68),
+ *        6 = s / max(out_w, out_h), 7 unused.
+ * out:   DEVICE float64 [B,K,CP_POST_STRIDE]; image b's kept detections, in the reference's final order, are
+ *        out[b][0 .. count[b]) with fields: score 0 | cls 1 | obj_scale 2 | obj_scale_uncertainty 5 |
+ *        kps_displacement_std 8 | bbox 24 | ct 28 | kps 30 | tracking 46 | tracking_hp 48 | kps_displacement_mean 64 |
+ *        kps_heatmap_mean 80 | kps_heatmap_std 96 | kps_heatmap_height 112.
+ * count: DEVICE int32 [B].   nms: 0 = threshold filter only (opt.nms False), 1 = Gaussian soft-NMS.
+ * div_scale: the `scale` of multi-scale testing (object_pose.py:171-176), 1 for the demo configuration.
+ * workspace: cp_postprocess_workspace_bytes(B, K) bytes.
+ * ------------------------------------------------------------------------------------------ */
+#define CP_POST_STRIDE 120
+size_t cp_postprocess_workspace_bytes(int B, int K);
+int cp_postprocess(cp_stream_t stream, const float* det, int B, int K, const double* meta, float vis_thresh, int nms,
+                   float div_scale, double* out, int* count, void* workspace, size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------------------------
  * Batched cuboid PnP — replaces the per-detection loop `pnp_shell` -> `CuboidPNPSolver.solve_pnp`
  *   -> `cv2.solvePnPGeneric(SOLVEPNP_ITERATIVE)` + `cv2.projectPoints`
  *   (utils/pnp/cuboid_pnp_shell.py:11-24, utils/pnp/cuboid_pnp_solver.py:141-239,

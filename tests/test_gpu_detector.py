@@ -139,3 +139,38 @@ def test_device_preprocess_matches_host_restatement(device):
     out = hip.preprocess(torch.from_numpy(img).to(device), trans, mean, std, 512, 512).cpu().numpy()[0]
     np.testing.assert_allclose(out, ref, atol=2e-4)
     assert out[:, 0, 0].tolist() == pytest.approx(((0 - mean) / std).tolist(), abs=1e-6)  # padding rows are "black"
+
+
+def test_device_postprocess_soft_nms_matches_reference_golden(device):
+    """cp_postprocess (transform + threshold + Gaussian soft-NMS on the device) against the REFERENCE's own
+    post_process + merge_outputs output on the same seeded detections (tests/golden/host_post.json)."""
+    import json
+    from oracle.tools import make_goldens as mg
+    from centerpose_amd.lib.utils.image import get_affine_transform
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "host_post.json")) as f:
+        g = json.load(f)
+    dets, metas = mg.host_cases()
+    B, K = dets["scores"].shape[0], dets["scores"].shape[1]
+    raw = np.zeros((B, K, hip.DET_STRIDE), np.float32)
+    for k, (off, w) in hip.DET_FIELDS.items():
+        raw[..., off:off + w] = dets[k].reshape(B, K, w)
+    meta = np.zeros((B, 8))
+    for b, m in enumerate(metas):
+        meta[b, :6] = get_affine_transform(m["c"], m["s"], 0, (m["out_width"], m["out_height"]), inv=1).reshape(-1)
+        meta[b, 6] = m["s"] / max(m["out_width"], m["out_height"])
+    rec, cnt = hip.postprocess(torch.from_numpy(raw).to(device), meta, mg.HostOpt.vis_thresh, nms=True)
+    rec, cnt = rec.cpu().numpy(), cnt.cpu().numpy()
+    for b in range(B):
+        ref = g["cases"][b]["merged"]
+        assert int(cnt[b]) == len(ref)
+        for r, theirs in zip(rec[b, :int(cnt[b])], ref):
+            for k, (off, w) in hip.POST_FIELDS.items():
+                np.testing.assert_allclose(r[off:off + w], np.asarray(theirs[k], np.float64).reshape(-1), rtol=1e-9,
+                                           atol=1e-9, err_msg=k)
+    # threshold filter only (opt.nms False): decode order, scores untouched
+    rec2, cnt2 = hip.postprocess(torch.from_numpy(raw).to(device), meta, mg.HostOpt.vis_thresh, nms=False)
+    for b in range(B):
+        keep = raw[b, :, 4] > mg.HostOpt.vis_thresh
+        assert int(cnt2[b]) == int(keep.sum())
+        np.testing.assert_array_equal(rec2[b, :int(cnt2[b]), 0].cpu().numpy(), raw[b, keep, 4].astype(np.float64))
