@@ -1193,6 +1193,13 @@ int cp_preprocess(cp_stream_t stream, const unsigned char* image_hwc_bgr, int H,
                                 (hipStream_t)stream);
 }
 
+int cp_render_gaussians(cp_stream_t stream, const double* recs, int N, float* out, int C, int H, int W, int clear) {
+    if (!out || C < 1 || H < 1 || W < 1 || N < 0 || (N > 0 && !recs)) return fail(CP_ERR_INVALID, "bad argument");
+    if (clear && hipMemsetAsync(out, 0, (size_t)C * H * W * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        return fail(CP_ERR_LAUNCH, "memset failed");
+    return cp_launch_render_gaussians(recs, N, out, C, H, W, (hipStream_t)stream);
+}
+
 size_t cp_postprocess_workspace_bytes(int B, int K) {
     return B > 0 && K > 0 ? (size_t)B * K * CP_POST_STRIDE * sizeof(double) : 0;
 }

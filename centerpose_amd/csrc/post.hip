@@ -148,7 +148,38 @@ __global__ __launch_bounds__(64) void postprocess_kernel(const float* __restrict
     }
 }
 
+// Tracking-input render (first half): `draw_umich_gaussian` (utils/image.py:135-150) for a list of
+// (channel, x, y, radius, k) records into the pre_hm / pre_hm_hp planes that CenterPoseTrack feeds back into the
+// network (base_detector.py:150-388 decides WHICH points; this kernel draws them).  One workgroup per record walks its
+// (2r+1)^2 window, clipped to the map exactly like the reference's slice arithmetic; the value is
+// float32(exp(-(dx^2+dy^2) / (2 sigma^2)) * k) with sigma = (2r+1)/6 evaluated in float64, merged with an integer
+// atomicMax on the bit pattern (all values are >= 0, so the order of records does not matter: deterministic).
+__global__ void render_gaussians_kernel(const double* __restrict__ recs, float* __restrict__ out, int C, int H, int W) {
+    const double* r = recs + (size_t)blockIdx.x * 5;
+    const int c = (int)r[0], x = (int)r[1], y = (int)r[2], radius = (int)r[3];
+    const double k = r[4];
+    if (c < 0 || c >= C || radius < 0) return;
+    const int d = 2 * radius + 1;
+    const double sigma = (double)d / 6.0;
+    const double den = 2 * sigma * sigma;
+    for (int i = threadIdx.x; i < d * d; i += blockDim.x) {
+        const int dy = i / d - radius, dx = i - (i / d) * d - radius;
+        const int px = x + dx, py = y + dy;
+        if (px < 0 || px >= W || py < 0 || py >= H) continue;
+        double g = exp(-((double)dx * dx + (double)dy * dy) / den);
+        if (g < 2.220446049250313e-16) g = 0.0;  // gaussian2D: h[h < eps * h.max()] = 0, h.max() = 1 at the centre
+        const float v = (float)(g * k);
+        if (v > 0.f) atomicMax(reinterpret_cast<int*>(out) + ((size_t)c * H + py) * W + px, __float_as_int(v));
+    }
+}
+
 }  // namespace
+
+int cp_launch_render_gaussians(const double* recs, int N, float* out, int C, int H, int W, hipStream_t s) {
+    if (N <= 0) return CP_OK;
+    hipLaunchKernelGGL(render_gaussians_kernel, dim3(N), dim3(256), 0, s, recs, out, C, H, W);
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}
 
 int cp_launch_postprocess(const float* det, int B, int K, const double* meta, float vis_thresh, int nms,
                           float div_scale, double* out, int* count, double* ws, hipStream_t s) {

@@ -63,6 +63,7 @@ def lib():
          ctypes.POINTER(c_void_p), c_int, c_int, c_int, ctypes.c_float, c_int, c_void_p, c_void_p, c_size_t, c_int)
     _sig(L.cp_set_default_precision, c_int, c_int)
     _sig(L.cp_set_debug, c_int, c_int)
+    _sig(L.cp_render_gaussians, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int)
     _sig(L.cp_postprocess_workspace_bytes, c_size_t, c_int, c_int)
     _sig(L.cp_postprocess, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.c_float, c_int, ctypes.c_float,
          c_void_p, c_void_p, c_void_p, c_size_t)
@@ -84,7 +85,7 @@ def exported_symbols():
             "cp_model_set_param", "cp_model_finalize", "cp_model_destroy", "cp_model_workspace_bytes",
             "cp_model_forward", "cp_model_forward_tap", "cp_conv2d_workspace_bytes", "cp_conv2d_nhwc",
             "cp_decode_workspace_bytes", "cp_decode", "cp_pnp_workspace_bytes", "cp_pnp_solve", "cp_model_profile", "cp_model_profile_read",
-            "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug", "cp_preprocess", "cp_postprocess_workspace_bytes", "cp_postprocess"]
+            "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug", "cp_preprocess", "cp_postprocess_workspace_bytes", "cp_postprocess", "cp_render_gaussians"]
 
 
 def _check(rc, what):
@@ -202,6 +203,20 @@ def preprocess(image_u8_hwc, trans_input, mean, std, out_h, out_w):
                          f3(*[float(v) for v in np.asarray(mean).reshape(-1)]),
                          f3(*[float(v) for v in np.asarray(std).reshape(-1)]), _ptr(out), out_h, out_w)
     _check(rc, "cp_preprocess")
+    return out
+
+
+def render_gaussians(records, C, H, W, device, out=None):
+    """Draw (channel, x, y, radius, k) Gaussians into a float32 [C,H,W] device map with max() merging
+    (draw_umich_gaussian, utils/image.py:135-150): the pre_hm / pre_hm_hp render of CenterPoseTrack."""
+    L = lib()
+    rec = torch.as_tensor(records, dtype=torch.float64).reshape(-1, 5).contiguous().to(device)
+    if out is None:
+        out = torch.empty(C, H, W, dtype=torch.float32, device=device)
+    elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (C, H, W)):
+        raise RuntimeError("render_gaussians: out must be a contiguous float32 device tensor [C,H,W]")
+    _check(L.cp_render_gaussians(_stream(), _ptr(rec) if rec.numel() else None, int(rec.shape[0]), _ptr(out), C, H, W,
+                                 1), "cp_render_gaussians")
     return out
 
 

@@ -198,6 +198,15 @@ int cp_postprocess(cp_stream_t stream, const float* det, int B, int K, const dou
                    float div_scale, double* out, int* count, void* workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------
+ * Tracking-input render — the drawing half of `BaseDetector._get_additional_inputs`
+ *   (detectors/base_detector.py:150-388 -> utils/image.py:135-150 `draw_umich_gaussian`, :126-132 `gaussian2D`).
+ * recs: DEVICE float64 [N,5] = (channel, x, y, radius, k) per Gaussian (x, y, radius integral; k = peak value);
+ * out:  DEVICE float32 [C,H,W] (pre_hm: C=1, pre_hm_hp: C=8, or both stacked); cleared first when clear != 0.
+ * Each record is drawn clipped to the map and merged with max(), exactly as the reference's in-place np.maximum.
+ * ------------------------------------------------------------------------------------------ */
+int cp_render_gaussians(cp_stream_t stream, const double* recs, int N, float* out, int C, int H, int W, int clear);
+
+/* ------------------------------------------------------------------------------------------
  * Batched cuboid PnP — replaces the per-detection loop `pnp_shell` -> `CuboidPNPSolver.solve_pnp`
  *   -> `cv2.solvePnPGeneric(SOLVEPNP_ITERATIVE)` + `cv2.projectPoints`
  *   (utils/pnp/cuboid_pnp_shell.py:11-24, utils/pnp/cuboid_pnp_solver.py:141-239,

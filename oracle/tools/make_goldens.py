@@ -137,6 +137,22 @@ def host_goldens():
     print("host_post.json:", [(c["n_post"], len(c["merged"])) for c in cases])
 
 
+RENDER_RECORDS = [  # (channel, x, y, radius, k): interior, clipped at each border, outside, zero radius, overlapping
+    (0, 40, 50, 6, 1.0), (0, 44, 52, 9, 0.73), (1, 2, 3, 7, 1.0), (2, 125, 64, 10, 0.5), (3, 64, 126, 5, 1.0),
+    (4, -4, 30, 8, 1.0), (5, 140, 20, 8, 1.0), (6, 70, 70, 0, 0.9), (7, 64, 64, 30, 0.31), (8, 10, 120, 12, 1.0),
+    (8, 14, 118, 4, 0.95)]
+
+
+def render_goldens():
+    """Reference draw_umich_gaussian (utils/image.py:135-150) on a 9 x 128 x 128 map -> render_ref.npz."""
+    rimage, _, _ = rh.reference_host_modules()
+    hm = np.zeros((9, 128, 128), np.float32)
+    for c, x, y, r, k in RENDER_RECORDS:
+        rimage.draw_umich_gaussian(hm[c], (x, y), r, k=k)
+    np.savez_compressed(os.path.join(GOLD, "render_ref.npz"), hm=hm)
+    print("render_ref.npz: nonzero", int((hm > 0).sum()))
+
+
 OPTS_SCENARIOS = [
     [],
     ["--arch", "dlav1_34", "--c", "cup", "--rep_mode", "1"],
@@ -217,6 +233,7 @@ def main():
     r = reference_decode_run(d, False, "uint8", rep_mode=0)
     np.savez_compressed(os.path.join(GOLD, "decode_pose_uint8_rep0.npz"), **r)
     host_goldens()
+    render_goldens()
     opts_goldens()
     print("done ->", GOLD)
 

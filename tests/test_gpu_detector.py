@@ -174,3 +174,19 @@ def test_device_postprocess_soft_nms_matches_reference_golden(device):
         keep = raw[b, :, 4] > mg.HostOpt.vis_thresh
         assert int(cnt2[b]) == int(keep.sum())
         np.testing.assert_array_equal(rec2[b, :int(cnt2[b]), 0].cpu().numpy(), raw[b, keep, 4].astype(np.float64))
+
+
+def test_device_gaussian_render_matches_reference_golden(device):
+    """cp_render_gaussians vs the reference's draw_umich_gaussian on the same records (tests/golden/render_ref.npz):
+    interior, clipped on every border, fully outside, radius 0, overlapping peaks; drawn in two different orders."""
+    from oracle.tools import make_goldens as mg
+
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "render_ref.npz"))["hm"]
+    recs = np.array(mg.RENDER_RECORDS, np.float64)
+    out = hip.render_gaussians(recs, 9, 128, 128, device).cpu().numpy()
+    # float64 exp on the device vs numpy, rounded to float32: equal up to one float32 ulp at isolated pixels
+    np.testing.assert_allclose(out, ref, rtol=2e-7, atol=1e-30)
+    assert (out > 0).sum() == (ref > 0).sum()
+    out2 = hip.render_gaussians(recs[::-1].copy(), 9, 128, 128, device).cpu().numpy()
+    assert np.array_equal(out, out2)   # max() merge: record order does not matter
+    assert float(hip.render_gaussians(np.zeros((0, 5)), 1, 8, 8, device).abs().sum()) == 0.0
