@@ -74,7 +74,7 @@ __device__ __forceinline__ Split2 split2(float a, float b) {
 #define CP_DBG(p) 0
 #endif
 template <int MT, int NT, int WM, int WN, bool DCN, bool MULTISRC, bool PF2>
-__global__ __launch_bounds__(NT16, 2) void igemm16_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
+__global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
