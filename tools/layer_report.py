@@ -4,9 +4,11 @@ import csv
 import json
 import sys
 
-bench, layers, steps = sys.argv[1], sys.argv[2], float(sys.argv[3])
+bench, layers = sys.argv[1], sys.argv[2]
 top = int(sys.argv[4]) if len(sys.argv) > 4 else 25
 d = json.loads(open(bench).read())
+# number of timed steps whose launches were profiled (bench.py samples every 4th step); argv[3] overrides
+steps = float(d["roofline"].get("timed_steps_sampled") or sys.argv[3])
 print("value %.1f img/s  %.2f ms/step  p50 B=1 %s ms  whole-step %.1f TF" % (
     d["value"], d["ms_per_step"], d.get("p50_frame_ms_batch1"), d["whole_step_tflops"]))
 for k, v in d["roofline"]["all_conv_kernels"].items():
