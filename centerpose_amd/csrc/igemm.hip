@@ -66,8 +66,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void igemm_kernel(const ConvParams p, 
     const int HWo = p.Ho * p.Wo;
 
     // ---- per-thread A-slot geometry (fixed over the K loop) ----
-    const float rcp_hwo = 1.f / (float)HWo, rcp_wo = 1.f / (float)p.Wo;
-    const bool big_m = M >= (1 << 24);
+    PixelDecomp pdec;
+    pdec.init(p.Ho, p.Wo, M);
     const int k4 = tid & 3;
     int a_b[A_SLOTS], a_h0[A_SLOTS], a_w0[A_SLOTS];
     int a_pix0[A_SLOTS];       // (b*H + h0)*W + w0, may be negative (halo)
@@ -78,9 +78,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void igemm_kernel(const ConvParams p, 
         const int m = tm * BM + (tid >> 2) + j * 64;
         a_ok[j] = m < M;
         const int mm = a_ok[j] ? m : 0;
-        int rem, wo;
-        const int b = div_small(mm, HWo, rcp_hwo, &rem, big_m);
-        const int ho = div_small(rem, p.Wo, rcp_wo, &wo, big_m);
+        int b, ho, wo;
+        pdec.split(mm, &b, &ho, &wo);
         a_b[j] = b;
         a_h0[j] = ho * p.stride - p.pad;
         a_w0[j] = wo * p.stride - p.pad;

@@ -97,8 +97,8 @@ __global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel
     const int tn = tile % tiles_n, tm = tile / tiles_n;
     const int M = p.B * p.Ho * p.Wo;
     const int HWo = p.Ho * p.Wo;
-    const float rcp_hwo = 1.f / (float)HWo, rcp_wo = 1.f / (float)p.Wo;
-    const bool big_m = M >= (1 << 24);
+    PixelDecomp pdec;
+    pdec.init(p.Ho, p.Wo, M);
 
     // ---- per-thread A-slot geometry: slot j covers pixel row (tid / 8) + 32 * j, float4 column tid % 8 ----
     const int k4 = tid & 7;
@@ -110,9 +110,8 @@ __global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel
         const int m = tm * BM + (tid >> 3) + j * 32;
         a_ok[j] = m < M;
         const int mm = a_ok[j] ? m : 0;
-        int rem, wo;
-        const int b = div_small(mm, HWo, rcp_hwo, &rem, big_m);
-        const int ho = div_small(rem, p.Wo, rcp_wo, &wo, big_m);
+        int b, ho, wo;
+        pdec.split(mm, &b, &ho, &wo);
         a_b[j] = b;
         a_h0[j] = ho * p.stride - p.pad;
         a_w0[j] = wo * p.stride - p.pad;
@@ -459,8 +458,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
     const int tn = tile % tiles_n, tm = tile / tiles_n;
     const int M = p.B * p.Ho * p.Wo;
     const int HWo = p.Ho * p.Wo;
-    const float rcp_hwo = 1.f / (float)HWo, rcp_wo = 1.f / (float)p.Wo;
-    const bool big_m = M >= (1 << 24);
+    PixelDecomp pdec;
+    pdec.init(p.Ho, p.Wo, M);
 
     const int k4 = tid & 7;
     int a_pix0[A_SLOTS];
@@ -470,9 +469,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
         const int m = tm * BM + (tid >> 3) + j * RPP;
         const bool ok = m < M;
         const int mm = ok ? m : 0;
-        int rem, wo;
-        const int b = div_small(mm, HWo, rcp_hwo, &rem, big_m);
-        const int ho = div_small(rem, p.Wo, rcp_wo, &wo, big_m);
+        int b, ho, wo;
+        pdec.split(mm, &b, &ho, &wo);
         const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
         a_pix0[j] = (b * p.H + h0) * p.W + w0;
         a_byte0[j] = (unsigned)(a_pix0[j] * p.src_c[0] + k4 * 4) * 4u;
