@@ -422,6 +422,9 @@ __global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel
 #ifndef CP_EXP
 #define CP_EXP 0
 #endif
+#if CP_EXP & 256
+__device__ unsigned long long g_cp_clk[2];  // shader-clock / 100 MHz-clock ticks of workgroup 0 (tuning: actual frequency)
+#endif
 // FUSE (128x128 tiles only): fused prediction head.  The main MFMAs run with swapped operands, so a wave's accumulators
 // hold hidden^T -- rows = 32 hidden channels of a fragment spread over (register, lane half), columns = 32 pixels over
 // the lanes.  That is exactly the B-operand shape of a second MFMA whose k runs over hidden channels: 8 consecutive
@@ -450,6 +453,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
     // reads and writes is pinned by hand below, no alias analysis needed)
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * BUF];
 
+#if CP_EXP & 256
+    const unsigned long long clk0 = clock64(), wclk0 = wall_clock64();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = tid >> 6;
@@ -782,6 +788,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
     }
     if (p.splitk > 1) igemm_store_partial<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane, blockIdx.y);
     else igemm_epilogue<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane);
+#if CP_EXP & 256
+    if (blockIdx.x == 4000 && threadIdx.x == 0) {
+        g_cp_clk[0] = clock64() - clk0;
+        g_cp_clk[1] = wall_clock64() - wclk0;
+    }
+#endif
 }
 
 template <int MT, int NT, int WM, int WN, bool DCN, bool MULTISRC>
@@ -934,3 +946,9 @@ int cp_launch_head_reduce(const float* slabs, const float* bias, float* out_nchw
                        sigmoid);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
+
+#if CP_EXP & 256
+extern "C" int cp_debug_read_clk(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cp_clk), sizeof(unsigned long long) * 2) == hipSuccess ? 0 : -1;
+}
+#endif
