@@ -88,8 +88,68 @@ def _ida(spec, p, o, channels, up_f):
         _deform(spec, "%s.node_%d" % (p, i), o, o)
 
 
+HG_DIMS = [256, 256, 384, 384, 384, 512]   # large_hourglass.py:296-298
+HG_MODULES = [2, 2, 2, 2, 2, 4]
+
+
+def _hg_residual(spec, p, cin, cout, stride=1):
+    """large_hourglass.py:50-78: conv1-bn1-relu, conv2-bn2, optional 1x1 skip + bn"""
+    spec[p + ".conv1.weight"] = (cout, cin, 3, 3)
+    _bn(spec, p + ".bn1", cout)
+    spec[p + ".conv2.weight"] = (cout, cout, 3, 3)
+    _bn(spec, p + ".bn2", cout)
+    if stride != 1 or cin != cout:
+        spec[p + ".skip.0.weight"] = (cout, cin, 1, 1)
+        _bn(spec, p + ".skip.1", cout)
+
+
+def _hg_kp(spec, p, n, dims, modules):
+    """kp_module (large_hourglass.py:129-189): up1 | low1 (stride 2) | low2 (recursive) | low3 (reversed)"""
+    cur, nxt, cm, nm = dims[0], dims[1], modules[0], modules[1]
+    for i in range(cm):
+        _hg_residual(spec, "%s.up1.%d" % (p, i), cur, cur)
+    for i in range(cm):
+        _hg_residual(spec, "%s.low1.%d" % (p, i), cur if i == 0 else nxt, nxt, 2 if i == 0 else 1)
+    if n > 1:
+        _hg_kp(spec, p + ".low2", n - 1, dims[1:], modules[1:])
+    else:
+        for i in range(nm):
+            _hg_residual(spec, "%s.low2.%d" % (p, i), nxt, nxt)
+    for i in range(cm):
+        _hg_residual(spec, "%s.low3.%d" % (p, i), nxt, nxt if i < cm - 1 else cur)
+
+
+def hourglass_param_spec(heads=None, nstack=2):
+    """OrderedDict name -> shape of the reference ``HourglassNet(heads, 2)`` state dict (large_hourglass.py:191-307)."""
+    heads = heads or HEADS_POSE
+    s = OrderedDict()
+    s["pre.0.conv.weight"] = (128, 3, 7, 7)
+    _bn(s, "pre.0.bn", 128)
+    _hg_residual(s, "pre.1", 128, 256, 2)
+    for k in range(nstack):
+        _hg_kp(s, "kps.%d" % k, 5, HG_DIMS, HG_MODULES)
+    for k in range(nstack):
+        s["cnvs.%d.conv.weight" % k] = (256, 256, 3, 3)
+        _bn(s, "cnvs.%d.bn" % k, 256)
+    for k in range(nstack - 1):
+        _hg_residual(s, "inters.%d" % k, 256, 256)
+    for nm in ("inters_", "cnvs_"):
+        for k in range(nstack - 1):
+            s["%s.%d.0.weight" % (nm, k)] = (256, 256, 1, 1)
+            _bn(s, "%s.%d.1" % (nm, k), 256)
+    for h, classes in heads.items():
+        for k in range(nstack):
+            s["%s.%d.0.conv.weight" % (h, k)] = (256, 256, 3, 3)
+            s["%s.%d.0.conv.bias" % (h, k)] = (256,)
+            s["%s.%d.1.weight" % (h, k)] = (classes, 256, 1, 1)
+            s["%s.%d.1.bias" % (h, k)] = (classes,)
+    return s
+
+
 def param_spec(arch="dla_34", heads=None, tracking=False, head_conv=256):
-    """OrderedDict name -> shape of the reference DLASeg state dict for 'dla_34' / 'dlav1_34'."""
+    """OrderedDict name -> shape of the reference state dict for 'dla_34' / 'dlav1_34' (DLASeg) / 'hourglass'."""
+    if arch == "hourglass":
+        return hourglass_param_spec(heads)
     base_arch = arch.split("_")[0]
     assert base_arch in ("dla", "dlav1"), arch
     heads = heads or (HEADS_TRACK if tracking else HEADS_POSE)
@@ -167,6 +227,8 @@ def make_state_dict(arch="dla_34", heads=None, tracking=False, seed=DEFAULT_SEED
     heads_ = heads or (HEADS_TRACK if tracking else HEADS_POSE)
     last = 3 if arch.split("_")[0] == "dlav1" else 2
     final_hm_bias = {"%s.%d.bias" % (h, last) for h in heads_ if "hm" in h}
+    if arch == "hourglass":  # heat[-1].bias.fill_(-2.19) on every stack (large_hourglass.py:246-247)
+        final_hm_bias = {"%s.%d.1.bias" % (h, k) for h in heads_ if "hm" in h for k in range(2)}
     sd = OrderedDict()
     for name, shape in spec.items():
         g = _gen(seed, name)
@@ -192,6 +254,13 @@ def make_state_dict(arch="dla_34", heads=None, tracking=False, seed=DEFAULT_SEED
         else:  # conv weight, He-normal on fan_in
             fan_in = shape[1] * shape[2] * shape[3]
             t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+            if arch == "hourglass":
+                # ~100 residual / merge additions deep: damp the branch that is ADDED (conv2 of a residual, the skip
+                # and merge paths keep unit gain) so activations neither explode nor vanish without a calibration pass
+                if name.endswith(".conv2.weight"):
+                    t = t * 0.35
+                elif len(shape) == 4 and shape[2] == 1 and name.count(".") == 3 and name.split(".")[0] in heads_:
+                    t = t * 0.5  # final 1x1 of a head: logits of O(1) around the -2.19 bias
         if name in scales:
             t = t * float(scales[name])
         sd[name] = t.float() if t.dtype != torch.long else t

@@ -7,6 +7,7 @@ and the HIP path are both checked against them.
 
   state_dict_keys.json      name -> shape of the reference ``create_model(...).state_dict()``
   backbone_<cfg>.npz        reference ``model(x, pre_img, pre_hm, pre_hm_hp)[-1]`` at 128x128, B=1
+                            (cfg: dla, dlav1, dla_track, dlav1_track, hourglass)
   dcn_ref.npz               reference CPU im2col + GEMM on a random-offset case + the reference's
                             own known-answer test (DCNv2/testcpu.py:32-67, check_zero_offset)
   decode_<cfg>.npz          reference ``object_pose_decode`` (Inference=True) on seeded heads:
@@ -205,6 +206,18 @@ def main():
         out["_weights_checksum"] = np.array([float(sum(v.double().sum() for v in sd.values() if v.is_floating_point()))])
         np.savez_compressed(os.path.join(GOLD, "backbone_%s.npz" % cfg), **out)
         print("backbone", cfg, {k: v.shape for k, v in out.items() if not k.startswith("_")})
+    # stacked hourglass (large_hourglass.py): the reference module on the seeded weights, last stack's heads
+    model = rh.create_reference_model("hourglass", synth.HEADS_POSE)
+    keys["hourglass"] = {k: list(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.make_state_dict("hourglass", synth.HEADS_POSE)
+    model.load_state_dict(sd, strict=True)
+    x, _ = backbone_inputs(False)
+    with torch.no_grad():
+        z = model(x)[-1]
+    out = {k: v.numpy() for k, v in z.items()}
+    out["_weights_checksum"] = np.array([float(sum(v.double().sum() for v in sd.values() if v.is_floating_point()))])
+    np.savez_compressed(os.path.join(GOLD, "backbone_hourglass.npz"), **out)
+    print("backbone hourglass", {k: v.shape for k, v in out.items() if not k.startswith("_")})
     with open(os.path.join(GOLD, "state_dict_keys.json"), "w") as f:
         json.dump(keys, f, indent=0, sort_keys=True)
 

@@ -42,6 +42,32 @@ def test_backbone_oracle_vs_reference_golden(arch, tracking):
         np.testing.assert_allclose(z[k].numpy(), gold[k], rtol=0, atol=1e-5, err_msg=k)
 
 
+def test_hourglass_spec_and_oracle_vs_reference_golden():
+    """Stacked hourglass (large_hourglass.py): parameter names / shapes / order and the oracle's forward against the
+    reference module's own output on the seeded weights."""
+    from oracle import hourglass as oh
+
+    with open(os.path.join(GOLD, "state_dict_keys.json")) as f:
+        keys = json.load(f)["hourglass"]
+    spec = synth.param_spec("hourglass", synth.HEADS_POSE)
+    assert {k: tuple(v) for k, v in keys.items()} == dict(spec)
+    gold = np.load(os.path.join(GOLD, "backbone_hourglass.npz"))
+    sd = synth.make_state_dict("hourglass", synth.HEADS_POSE)
+    chk = float(sum(v.double().sum() for v in sd.values() if v.is_floating_point()))
+    assert abs(chk - float(gold["_weights_checksum"][0])) < 1e-6 * max(1.0, abs(chk)), "seeded weights differ"
+    x, _ = mg.backbone_inputs(False)
+    z = oh.hourglass_forward(sd, x, synth.HEADS_POSE)
+    for k in synth.HEADS_POSE:
+        np.testing.assert_allclose(z[k].numpy(), gold[k], rtol=0, atol=1e-5, err_msg=k)
+    if rh.available():
+        model = rh.create_reference_model("hourglass", synth.HEADS_POSE)
+        model.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            zr = model(x)[-1]
+        for k in synth.HEADS_POSE:
+            assert torch.equal(zr[k], z[k]), k
+
+
 def test_dcn_oracle_vs_reference_golden_and_kat():
     gold = np.load(os.path.join(GOLD, "dcn_ref.npz"))
     x, w, b, off, mask = mg.dcn_case()
