@@ -35,7 +35,9 @@ from centerpose_amd import hip, synth  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, dense f32 matrix
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense f16/bf16 matrix
 GFLOP_PER_IMG = {"dlav1_34": 106.85, "dla_34": 85.11, "dla_34_track": 109.68,
-                 "dlav1_34_track": 138.7}  # BASELINE.md section 2, SURVEY 8(f) N4
+                 "dlav1_34_track": 138.7, "hourglass": 603.7}  # BASELINE.md section 2, SURVEY 8(a) M9 / 8(f) N4
+# hourglass: 739.0 GFLOP/img for the reference module minus the 135.3 of the first stack's seven heads, which do not feed
+# model(x)[-1] and are not computed
 
 
 def parse():
@@ -43,11 +45,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="decode", choices=["decode", "full", "track", "track_gru"],
+    ap.add_argument("--workload", default="decode", choices=["decode", "full", "track", "track_gru", "hourglass"],
                     help="decode: configs[1] (default); full: configs[2] dla_34 + PnP; track: dla_34 two-frame "
                          "CenterPoseTrack inputs + Gaussian-moment decode + RCCL all-gather of detection records; "
                          "track_gru: the same on dlav1_34 (two-frame input + ConvGRU heads = BASELINE configs[4] as "
-                         "the reference can actually run it, SURVEY 8(f) N4 option ii)")
+                         "the reference can actually run it, SURVEY 8(f) N4 option ii); hourglass: the 2-stack hourglass "
+                         "backbone, single frame, + decode (configs[4] as the reference DEFINES it, N4 option i)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 / 64)")
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
                     help="f32: exact float32 MFMA; f16x3: split-binary16 MFMA (float32-class accuracy)")
@@ -61,7 +64,7 @@ class Pipeline(object):
 
     def __init__(self, workload, batch, device, seed, precision="f32"):
         self.workload = workload
-        self.arch = "dlav1_34" if workload in ("decode", "track_gru") else "dla_34"
+        self.arch = "dlav1_34" if workload in ("decode", "track_gru") else "hourglass" if workload == "hourglass" else "dla_34"
         self.track = workload in ("track", "track_gru")
         self.heads = synth.HEADS_TRACK if self.track else synth.HEADS_POSE
         self.batch = batch
@@ -86,7 +89,7 @@ class Pipeline(object):
             x, extra = self.x, self.extra
         else:
             extra = {k: v[: x.shape[0]] for k, v in self.extra.items()}
-        if self.workload == "decode":
+        if self.workload in ("decode", "hourglass"):
             # backbone + sigmoid + decode in one library call (hipGraph replay when graph=True)
             return self.model.detect(x, K=100, rep_mode=1, fit_gaussian=False, balance=2.0, graph=graph)[1]
         z = self.model(x, sigmoid_hm=True, **extra)
@@ -115,7 +118,7 @@ class Pipeline(object):
 
 def cpu_baseline(workload, arch, budget_s=12.0, max_imgs=16):
     """Oracle (CPU port of the reference graph) on a bounded sample of the same workload."""
-    if workload in ("track", "track_gru"):
+    if workload in ("track", "track_gru", "hourglass"):
         return None
     from oracle import backbone as ob
     from oracle import decode as odec
@@ -153,7 +156,7 @@ def main():
         import torch.distributed as dist
 
         cpd.init_from_env("nccl")
-    batch = args.batch or {"decode": 32, "full": 64, "track": 16, "track_gru": 16}[args.workload]
+    batch = args.batch or {"decode": 32, "full": 64, "track": 16, "track_gru": 16, "hourglass": 8}[args.workload]
     pipe = Pipeline(args.workload, batch, device, seed=317 + 1000 * rank, precision=args.precision)
 
     def barrier():
@@ -239,7 +242,8 @@ def main():
             cpu = cpu_baseline(args.workload, pipe.arch)
         gf = GFLOP_PER_IMG[pipe.arch + ("_track" if pipe.track else "")]
         out = {
-            "metric": "images/sec at 512x512 DLA-34 (backbone + heat-map decode%s)" % (
+            "metric": "images/sec at 512x512 %s (backbone + heat-map decode%s)" % (
+                "2-stack hourglass" if pipe.arch == "hourglass" else "DLA-34",
                 " + PnP" if args.workload == "full" else " + detection all-gather" if pipe.track else ""),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,

@@ -127,6 +127,9 @@ int cp_launch_upsample_add(const float* in, const float* w, const float* add, fl
                            int C, int f, hipStream_t s);
 int cp_launch_add_relu_sum(const float* a, const float* b, const float* c, const float* d, float* out, size_t n,
                            hipStream_t s);
+// hourglass merge: out[B,2H,2W,C] = up1 + nearest-x2(low[B,H,W,C])  (large_hourglass.py:186-188)
+int cp_launch_upsample2_nearest_add(const float* up1, const float* low, float* out, int B, int H, int W, int C,
+                                    hipStream_t s);
 // ConvGRU gates (convGRU.py:32-39).  x3/h3: [M,192] = (r,z,n) pre-activations, h: [M,64]
 int cp_launch_gru_gate(const float* x3, const float* h3, const float* hprev, float* hout, size_t M, hipStream_t s);
 // GroupNorm(32 groups) over NHWC [B, HW, C]: stats then in-place normalise + affine + ReLU

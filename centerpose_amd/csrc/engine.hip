@@ -135,7 +135,7 @@ struct HeadW {
 
 struct cp_model {
     std::string arch;
-    bool gru = false, tracking = false, finalized = false;
+    bool gru = false, tracking = false, finalized = false, hourglass = false;
     int precision = g_default_precision;
     int head_conv = 256;
     std::vector<std::pair<std::string, int>> heads;
@@ -325,6 +325,60 @@ struct Packer {
             if (const auto* w = get(p + ".up_" + k + ".weight", (size_t)o * 4 * f * f)) m->ups[p + ".up_" + k] = upload(*w);
         }
     }
+    // ---- stacked hourglass (large_hourglass.py) ----
+    void hg_residual(const std::string& p, int cin, int cout, int stride) {
+        conv_bn(p + ".conv1", p + ".conv1", p + ".bn1", cout, cin, 3);
+        conv_bn(p + ".conv2", p + ".conv2", p + ".bn2", cout, cout, 3);
+        if (stride != 1 || cin != cout) conv_bn(p + ".skip", p + ".skip.0", p + ".skip.1", cout, cin, 1);
+    }
+    void hg_kp(const std::string& p, int n, const int* dims, const int* mods) {
+        const int cur = dims[0], nxt = dims[1], cm = mods[0], nm = mods[1];
+        for (int i = 0; i < cm; ++i) hg_residual(p + ".up1." + std::to_string(i), cur, cur, 1);
+        for (int i = 0; i < cm; ++i) hg_residual(p + ".low1." + std::to_string(i), i == 0 ? cur : nxt, nxt, i == 0 ? 2 : 1);
+        if (n > 1) hg_kp(p + ".low2", n - 1, dims + 1, mods + 1);
+        else
+            for (int i = 0; i < nm; ++i) hg_residual(p + ".low2." + std::to_string(i), nxt, nxt, 1);
+        for (int i = 0; i < cm; ++i) hg_residual(p + ".low3." + std::to_string(i), nxt, i < cm - 1 ? nxt : cur, 1);
+    }
+    void run_hourglass() {
+        static const int dims[6] = {256, 256, 384, 384, 384, 512}, mods[6] = {2, 2, 2, 2, 2, 4};
+        conv_bn("pre.0", "pre.0.conv", "pre.0.bn", 128, 3, 7, 4);
+        hg_residual("pre.1", 128, 256, 2);
+        for (int k = 0; k < 2; ++k) {
+            const std::string ks = std::to_string(k);
+            hg_kp("kps." + ks, 5, dims, mods);
+            conv_bn("cnvs." + ks, "cnvs." + ks + ".conv", "cnvs." + ks + ".bn", 256, 256, 3);
+        }
+        hg_residual("inters.0", 256, 256, 1);
+        conv_bn("inters_.0", "inters_.0.0", "inters_.0.1", 256, 256, 1);
+        conv_bn("cnvs_.0", "cnvs_.0.0", "cnvs_.0.1", 256, 256, 1);
+        // heads of the LAST stack only: the detector takes model(x)[-1] (object_pose.py:135); the first stack's head
+        // tensors do not feed anything downstream
+        for (auto& h : m->heads) {
+            HeadW hw;
+            hw.name = h.first;
+            hw.classes = h.second;
+            const std::string b = h.first + ".1";
+            hw.c0 = pack({b + ".0.conv.weight"}, 256, 256, 3, 3);
+            if (const auto* bias = get(b + ".0.conv.bias", 256)) set_affine(hw.c0, nullptr, *bias);
+            hw.c1 = pack({b + ".1.weight"}, h.second, 256, 1, 1);
+            if (const auto* bias = get(b + ".1.bias", h.second)) set_affine(hw.c1, nullptr, *bias);
+            if (h.second <= 32 && hw.c0.w16_hi) {
+                if (const auto* w1 = get(b + ".1.weight", (size_t)h.second * 256)) {
+                    float* tmp = upload(*w1);
+                    hw.w2_hi = dev_alloc((size_t)256 * 32 / 2);
+                    hw.w2_lo = dev_alloc((size_t)256 * 32 / 2);
+                    if (tmp && hw.w2_hi && hw.w2_lo) {
+                        const int rc = cp_launch_pack_head_w2(tmp, hw.w2_hi, hw.w2_lo, h.second, 256, nullptr);
+                        hipDeviceSynchronize();
+                        if (rc != CP_OK) status = rc;
+                    }
+                }
+            }
+            m->headw.push_back(hw);
+        }
+    }
+
     // weight fragments for the direct low-channel kernels (f16x3 mode); the folded BatchNorm comes from the ConvW
     void lowc(const std::string& name, const std::string& wname, int kind, int cout, int cin, int k) {
         const auto* w = get(wname + ".weight", (size_t)cout * cin * k * k);
@@ -751,6 +805,63 @@ struct Fwd {
         return t;
     }
 
+    // ---- stacked hourglass forward (large_hourglass.py:50-78, 129-189, 266-286) ----
+    Tensor hg_residual(const std::string& p, const Tensor& x, int stride) {
+        Tensor t = conv(cw(p + ".conv1"), {&x}, stride, 1, CP_ACT_RELU);
+        if (m->convs.count(p + ".skip")) {
+            Tensor sk = conv(cw(p + ".skip"), {&x}, stride, 0, CP_ACT_NONE);
+            return conv(cw(p + ".conv2"), {&t}, 1, 1, CP_ACT_RELU, &sk);  // relu(bn2(conv2) + skip)
+        }
+        return conv(cw(p + ".conv2"), {&t}, 1, 1, CP_ACT_RELU, &x);
+    }
+    Tensor hg_seq(const std::string& p, Tensor x, int n, int first_stride) {
+        for (int i = 0; i < n; ++i) x = hg_residual(p + "." + std::to_string(i), x, i == 0 ? first_stride : 1);
+        return x;
+    }
+    Tensor hg_kp(const std::string& p, const Tensor& x, int n, const int* mods) {
+        const int cm = mods[0], nm = mods[1];
+        Tensor up1 = hg_seq(p + ".up1", x, cm, 1);
+        Tensor low = hg_seq(p + ".low1", x, cm, 2);
+        low = n > 1 ? hg_kp(p + ".low2", low, n - 1, mods + 1) : hg_seq(p + ".low2", low, nm, 1);
+        low = hg_seq(p + ".low3", low, cm, 1);
+        Tensor out = make(up1.C, up1.H, up1.W);
+        if (!m->dry) chk(cp_launch_upsample2_nearest_add(up1.ptr(), low.ptr(), out.ptr(), B, low.H, low.W, low.C, s));
+        tap(p, out);
+        return out;
+    }
+    void run_hourglass(int H, int W, const float* images, float* const* head_out, int sigmoid_hm) {
+        static const int mods[6] = {2, 2, 2, 2, 2, 4};
+        Tensor inter;
+        {
+            Tensor in = to_nhwc(images, 3, 4, H, W);
+            Tensor p0 = conv(cw("pre.0"), {&in}, 2, 3, CP_ACT_RELU);
+            inter = hg_residual("pre.1", p0, 2);
+        }
+        tap("pre", inter);
+        Tensor cnv;
+        for (int k = 0; k < 2; ++k) {
+            const std::string ks = std::to_string(k);
+            Tensor kp = hg_kp("kps." + ks, inter, 5, mods);
+            cnv = conv(cw("cnvs." + ks), {&kp}, 1, 1, CP_ACT_RELU);
+            tap("cnvs." + ks, cnv);
+            if (k == 0) {
+                Tensor a = conv(cw("inters_.0"), {&inter}, 1, 0, CP_ACT_NONE);
+                Tensor b = conv(cw("cnvs_.0"), {&cnv}, 1, 0, CP_ACT_RELU, &a);  // relu(inters_(inter) + cnvs_(cnv))
+                inter = hg_residual("inters.0", b, 1);
+            }
+        }
+        for (size_t i = 0; i < m->headw.size(); ++i) {
+            const HeadW& hw = m->headw[i];
+            const bool sg = sigmoid_hm && (hw.name == "hm" || hw.name == "hm_hp");
+            if (hw.w2_hi && m->precision == CP_PREC_F16X3 && !m->tap_name && !(g_dbg & 32) &&
+                fused_head(hw, cnv, sg, m->dry ? (float*)0x1000 : head_out[i]))
+                continue;
+            Tensor hid = conv(hw.c0, {&cnv}, 1, 1, CP_ACT_RELU);
+            conv(hw.c1, {&hid}, 1, 0, sg ? CP_ACT_SIGMOID : CP_ACT_NONE, nullptr, nullptr, 0,
+                 m->dry ? (float*)0x1000 : head_out[i], hw.classes);
+        }
+    }
+
     void run(int H, int W, const float* images, const float* pre_img, const float* pre_hm, const float* pre_hm_hp,
              float* const* head_out, int sigmoid_hm) {
         Tensor x0 = lowc("base.base_layer", 0, images, H, W, 3);
@@ -909,11 +1020,14 @@ int forward_impl(cp_model* m, hipStream_t stream, int B, int H, int W, const flo
                  size_t ws_bytes, bool dry) {
     if (!m || !m->finalized) return fail(CP_ERR_STATE, "model not finalized");
     if (B < 1 || H % 32 || W % 32 || H < 32 || W < 32) return fail(CP_ERR_INVALID, "H and W must be multiples of 32");
+    if (m->hourglass && (H % 128 || W % 128))
+        return fail(CP_ERR_INVALID, "hourglass: H and W must be multiples of 128 (stride 4, then five stride-2 levels)");
     m->arena.reset(dry ? nullptr : ws, ws_bytes);
     m->dry = dry;
     m->status = CP_OK;
     Fwd f{m, B, stream};
-    f.run(H, W, images, pre_img, pre_hm, pre_hm_hp, head_out, sigmoid_hm);
+    if (m->hourglass) f.run_hourglass(H, W, images, head_out, sigmoid_hm);
+    else f.run(H, W, images, pre_img, pre_hm, pre_hm_hp, head_out, sigmoid_hm);
     if (!dry && m->arena.overflow) return fail(CP_ERR_INVALID, "workspace too small");
     return m->status;
 }
@@ -930,11 +1044,15 @@ int cp_model_create(const char* arch, int tracking_task, int num_heads, const ch
                     const int* head_classes, int head_conv, cp_model** out) {
     if (!arch || !out || num_heads < 1 || !head_names || !head_classes) return fail(CP_ERR_INVALID, "null argument");
     std::string a(arch);
-    if (a != "dla_34" && a != "dlav1_34") return fail(CP_ERR_INVALID, "arch must be dla_34 or dlav1_34");
+    if (a != "dla_34" && a != "dlav1_34" && a != "hourglass")
+        return fail(CP_ERR_INVALID, "arch must be dla_34, dlav1_34 or hourglass");
+    if (a == "hourglass" && tracking_task)
+        return fail(CP_ERR_INVALID, "the hourglass takes a single frame (large_hourglass.py:266)");
     if (head_conv <= 0 || head_conv % 32 != 0) return fail(CP_ERR_INVALID, "head_conv must be a positive multiple of 32");
     cp_model* m = new cp_model();
     m->arch = a;
     m->gru = (a == "dlav1_34");
+    m->hourglass = (a == "hourglass");
     m->tracking = tracking_task != 0;
     m->head_conv = head_conv;
     for (int i = 0; i < num_heads; ++i) m->heads.push_back({head_names[i], head_classes[i]});
@@ -953,7 +1071,8 @@ int cp_model_finalize(cp_model* m) {
     if (!m) return fail(CP_ERR_INVALID, "null model");
     if (m->finalized) return CP_OK;
     Packer pk{m};
-    pk.run();
+    if (m->hourglass) pk.run_hourglass();
+    else pk.run();
     hipDeviceSynchronize();
     if (pk.status != CP_OK) return fail(pk.status, "missing or mis-shaped parameter: " + pk.missing);
     m->params.clear();

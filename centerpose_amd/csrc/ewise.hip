@@ -295,6 +295,24 @@ __global__ void preprocess_kernel(const unsigned char* __restrict__ img, int H, 
     for (int c = 0; c < 3; ++c) out[(size_t)c * OH * OW + i] = (acc[c] / 255.f - pp.mean[c]) * pp.inv_std[c];
 }
 
+// kp_module merge of the stacked hourglass (large_hourglass.py:186-188): out = up1 + Upsample(scale_factor=2)(low3),
+// nearest neighbour.  up1 / out: [B, 2H, 2W, C], low: [B, H, W, C]; one float4 per lane.
+__global__ void upsample2_nearest_add_kernel(const float* __restrict__ up1, const float* __restrict__ low,
+                                             float* __restrict__ out, int B, int H, int W, int C4) {
+    const size_t total = (size_t)B * 2 * H * 2 * W * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t r = i / C4;
+        const int x = (int)(r % (2 * W));
+        r /= 2 * W;
+        const int y = (int)(r % (2 * H));
+        const size_t b = r / (2 * H);
+        const float4 a = reinterpret_cast<const float4*>(up1)[i];
+        const float4 l = reinterpret_cast<const float4*>(low)[((b * H + (y >> 1)) * W + (x >> 1)) * C4 + c];
+        reinterpret_cast<float4*>(out)[i] = make_float4(a.x + l.x, a.y + l.y, a.z + l.z, a.w + l.w);
+    }
+}
+
 inline int check() { return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH; }
 
 }  // namespace
@@ -339,6 +357,14 @@ int cp_launch_add_relu_sum(const float* a, const float* b, const float* c, const
     if (n % 4) return CP_ERR_INVALID;
     hipLaunchKernelGGL(add_n_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, s, (const float4*)a, (const float4*)b,
                        (const float4*)c, (const float4*)d, (float4*)out, n / 4);
+    return check();
+}
+
+int cp_launch_upsample2_nearest_add(const float* up1, const float* low, float* out, int B, int H, int W, int C,
+                                    hipStream_t s) {
+    if (C % 4) return CP_ERR_INVALID;
+    hipLaunchKernelGGL(upsample2_nearest_add_kernel, dim3(grid_for((size_t)B * 4 * H * W * (C / 4))), dim3(TPB), 0, s, up1,
+                       low, out, B, H, W, C / 4);
     return check();
 }
 

@@ -12,7 +12,7 @@ import torch
 from centerpose_amd import hip as _hip
 from centerpose_amd import synth as _synth
 
-_SUPPORTED = ('dla', 'dlav1')  # model.py:16-23: the other factories are not named by any benchmark config
+_SUPPORTED = ('dla', 'dlav1', 'hourglass')  # model.py:16-23: the other factories are not named by any benchmark config
 
 
 class HipPoseNet(object):
@@ -20,9 +20,12 @@ class HipPoseNet(object):
     (a list with one dict of head tensors)."""
 
     def __init__(self, arch, num_layers, heads, head_conv, opt=None):
-        if num_layers != 34:
+        if arch == 'hourglass':  # get_large_hourglass_net ignores num_layers / head_conv (large_hourglass.py:311-313)
+            self.arch = 'hourglass'
+        elif num_layers != 34:
             raise NotImplementedError("only DLA-34 is built (BASELINE configs); got %s_%d" % (arch, num_layers))
-        self.arch = "%s_%d" % (arch, num_layers)
+        else:
+            self.arch = "%s_%d" % (arch, num_layers)
         self.heads = OrderedDict(heads)
         self.head_conv = head_conv
         self.opt = opt
@@ -43,7 +46,11 @@ class HipPoseNet(object):
                 self._sd[k] = torch.zeros(shape)
         for h in self.heads:
             if 'hm' in h:
-                self._sd['%s.%d.bias' % (h, last)].fill_(-2.19)
+                if arch == 'hourglass':  # large_hourglass.py:246-247, both stacks
+                    for k in range(2):
+                        self._sd['%s.%d.1.bias' % (h, k)].fill_(-2.19)
+                else:
+                    self._sd['%s.%d.bias' % (h, last)].fill_(-2.19)
         self.device = torch.device('cpu')
         self.training = False
         self._hip = None
@@ -110,7 +117,11 @@ def _dlav1(num_layers, heads, head_conv=256, down_ratio=4, opt=None):
     return HipPoseNet('dlav1', num_layers, heads, head_conv, opt)
 
 
-_model_factory = {'dla': _dla, 'dlav1': _dlav1}
+def _hourglass(num_layers, heads, head_conv=256, down_ratio=4, opt=None):
+    return HipPoseNet('hourglass', num_layers, heads, head_conv, opt)
+
+
+_model_factory = {'dla': _dla, 'dlav1': _dlav1, 'hourglass': _hourglass}
 
 
 def create_model(arch, heads, head_conv, opt=None):

@@ -188,6 +188,40 @@ def test_backbone_non_square_ragged_tiles_vs_oracle(device, prec):
         assert float((z[k].cpu() - zo[k]).abs().max()) < 1e-3 * max(1.0, float(zo[k].abs().max())), k
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_hourglass_vs_reference_golden(device, prec):
+    """Stacked hourglass (BASELINE configs[4] as the reference defines it, single frame): engine vs the reference
+    module's own output on the seeded weights (tests/golden/backbone_hourglass.npz, 128x128 -> 1x1 at the deepest level)."""
+    heads = synth.HEADS_POSE
+    gold = np.load(os.path.join(GOLD, "backbone_hourglass.npz"))
+    sd = synth.make_state_dict("hourglass", heads)
+    x, _ = mg.backbone_inputs(False)
+    model = hip.HipModel("hourglass", heads, sd, precision=prec)
+    z = model(x.to(device))
+    for k in heads:
+        ref = torch.from_numpy(gold[k])
+        err = float((z[k].cpu() - ref).abs().max())
+        assert err < 1e-3 * max(1.0, float(ref.abs().max())), (k, err)
+    hm = torch.sigmoid(z["hm"].cpu())
+    assert float((hm - torch.sigmoid(torch.from_numpy(gold["hm"]))).abs().max()) < 1e-3
+
+
+def test_hourglass_256_vs_oracle_and_rejects_bad_sizes(device):
+    from oracle import hourglass as oh
+
+    heads = synth.HEADS_POSE
+    sd = synth.make_state_dict("hourglass", heads)
+    x = synth.frames(2, seed=37, h=256, w=256)
+    model = hip.HipModel("hourglass", heads, sd, precision="f16x3")
+    z = model(x.to(device), sigmoid_hm=True)
+    zo = oh.hourglass_forward(sd, x, heads)
+    assert float((z["hm"].cpu() - torch.sigmoid(zo["hm"])).abs().max()) < 1e-3
+    for k in ("wh", "hps", "reg", "hp_offset", "scale"):
+        assert float((z[k].cpu() - zo[k]).abs().max()) < 1e-3 * max(1.0, float(zo[k].abs().max())), k
+    with pytest.raises(RuntimeError):
+        model(synth.frames(1, seed=1, h=160, w=160).to(device))   # not a multiple of 128
+
+
 def test_fused_head_matches_unfused_path(device):
     """dla_34 heads (conv3x3 -> ReLU -> conv1x1, no GroupNorm) run as one fused kernel in f16x3 mode; the two-kernel
     path (debug flag 32) must give the same maps to float32 round-off, and the fused path must be deterministic."""
