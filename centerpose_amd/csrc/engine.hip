@@ -1037,7 +1037,7 @@ int forward_impl(cp_model* m, hipStream_t stream, int B, int H, int W, const flo
 // ============================================ C ABI ==============================================
 extern "C" {
 
-const char* cp_version(void) { return "centerpose_hip 0.1.0 (gfx950, f32 MFMA)"; }
+const char* cp_version(void) { return "centerpose_hip 0.2.0 (gfx950; f32 and split-f16 MFMA)"; }
 const char* cp_last_error(void) { return g_err.c_str(); }
 
 int cp_model_create(const char* arch, int tracking_task, int num_heads, const char* const* head_names,
