@@ -114,6 +114,9 @@ struct ConvW {
 };
 
 int g_default_precision = CP_PREC_F32;
+// split-K policy: launches with fewer output tiles than kSplitTiles (and >= 8 K steps) are cut into K slices until
+// about kSplitTarget workgroups exist
+constexpr int kSplitTiles = 128, kSplitTarget = 384;  // (384 / 512 measured: B=32 equal, hourglass B=1 latency +7 %)
 int g_dbg = 0;  // cp_set_debug: 16 previous (non-pipelined) f16x3 kernel, 32 no head fusion, 64 no lowc kernels
 
 struct DeformW {
@@ -537,7 +540,7 @@ struct Fwd {
         if (w.KH != 3 || w.KW != 3 || !cp_head_fuse_supported(p, hw.classes)) return false;
         int tiles = 0, nk = 0;
         cp_conv_geometry(p, true, &tiles, &nk);
-        if (tiles < 128 && nk >= 8) return false;  // small launches keep the split-K path (conv())
+        if (tiles < kSplitTiles && nk >= 8) return false;  // small launches keep the split-K path (conv())
         const int slices = p.CoutPad / 128;
         Tensor slabs = make(slices * hw.classes, p.Ho, p.Wo);
         p.fuse_out = slabs.ptr();
@@ -647,8 +650,8 @@ struct Fwd {
         {
             int tiles = 0, nk = 0;
             cp_conv_geometry(p, use16, &tiles, &nk);
-            if (tiles > 0 && tiles < 128 && nk >= 8 && !p.gn_stats) {
-                int want = (384 + tiles - 1) / tiles;
+            if (tiles > 0 && tiles < kSplitTiles && nk >= 8 && !p.gn_stats) {
+                int want = (kSplitTarget + tiles - 1) / tiles;
                 if (want > nk / 2) want = nk / 2;
                 if (want > 32) want = 32;
                 if (want > 1) {
