@@ -6,7 +6,7 @@
 // base_detector.py:547-654).  OpenCV's arithmetic is not in the reference tree (un-vendored
 // opencv-python>=4.5.3.56); this kernel restates calib3d's published SOLVEPNP_ITERATIVE for >= 6
 // non-planar points exactly as oracle/pnp.py does:
-//   normalise by K -> DLT: smallest eigenvector of L^T L (12x12, cyclic Jacobi) -> det sign fix ->
+//   normalise by K -> DLT: smallest eigenvector of L^T L (12x12; shifted inverse iteration in registers) -> det sign fix ->
 //   polar factor R = U V^T, t *= |R| / |R_raw| -> Rodrigues -> Levenberg-Marquardt (<= 20 iterations,
 //   eps = FLT_EPSILON, lambda = 10^k from k = -3, diag(JtJ) *= 1 + lambda) on pixel reprojection error.
 // The cuboid model, point filtering (x or y < -5000 dropped; point i belongs to vertex i / (n/8)),
@@ -99,50 +99,76 @@ __device__ void rot_to_rvec(const double R[9], double r[3]) {
     r[0] = rx * v; r[1] = ry * v; r[2] = rz * v;
 }
 
-// Smallest eigenvector of a symmetric 12x12 matrix by cyclic Jacobi (A destroyed; V accumulates).
-#define A_(idx) A[(size_t)(idx) * stride]
-#define V_(idx) V[(size_t)(idx) * stride]
-__device__ void smallest_eigvec12(double* A /*144, strided*/, double* V /*144, strided*/, size_t stride, double out[12]) {
-    const int n = 12;
-    for (int i = 0; i < n * n; ++i) V_(i) = (i % (n + 1) == 0) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0, dg = 0;
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) (i == j ? dg : off) += A_(i * n + j) * A_(i * n + j);
-        if (off <= 1e-30 * dg) break;
-        for (int p = 0; p < n - 1; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = A_(p * n + q);
-                if (fabs(apq) < 1e-300) continue;
-                const double app = A_(p * n + p), aqq = A_(q * n + q);
-                const double tau = (aqq - app) / (2.0 * apq);
-                const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
-                for (int k = 0; k < n; ++k) {
-                    const double akp = A_(k * n + p), akq = A_(k * n + q);
-                    A_(k * n + p) = c * akp - s * akq;
-                    A_(k * n + q) = s * akp + c * akq;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double apk = A_(p * n + k), aqk = A_(q * n + k);
-                    A_(p * n + k) = c * apk - s * aqk;
-                    A_(q * n + k) = s * apk + c * aqk;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double vkp = V_(k * n + p), vkq = V_(k * n + q);
-                    V_(k * n + p) = c * vkp - s * vkq;
-                    V_(k * n + q) = s * vkp + c * vkq;
-                }
-            }
+// Smallest eigenvector of a symmetric positive semi-definite 12x12 matrix (lower triangle, packed: element (i, j),
+// j <= i, at i*(i+1)/2 + j), by shifted inverse iteration on a Cholesky factor held entirely in registers:
+//   A + mu*I = L L^T (mu = 1e-13 * trace keeps the factorisation positive when the smallest eigenvalue is ~0, as it is for
+//   exact correspondences, without moving the eigenvectors), then x <- normalise(L^-T L^-1 x) until the direction stops
+//   changing.  ~300 FMAs for the factor + 160 per iteration, against ~10^5 strided global loads / stores for the cyclic
+//   Jacobi sweep this replaces (which was 90 % of the kernel's time: 4.1 ms per 6400 detections).  The convergence
+//   ratio is lambda_1 / lambda_2; the iteration cap only bites on (near-)degenerate point sets, whose pose is
+//   ill-defined anyway and is refined by the Levenberg-Marquardt stage regardless.
+#define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
+__device__ void smallest_eigvec12(double* A /*78, destroyed*/, double out[12]) {
+    constexpr int n = 12;
+    double tr = 0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) tr += A[TRI(i, i)];
+    const double mu = 1e-13 * tr + 1e-300;
+#pragma unroll
+    for (int i = 0; i < n; ++i) A[TRI(i, i)] += mu;
+    // in-place Cholesky, column by column (all indices are compile-time constants after unrolling -> registers)
+    double dinv[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+        double d = A[TRI(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= A[TRI(j, k)] * A[TRI(j, k)];
+        d = d > mu * 1e-3 ? d : mu * 1e-3;  // rounding can eat a ~0 pivot; keep the factor real
+        const double l = sqrt(d);
+        A[TRI(j, j)] = l;
+        dinv[j] = 1.0 / l;
+#pragma unroll
+        for (int i = j + 1; i < n; ++i) {
+            double v = A[TRI(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= A[TRI(i, k)] * A[TRI(j, k)];
+            A[TRI(i, j)] = v * dinv[j];
+        }
     }
-    int best = 0;
-    for (int i = 1; i < n; ++i)
-        if (A_(i * n + i) < A_(best * n + best)) best = i;
-    for (int k = 0; k < n; ++k) out[k] = V_(k * n + best);
+    double x[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = 0.28867513459481287 * ((i & 1) ? 1.0 : 0.9) * ((i % 3 == 2) ? -1.0 : 1.0);  // generic start
+    for (int it = 0; it < 400; ++it) {
+        double y[n];
+        // forward: L z = x
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double v = x[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) v -= A[TRI(i, k)] * y[k];
+            y[i] = v * dinv[i];
+        }
+        // backward: L^T w = z
+#pragma unroll
+        for (int i = n - 1; i >= 0; --i) {
+            double v = y[i];
+#pragma unroll
+            for (int k = i + 1; k < n; ++k) v -= A[TRI(k, i)] * y[k];
+            y[i] = v * dinv[i];
+        }
+        double nn = 0, dot = 0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) nn += y[i] * y[i];
+        const double inv = 1.0 / sqrt(nn);
+#pragma unroll
+        for (int i = 0; i < n; ++i) { y[i] *= inv; dot += y[i] * x[i]; }
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = y[i];
+        if (it >= 2 && 1.0 - fabs(dot) < 1e-16) break;
+    }
+#pragma unroll
+    for (int i = 0; i < n; ++i) out[i] = x[i];
 }
-
-#undef A_
-#undef V_
 
 // solve 6x6 A x = b (Gaussian elimination, partial pivoting); A, b destroyed
 __device__ void solve6(double A[36], double b[6], double x[6]) {
@@ -192,7 +218,7 @@ __device__ void axis_angle_quat(const double r[3], double q[4]) {
 }
 
 // pts [N][npts][2] float (npts = 8 or 16), scale [N][3] float, cam [N][4] double (fx, fy, cx, cy)
-// out [N][CP_PNP_STRIDE] double;  scratch [N][288] double for the Jacobi matrices.
+// out [N][CP_PNP_STRIDE] double;  scratch: unused since the eigen-solver moved into registers (kept in the ABI).
 __global__ __launch_bounds__(64) void pnp_kernel(const float* __restrict__ pts, const float* __restrict__ scale,
                                                  const double* __restrict__ camp, int N, int npts,
                                                  double* __restrict__ out, double* __restrict__ scratch) {
@@ -253,24 +279,23 @@ __global__ __launch_bounds__(64) void pnp_kernel(const float* __restrict__ pts, 
         if (e0 < e1) { tmp = e0; e0 = e1; e1 = tmp; }
         if (e2 / e1 < 1e-3) { o[0] = -3; return; }  // planar: homography branch not restated
     }
-    // ---- DLT ----
-    // Jacobi matrices live in global scratch, element-major (element k of detection i at [k * N + i]) so
-    // that the 64 lanes of a wavefront touch consecutive addresses
-    const size_t stride = (size_t)N;
-    double* A = scratch + i;
-    double* Vm = scratch + (size_t)144 * N + i;
-    for (int k = 0; k < 144; ++k) A[(size_t)k * stride] = 0.0;
+    // ---- DLT ----  L^T L accumulated as a packed lower triangle in registers
+    double As[78];
+#pragma unroll
+    for (int k = 0; k < 78; ++k) As[k] = 0.0;
     for (int k = 0; k < npts; ++k) {
         if (P[2 * k] < -5000.f || P[2 * k + 1] < -5000.f) continue;
         const double* M = V3[k / per];
         const double x = -((double)P[2 * k] - cam.cx) / cam.fx, y = -((double)P[2 * k + 1] - cam.cy) / cam.fy;
         const double r0[12] = {M[0], M[1], M[2], 1, 0, 0, 0, 0, x * M[0], x * M[1], x * M[2], x};
         const double r1[12] = {0, 0, 0, 0, M[0], M[1], M[2], 1, y * M[0], y * M[1], y * M[2], y};
+#pragma unroll
         for (int a = 0; a < 12; ++a)
-            for (int b = 0; b < 12; ++b) A[(size_t)(a * 12 + b) * stride] += r0[a] * r0[b] + r1[a] * r1[b];
+#pragma unroll
+            for (int b = 0; b <= a; ++b) As[TRI(a, b)] += r0[a] * r0[b] + r1[a] * r1[b];
     }
     double ev[12];
-    smallest_eigvec12(A, Vm, stride, ev);
+    smallest_eigvec12(As, ev);
     double RR[9] = {ev[0], ev[1], ev[2], ev[4], ev[5], ev[6], ev[8], ev[9], ev[10]};
     double tt[3] = {ev[3], ev[7], ev[11]};
     const double det = RR[0] * (RR[4] * RR[8] - RR[5] * RR[7]) - RR[1] * (RR[3] * RR[8] - RR[5] * RR[6]) +
