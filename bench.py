@@ -149,19 +149,28 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    # one GPU per rank; ($CP_BENCH_BACKEND=gloo with fewer GPUs than ranks is a plumbing rehearsal on a 1-GPU box)
+    backend = os.environ.get("CP_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if world > ndev and backend == "nccl":
+        raise SystemExit("bench.py: %d ranks but %d visible GPUs (RCCL needs one GPU per rank)" % (world, ndev))
+    local = local % ndev
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        cpd.init_from_env("nccl")
+        cpd.init_from_env(backend)
     batch = args.batch or {"decode": 32, "full": 64, "track": 16, "track_gru": 16, "hourglass": 8}[args.workload]
     pipe = Pipeline(args.workload, batch, device, seed=317 + 1000 * rank, precision=args.precision)
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local])
+            if backend == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     side = torch.cuda.Stream(device=device)  # a non-default stream (hipGraph capture needs one)
