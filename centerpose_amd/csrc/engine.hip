@@ -190,6 +190,14 @@ struct Packer {
     int status = CP_OK;
     std::string missing;
 
+    // a failing HIP runtime call while packing makes cp_model_finalize fail (first error wins)
+    bool hip_ok(hipError_t e) {
+        if (e != hipSuccess && status == CP_OK) {
+            status = CP_ERR_LAUNCH;
+            missing = std::string("HIP runtime: ") + hipGetErrorString(e);
+        }
+        return e == hipSuccess;
+    }
     const std::vector<float>* get(const std::string& n, size_t numel) {
         auto it = m->params.find(n);
         if (it == m->params.end() || it->second.size() != numel) {
@@ -205,13 +213,13 @@ struct Packer {
             status = CP_ERR_ALLOC;
             return nullptr;
         }
-        if (zero) hipMemset(p, 0, nfloat * sizeof(float));
+        if (zero) hip_ok(hipMemset(p, 0, nfloat * sizeof(float)));
         m->device_allocs.push_back(p);
         return (float*)p;
     }
     float* upload(const std::vector<float>& h) {
         float* d = dev_alloc(h.size(), false);
-        if (d) hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (d) hip_ok(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
         return d;
     }
     // Pack several PyTorch-layout weights side by side along Cout (GRU gates) into one GEMM operand.
@@ -242,14 +250,14 @@ struct Packer {
                 status = CP_ERR_ALLOC;
                 return c;
             }
-            hipMemcpy(tmp, w->data(), w->size() * sizeof(float), hipMemcpyHostToDevice);
+            hip_ok(hipMemcpy(tmp, w->data(), w->size() * sizeof(float), hipMemcpyHostToDevice));
             int rc = cp_launch_pack_weight(tmp, c.wp, cout_each, cin, kh * kw, c.CinP, c.CoutPad, (int)i * cout_each,
                                            nullptr);
             if (rc == CP_OK && c.w16_hi && c.w16_lo)
                 rc = cp_launch_pack_weight16(tmp, c.w16_hi, c.w16_lo, cout_each, cin, kh * kw, c.Kpad16,
                                              (int)i * cout_each, nullptr);
-            hipDeviceSynchronize();
-            hipFree(tmp);
+            hip_ok(hipDeviceSynchronize());
+            (void)hipFree(tmp);
             if (rc != CP_OK) status = rc;
         }
         return c;
@@ -373,7 +381,7 @@ struct Packer {
                     hw.w2_lo = dev_alloc((size_t)256 * 32 / 2);
                     if (tmp && hw.w2_hi && hw.w2_lo) {
                         const int rc = cp_launch_pack_head_w2(tmp, hw.w2_hi, hw.w2_lo, h.second, 256, nullptr);
-                        hipDeviceSynchronize();
+                        hip_ok(hipDeviceSynchronize());
                         if (rc != CP_OK) status = rc;
                     }
                 }
@@ -392,7 +400,7 @@ struct Packer {
         void* lo = dev_alloc(halfs / 2);
         if (!tmp || !hi || !lo) return;
         const int rc = cp_launch_pack_lowc(kind, tmp, hi, lo, cin, nullptr);
-        hipDeviceSynchronize();
+        hip_ok(hipDeviceSynchronize());
         if (rc != CP_OK) status = rc;
         m->lowc[name] = {hi, lo};
     }
@@ -449,7 +457,7 @@ struct Packer {
                     hw.w2_lo = dev_alloc((size_t)hc * 32 / 2);
                     if (tmp && hw.w2_hi && hw.w2_lo) {
                         const int rc = cp_launch_pack_head_w2(tmp, hw.w2_hi, hw.w2_lo, h.second, hc, nullptr);
-                        hipDeviceSynchronize();
+                        hip_ok(hipDeviceSynchronize());
                         if (rc != CP_OK) status = rc;
                     }
                 }
@@ -1076,8 +1084,9 @@ int cp_model_finalize(cp_model* m) {
     Packer pk{m};
     if (m->hourglass) pk.run_hourglass();
     else pk.run();
-    hipDeviceSynchronize();
-    if (pk.status != CP_OK) return fail(pk.status, "missing or mis-shaped parameter: " + pk.missing);
+    pk.hip_ok(hipDeviceSynchronize());
+    if (pk.status != CP_OK)
+        return fail(pk.status, (pk.status == CP_ERR_STATE ? "missing or mis-shaped parameter: " : "finalize failed: ") + pk.missing);
     m->params.clear();
     m->finalized = true;
     return CP_OK;
@@ -1142,7 +1151,7 @@ void cp_model_destroy(cp_model* m) {
     }
     for (auto e : m->event_pool) (void)hipEventDestroy(e);
     for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
-    for (void* p : m->device_allocs) hipFree(p);
+    for (void* p : m->device_allocs) (void)hipFree(p);
     delete m;
 }
 
