@@ -1,6 +1,6 @@
-"""GPU diagnostic sweep (not a test): runs every kernel family against the CPU oracle and prints one
+"""GPU diagnostic sweep (test infrastructure, not collected by pytest): runs every kernel family against the CPU oracle and prints one
 line per case without stopping at the first mismatch.  Usage on the GPU box:
-    python tools/gpu_diag.py [--full]      (output is also what gpurun shows in its tail)
+    python tests/gpu_diag.py [--full | --f16x3 | --decode-only | --pnp-only]      (output is also what gpurun shows in its tail)
 """
 import os
 import sys
