@@ -117,7 +117,7 @@ int g_default_precision = CP_PREC_F32;
 // split-K policy: launches with fewer output tiles than kSplitTiles (and >= 8 K steps) are cut into K slices until
 // about kSplitTarget workgroups exist
 constexpr int kSplitTiles = 128, kSplitTarget = 384;  // (384 / 512 measured: B=32 equal, hourglass B=1 latency +7 %)
-int g_dbg = 0;  // cp_set_debug: 16 previous (non-pipelined) f16x3 kernel, 32 no head fusion, 64 no lowc kernels
+int g_dbg = 0;  // cp_set_debug (A/B switches for tests and tuning): 32 no head fusion, 64 no lowc kernels
 
 struct DeformW {
     ConvW offset;  // conv_offset_mask (27 -> 32 padded), shift = bias

@@ -96,7 +96,6 @@ __global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel
     const int tile = tile_of_block(tiles_m, tiles_n);
     const int tn = tile % tiles_n, tm = tile / tiles_n;
     const int M = p.B * p.Ho * p.Wo;
-    const int HWo = p.Ho * p.Wo;
     PixelDecomp pdec;
     pdec.init(p.Ho, p.Wo, M);
 
@@ -463,7 +462,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
     const int tile = tile_of_block(tiles_m, tiles_n);
     const int tn = tile % tiles_n, tm = tile / tiles_n;
     const int M = p.B * p.Ho * p.Wo;
-    const int HWo = p.Ho * p.Wo;
     PixelDecomp pdec;
     pdec.init(p.Ho, p.Wo, M);
 
@@ -798,18 +796,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
 
 template <int MT, int NT, int WM, int WN, bool DCN, bool MULTISRC>
 int launch16(const ConvParams& p, hipStream_t stream) {
-    constexpr bool PF2 = !DCN;
+    constexpr bool PF2 = false;  // the DCN loader blends on arrival: one register set
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = p.CoutPad / BN;
     if (p.CoutPad % BN != 0 || p.Kpad16 % BK16 != 0) return CP_ERR_INVALID;
     const dim3 grid(tiles_m * tiles_n, p.splitk > 1 ? p.splitk : 1);
     if constexpr (!DCN) {
-        if (!(p.dbg & 16)) {
-            hipLaunchKernelGGL((igemm16p_kernel<MT, NT, WM, WN, MULTISRC>), grid, dim3(NT16), 0, stream, p, tiles_m,
-                               tiles_n);
-            return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
-        }
+        // every non-DCN layer runs the pipelined kernel; igemm16_kernel is only instantiated for the DCN gather layers
+        hipLaunchKernelGGL((igemm16p_kernel<MT, NT, WM, WN, MULTISRC>), grid, dim3(NT16), 0, stream, p, tiles_m, tiles_n);
+        return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
     }
     hipLaunchKernelGGL((igemm16_kernel<MT, NT, WM, WN, DCN, MULTISRC, PF2>), grid, dim3(NT16), 0, stream, p, tiles_m,
                        tiles_n);
