@@ -7,6 +7,11 @@
  * launches on the caller's stream and never synchronises.  Unless stated otherwise pointers are
  * DEVICE pointers to float32.  Paths below are relative to the reference tree
  * (/root/reference/src/lib/...).
+ *
+ * Threading: stateless entry points (cp_dcnv2_forward, cp_conv2d_nhwc, cp_decode, cp_postprocess, cp_pnp_solve,
+ * cp_preprocess, cp_render_gaussians) may be called concurrently on different streams.  A cp_model is not re-entrant:
+ * one forward / detect at a time per model (its workspace, profile records and hipGraph cache are per model).
+ * cp_last_error(), cp_set_default_precision() and cp_set_debug() are process-global.
  */
 #ifndef CENTERPOSE_HIP_H
 #define CENTERPOSE_HIP_H
