@@ -67,6 +67,10 @@ struct ConvParams {
     const float* gn_in_mr;
     const float* gn_in_gamma;
     const float* gn_in_beta;
+    // the same fusion for the f16x3 1x1 kernel: the normalisation pre-folded per (image, channel) to y = relu(a*x + d),
+    // planes [B][Cin] each (cp_launch_gn_affine)
+    const float* gn_in_a;
+    const float* gn_in_d;
     // deterministic split-K (few output tiles, long K: low-resolution layers at small batch): blockIdx.y = K slice,
     // raw accumulators go to partial[slice][M][CoutPad]; cp_launch_splitk_epilogue sums the slices in order and
     // applies the usual epilogue.
@@ -136,6 +140,9 @@ int cp_launch_gru_gate(const float* x3, const float* h3, const float* hprev, flo
 int cp_launch_groupnorm_relu(float* x, const float* gamma, const float* beta, double* stats_ws, int B, int HW, int C,
                              int groups, float eps, hipStream_t s);
 // (sum, sumsq) doubles -> (mean, rstd) floats per (image, group)
+// (sum, sum of squares) per (image, group) -> per (image, channel) affine a = rstd*gamma, d = beta - mean*rstd*gamma
+int cp_launch_gn_affine(const double* stats, const float* gamma, const float* beta, float* a, float* d, int B, int C,
+                        int groups, double count, float eps, hipStream_t s);
 int cp_launch_gn_finalize(const double* stats, float* mr, int n, double count, float eps, hipStream_t s);
 // PyTorch [Cout][Cin][taps] weights -> packed GEMM operand (buffer must be pre-zeroed for padding)
 int cp_launch_pack_weight(const float* w, float* wp, int Cout, int Cin, int taps, int CinP, int CoutPad, int coff,

@@ -117,7 +117,7 @@ int g_default_precision = CP_PREC_F32;
 // split-K policy: launches with fewer output tiles than kSplitTiles (and >= 8 K steps) are cut into K slices until
 // about kSplitTarget workgroups exist
 constexpr int kSplitTiles = 128, kSplitTarget = 384;  // (384 / 512 measured: B=32 equal, hourglass B=1 latency +7 %)
-int g_dbg = 0;  // cp_set_debug (A/B switches for tests and tuning): 32 no head fusion, 64 no lowc kernels
+int g_dbg = 0;  // cp_set_debug (A/B switches for tests and tuning): 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel
 
 struct DeformW {
     ConvW offset;  // conv_offset_mask (27 -> 32 padded), shift = bias
@@ -223,19 +223,21 @@ struct Packer {
         return d;
     }
     // Pack several PyTorch-layout weights side by side along Cout (GRU gates) into one GEMM operand.
-    ConvW pack(const std::vector<std::string>& wnames, int cout_each, int cin, int kh, int kw, int cin_pad = 0) {
+    ConvW pack(const std::vector<std::string>& wnames, int cout_each, int cin, int kh, int kw, int cin_pad = 0,
+               int cout_pad_min = 0) {
         ConvW c;
         c.Cin = cin;
         c.CinP = cin_pad ? cin_pad : cin;
         c.Cout = cout_each * (int)wnames.size();
         c.CoutPad = (int)align_up(c.Cout, cp_conv_tile_n(c.Cout));
+        if (c.CoutPad < cout_pad_min) c.CoutPad = cout_pad_min;  // <= 16-wide heads: 32 columns for the f16x3 N tile
         c.KH = kh;
         c.KW = kw;
         c.K = kh * kw * c.CinP;
         c.Kpad = (int)align_up(c.K, 16);
         c.wp = dev_alloc((size_t)c.Kpad * c.CoutPad);
         if (!c.wp) return c;
-        const bool want16 = (c.CinP == cin) && (cin % 32 == 0) && cp_conv_tile_n(c.Cout) >= 32 && kh * kw <= 32;
+        const bool want16 = (c.CinP == cin) && (cin % 32 == 0) && c.CoutPad >= 32 && c.CoutPad % 32 == 0 && kh * kw <= 32;
         if (want16) {
             c.Kpad16 = c.K;
             const size_t halfs = (size_t)c.CoutPad * c.Kpad16;
@@ -447,7 +449,7 @@ struct Packer {
             const std::string last = h.first + (m->gru ? ".3" : ".2");
             hw.c0 = pack({h.first + ".0.weight"}, hc, 64, 3, 3);
             if (const auto* b = get(h.first + ".0.bias", hc)) set_affine(hw.c0, nullptr, *b);
-            hw.c1 = pack({last + ".weight"}, h.second, hc, 1, 1);
+            hw.c1 = pack({last + ".weight"}, h.second, hc, 1, 1, 0, m->gru ? 32 : 0);
             if (const auto* b = get(last + ".bias", h.second)) set_affine(hw.c1, nullptr, *b);
             if (!m->gru && hc % 128 == 0 && h.second <= 32 && hw.c0.w16_hi) {
                 // conv3x3 -> ReLU -> conv1x1 head: keep the 1x1 weights as MFMA fragments for the fused kernel too
@@ -483,6 +485,8 @@ struct Fwd {
     // GroupNorm fusion hooks for the next conv() call (reset after use)
     double* gn_stats_out = nullptr;
     const float* gn_in_mr = nullptr;
+    const float* gn_in_a = nullptr;  // f16x3 form of the same fusion: per (image, channel) a, d planes
+    const float* gn_in_d = nullptr;
     const float* gn_in_gamma = nullptr;
     const float* gn_in_beta = nullptr;
 
@@ -626,6 +630,10 @@ struct Fwd {
         p.gn_stats = gn_stats_out;
         p.gn_groups = 32;
         p.gn_cpg = w.Cout / 32 > 0 ? w.Cout / 32 : 1;
+        if (gn_in_a) {
+            p.gn_in_a = gn_in_a;
+            p.gn_in_d = gn_in_d;
+        }
         if (gn_in_mr) {
             p.gn_in_mr = gn_in_mr;
             p.gn_in_gamma = gn_in_gamma;
@@ -636,6 +644,10 @@ struct Fwd {
         p.w16_lo = w.w16_lo;
         p.Kpad16 = w.Kpad16;
         const bool use16 = m->precision == CP_PREC_F16X3 && cp_conv16_supported(p);
+        if (p.gn_in_a && !use16) {  // the per-channel affine form only exists in the f16x3 1x1 kernel
+            chk(fail(CP_ERR_INVALID, "conv: GroupNorm affine input without an f16x3 kernel"));
+            return Tensor();
+        }
         Tensor out;
         if (out_nchw) {
             p.out = out_nchw;
@@ -702,6 +714,8 @@ struct Fwd {
         }
         gn_stats_out = nullptr;
         gn_in_mr = nullptr;
+        gn_in_a = nullptr;
+        gn_in_d = nullptr;
         return out;
     }
     const ConvW& cw(const std::string& k) { return m->convs.at(k); }
@@ -987,7 +1001,7 @@ struct Fwd {
                 if (r < 0) continue;  // the reference leaves such heads out of z (:545-563)
                 src = &gru_out[r];
             }
-            Tensor stats, mr;
+            Tensor stats, mr, ad;
             const bool fuse_gn = m->gru && ((src->H * src->W) % 32 == 0) && hw.c0.Cout % 32 == 0 && (hw.c0.Cout / 32) % 4 == 0;
             if (m->gru) {
                 // GroupNorm statistics: 32 groups x (sum, sumsq) doubles per image = 128 floats per image
@@ -1008,7 +1022,20 @@ struct Fwd {
             if (m->gru) {
                 if (fuse_gn) {
                     // statistics came out of the conv epilogue; normalise + affine + ReLU happens in the 1x1 loader
-                    if (!m->dry) {
+                    const bool affine16 = m->precision == CP_PREC_F16X3 && hw.c1.w16_hi && (hid.H * hid.W) % 128 == 0 &&
+                                          !(g_dbg & 128);
+                    if (affine16) {
+                        // f16x3 1x1 kernel: the normalisation pre-folded to y = relu(a*x + d) per (image, channel)
+                        ad = make(2 * hid.C, 1, 1);
+                        if (!m->dry) {
+                            float* ap = ad.ptr();
+                            float* dp = ap + (size_t)B * hid.C;
+                            chk(cp_launch_gn_affine((const double*)stats.ptr(), hw.gn_gamma, hw.gn_beta, ap, dp, B, hid.C, 32,
+                                                    (double)hid.H * hid.W * (hid.C / 32), 1e-5f, s));
+                            gn_in_a = ap;
+                            gn_in_d = dp;
+                        }
+                    } else if (!m->dry) {
                         chk(cp_launch_gn_finalize((const double*)stats.ptr(), mr.ptr(), B * 32,
                                                   (double)hid.H * hid.W * (hid.C / 32), 1e-5f, s));
                         gn_in_mr = mr.ptr();

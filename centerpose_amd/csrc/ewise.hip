@@ -260,6 +260,21 @@ __global__ void gn_finalize_kernel(const double* __restrict__ stats, float* __re
     mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+__global__ void gn_affine_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float* __restrict__ a, float* __restrict__ d, int B, int C,
+                                 int groups, double count, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C, g = c / (C / groups);
+    const double mean = stats[2 * (b * groups + g)] / count;
+    double var = stats[2 * (b * groups + g) + 1] / count - mean * mean;
+    if (var < 0) var = 0;
+    const float mu = (float)mean, rs = (float)(1.0 / sqrt(var + (double)eps));
+    const float av = rs * gamma[c];
+    a[i] = av;
+    d[i] = beta[c] - mu * av;
+}
+
 // BaseDetector.pre_process on device (base_detector.py:127-134): warpAffine(INTER_LINEAR, constant 0 border) of an
 // 8-bit HWC BGR frame to the network input size, then (x / 255 - mean) / std, written NCHW float32.  `minv` maps
 // output pixel (x, y) to source coordinates (the inverse of trans_input).  Float bilinear weights (cv2 uses 5-bit
@@ -389,6 +404,14 @@ int cp_launch_pack_weight(const float* w, float* wp, int Cout, int Cin, int taps
                           hipStream_t s) {
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((size_t)Cout * Cin * taps)), dim3(TPB), 0, s, w, wp, Cout, Cin,
                        taps, CinP, CoutPad, coff);
+    return check();
+}
+
+int cp_launch_gn_affine(const double* stats, const float* gamma, const float* beta, float* a, float* d, int B, int C,
+                        int groups, double count, float eps, hipStream_t s) {
+    if (C % groups) return CP_ERR_INVALID;
+    hipLaunchKernelGGL(gn_affine_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, stats, gamma, beta, a, d, B, C, groups,
+                       count, eps);
     return check();
 }
 

@@ -63,7 +63,6 @@ __global__ __launch_bounds__(NTHREADS, 3) void igemm_kernel(const ConvParams p, 
     const int tn = tile % tiles_n, tm = tile / tiles_n;
 
     const int M = p.B * p.Ho * p.Wo;
-    const int HWo = p.Ho * p.Wo;
 
     // ---- per-thread A-slot geometry (fixed over the K loop) ----
     PixelDecomp pdec;
@@ -327,7 +326,9 @@ int launch_a(const ConvParams& p, hipStream_t stream) {
     constexpr int BM = FRAG * MT * WM, BN = FRAG * NT * WN;
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = (M + BM - 1) / BM;
-    const int tiles_n = p.CoutPad / BN;
+    // N tiles that hold real output columns (weights may be padded wider than this kernel's N tile, e.g. the <= 16-wide
+    // final heads are packed to 32 columns for the f16x3 kernel: the all-padding tile is not launched)
+    const int tiles_n = (p.Cout + BN - 1) / BN;
     if (p.CoutPad % BN != 0 || p.Kpad % BK != 0) return CP_ERR_INVALID;
     hipLaunchKernelGGL((igemm_kernel<FRAG, MT, NT, WM, WN, DCN, ALIGNED, MULTISRC>),
                        dim3(tiles_m * tiles_n, p.splitk > 1 ? p.splitk : 1), dim3(NTHREADS), 0, stream, p, tiles_m, tiles_n);
@@ -386,10 +387,11 @@ const char* cp_conv_variant_name(int v) {
 }
 
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk) {
-    const int bn = cp_conv_tile_n(p.Cout);
+    int bn = cp_conv_tile_n(p.Cout);
+    if (f16x3 && bn < 32) bn = 32;
     const int bm = f16x3 ? 128 : (bn <= 32 ? 256 : 128);
     const int M = p.B * p.Ho * p.Wo;
-    *tiles = ((M + bm - 1) / bm) * (p.CoutPad / bn);
+    *tiles = ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn);
     *nk = f16x3 ? p.Kpad16 / 32 : p.Kpad / BK;
 }
 

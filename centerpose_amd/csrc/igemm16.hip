@@ -431,7 +431,9 @@ __device__ unsigned long long g_cp_clk[2];  // shader-clock / 100 MHz-clock tick
 // registers and multiplied by the 1x1 weights (A operand, pre-packed in the matching channel order) into a
 // [32 final channels][pixels] accumulator -- no LDS transpose, no hidden tensor in HBM.  The two waves of a pixel
 // range (hidden-channel halves) are summed through LDS, the N-tiles of the hidden dimension through fuse_out slices.
-template <int MT, int NT, int WM, int WN, bool MULTISRC, bool FUSE = false>
+// GNIN (1x1 layers whose input is a GroupNorm'd tensor, dlav1 heads): the A loader applies the pre-folded
+// normalisation + ReLU y = max(a*x + d, 0) (a, d per image and channel) before the hi/lo split; an output tile lies in one image.
+template <int MT, int NT, int WM, int WN, bool MULTISRC, bool FUSE = false, bool GNIN = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     static_assert(!FUSE || (MT == 2 && NT == 2 && WM == 2 && WN == 2 && !MULTISRC), "fused head: 128x128 tiles");
     typedef Frag<32> F;
@@ -522,7 +524,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
     int tiles_left = n;  // tiles not yet issued; past the end every load goes out of range
 
     // ---- loader pieces: A slot j / B slot j of the tile the K walk points at, then the walk step ----
+    float4 gn_a4 = make_float4(1.f, 1.f, 1.f, 1.f), gn_d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int gn_b = GNIN ? (tm * BM) / (p.Ho * p.Wo) : 0;  // the tile's image (the launcher guarantees Ho*Wo % BM == 0)
     auto issue_a = [&](float4(&ga)[A_SLOTS], int j) {
+        if (GNIN && j == 0) {  // affine of the 4 channels this lane converts, for the K tile being issued
+            const int c = (tiles_left > 0 ? u_cs : 0) + k4 * 4;
+            gn_a4 = *reinterpret_cast<const float4*>(p.gn_in_a + (size_t)gn_b * p.Cin + c);
+            gn_d4 = *reinterpret_cast<const float4*>(p.gn_in_d + (size_t)gn_b * p.Cin + c);
+        }
         __amdgpu_buffer_rsrc_t rs = r_s0;
         int sc = p.src_c[0];
         if (MULTISRC) {
@@ -574,8 +583,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
         _Float16* Al = Ah + A_SZ;
         const int row = (tid >> 3) + j * RPP;
         const int col = ((((k4 >> 1) ^ swz(row)) << 1) | (k4 & 1)) * 4;
-        if (q == 0) cs0[j] = split2(ga[j].x, ga[j].y);
-        else if (q == 1) cs1[j] = split2(ga[j].z, ga[j].w);
+        if (q == 0) {
+            float x = ga[j].x, y = ga[j].y;
+            if (GNIN) { x = fmaxf(fmaf(x, gn_a4.x, gn_d4.x), 0.f); y = fmaxf(fmaf(y, gn_a4.y, gn_d4.y), 0.f); }
+            cs0[j] = split2(x, y);
+        } else if (q == 1) {
+            float z = ga[j].z, w = ga[j].w;
+            if (GNIN) { z = fmaxf(fmaf(z, gn_a4.z, gn_d4.z), 0.f); w = fmaxf(fmaf(w, gn_a4.w, gn_d4.w), 0.f); }
+            cs1[j] = split2(z, w);
+        }
         else if (q == 2) *reinterpret_cast<u32x2*>(Ah + row * LDH + col) = u32x2{cs0[j].hi, cs1[j].hi};
         else *reinterpret_cast<u32x2*>(Al + row * LDH + col) = u32x2{cs0[j].lo, cs1[j].lo};
     };
@@ -864,12 +880,25 @@ __global__ void pack_weight16_kernel(const float* __restrict__ w, _Float16* __re
 
 }  // namespace
 
+// N tile of the f16x3 launch: cp_conv_tile_n, except that <= 16-wide outputs whose weights were packed to 32 columns
+// (the GroupNorm'd final 1x1 heads) take the 32-wide tile
+static int conv16_tile_n(const ConvParams& p) {
+    const int bn = cp_conv_tile_n(p.Cout);
+    return (bn < 32 && p.CoutPad >= 32 && p.CoutPad % 32 == 0) ? 32 : bn;
+}
+
 bool cp_conv16_supported(const ConvParams& p) {
     if (!p.w16_hi || !p.w16_lo || p.Cin % BK16 != 0 || p.KH * p.KW > 32) return false;
     for (int s = 0; s < p.nsrc; ++s)
         if (p.src_c[s] % BK16 != 0) return false;
-    const int bn = cp_conv_tile_n(p.Cout);
+    const int bn = conv16_tile_n(p);
     if (bn < 32) return false;
+    if (p.gn_in_mr) return false;  // the per-group form belongs to the exact-f32 loader
+    if (p.gn_in_a || p.gn_in_d) {
+        if (!p.gn_in_a || !p.gn_in_d || bn != 32 || p.KH != 1 || p.KW != 1 || p.pad != 0 || p.stride != 1 || p.nsrc != 1 ||
+            p.offmask || (p.Ho * p.Wo) % 128 != 0)
+            return false;
+    }
     if (p.offmask && bn < 64) return false;
     // 32-bit byte offsets of the buffer loads
     for (int s = 0; s < p.nsrc; ++s)
@@ -880,8 +909,15 @@ bool cp_conv16_supported(const ConvParams& p) {
 
 int cp_launch_conv16(const ConvParams& p, hipStream_t stream) {
     if (!cp_conv16_supported(p)) return CP_ERR_INVALID;
-    const int bn = cp_conv_tile_n(p.Cout);
+    const int bn = conv16_tile_n(p);
     const bool cat = p.nsrc > 1;
+    if (p.gn_in_a) {
+        const int M = p.B * p.Ho * p.Wo;
+        const int tiles_m = (M + 127) / 128, tiles_n = p.CoutPad / 32;
+        hipLaunchKernelGGL((igemm16p_kernel<1, 1, 4, 1, false, false, true>),
+                           dim3(tiles_m * tiles_n, p.splitk > 1 ? p.splitk : 1), dim3(NT16), 0, stream, p, tiles_m, tiles_n);
+        return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+    }
     if (p.offmask) {
         if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.nsrc != 1 || p.H != p.Ho || p.W != p.Wo)
             return CP_ERR_INVALID;
@@ -894,7 +930,7 @@ int cp_launch_conv16(const ConvParams& p, hipStream_t stream) {
 
 // kernel-variant ids continue after the exact-f32 ones (cp_conv_variant): 14.. = split-f16 instantiations
 int cp_conv16_variant(const ConvParams& p) {
-    const int bn = cp_conv_tile_n(p.Cout);
+    const int bn = conv16_tile_n(p);
     if (p.offmask) return bn == 128 ? 18 : 17;
     const int t = bn == 32 ? 0 : bn == 64 ? 1 : 2;
     return (p.nsrc > 1 ? 19 : 14) + t;
