@@ -71,6 +71,11 @@ struct ConvParams {
     // planes [B][Cin] each (cp_launch_gn_affine)
     const float* gn_in_a;
     const float* gn_in_d;
+    // fused ConvGRU step (convGRU.py:32-39) on the hidden-side 3x3 convolution: weights packed so that an N tile of 96
+    // holds [r | z | n] of the same 32 channels; the epilogue reads gru_x3 ([M,192] = input-side pre-activations) and
+    // gru_hprev ([M,64]) and writes h' = (1-z)*n + z*h into out ([M,64]).  The [M,192] hidden-side tensor never exists.
+    const float* gru_x3;
+    const float* gru_hprev;
     // deterministic split-K (few output tiles, long K: low-resolution layers at small batch): blockIdx.y = K slice,
     // raw accumulators go to partial[slice][M][CoutPad]; cp_launch_splitk_epilogue sums the slices in order and
     // applies the usual epilogue.
@@ -97,7 +102,8 @@ int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream);
 // K steps (of 16 for the f32 kernels, 32 for f16x3) and output tiles of the launch cp_launch_conv[16] would make
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 26
+#define CP_NUM_CONV_VARIANTS 27
+#define CP_VARIANT_GRU 26
 // split-f16 ("f16x3") implicit GEMM (igemm16.hip)
 bool cp_conv16_supported(const ConvParams& p);
 int cp_launch_conv16(const ConvParams& p, hipStream_t stream);
@@ -111,6 +117,7 @@ int cp_launch_conv16_fused_head(const ConvParams& p, hipStream_t stream);
 int cp_launch_pack_head_w2(const float* w1, void* hi, void* lo, int C2, int Chid, hipStream_t s);
 int cp_launch_head_reduce(const float* slabs, const float* bias, float* out_nchw, int slices, int C2, int B, int HW,
                           int sigmoid, hipStream_t s);
+int cp_launch_conv16_gru(const ConvParams& p, hipStream_t stream);
 #define CP_VARIANT_FUSED_HEAD 22
 // direct low-channel convolutions of the network's first three layers in f16x3 mode (lowc.hip).
 // kind: 0 stem 7x7 (NCHW input, `planes` <= 4) -> 16; 1 level0 3x3 16->16; 2 level1 3x3 stride 2 16->32

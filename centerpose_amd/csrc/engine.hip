@@ -117,7 +117,7 @@ int g_default_precision = CP_PREC_F32;
 // split-K policy: launches with fewer output tiles than kSplitTiles (and >= 8 K steps) are cut into K slices until
 // about kSplitTarget workgroups exist
 constexpr int kSplitTiles = 128, kSplitTarget = 384;  // (384 / 512 measured: B=32 equal, hourglass B=1 latency +7 %)
-int g_dbg = 0;  // cp_set_debug (A/B switches for tests and tuning): 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel
+int g_dbg = 0;  // cp_set_debug (A/B switches for tests and tuning): 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel, 256 unfused ConvGRU step
 
 struct DeformW {
     ConvW offset;  // conv_offset_mask (27 -> 32 padded), shift = bias
@@ -149,6 +149,8 @@ struct cp_model {
     std::vector<HeadW> headw;
     std::map<std::string, std::pair<void*, void*>> lowc;  // hi / lo weight fragments of the lowc.hip layers
     ConvW gru_x, gru_h;
+    void* gru_h16_hi = nullptr;  // hidden-side GRU weights re-ordered [tile][r|z|n][32] for the fused-gate kernel
+    void* gru_h16_lo = nullptr;
     std::vector<void*> device_allocs;
     Arena arena;
     // forward-call state
@@ -440,6 +442,24 @@ struct Packer {
             }
             if (b.size() == 192) set_affine(m->gru_x, nullptr, b);
             m->gru_h = pack({c + "Whr.weight", c + "Whz.weight", c + "Whn.weight"}, 64, 64, 3, 3);
+            {   // the same weights in the fused-gate order: N tile t (96 wide) = [r | z | n] of channels 32t .. 32t+31
+                const size_t halfs = (size_t)192 * 576;
+                m->gru_h16_hi = dev_alloc(halfs / 2);
+                m->gru_h16_lo = dev_alloc(halfs / 2);
+                const char* gates[3] = {"Whr", "Whz", "Whn"};
+                for (int g = 0; g < 3 && m->gru_h16_hi && m->gru_h16_lo; ++g) {
+                    const auto* w = get(c + gates[g] + ".weight", (size_t)64 * 64 * 9);
+                    if (!w) break;
+                    float* tmp = upload(*w);
+                    if (!tmp) break;
+                    for (int t = 0; t < 2; ++t) {
+                        const int rc = cp_launch_pack_weight16(tmp + (size_t)32 * t * 64 * 9, m->gru_h16_hi, m->gru_h16_lo, 32,
+                                                               64, 9, 576, t * 96 + g * 32, nullptr);
+                        if (rc != CP_OK) status = rc;
+                    }
+                    hip_ok(hipDeviceSynchronize());
+                }
+            }
         }
         const int hc = m->head_conv;
         for (auto& h : m->heads) {
@@ -972,6 +992,42 @@ struct Fwd {
                 if (st == 0) {
                     // h0 = 0: the three hidden-side convolutions are identically zero (convGRU.py:51,80-84)
                     if (!m->dry) chk(cp_launch_gru_gate(x3.ptr(), nullptr, nullptr, hn.ptr(), M, s));
+                } else if (m->precision == CP_PREC_F16X3 && m->gru_h16_hi && !(g_dbg & 256) &&
+                           (size_t)M * 192 * 4 < (size_t)0xf0000000u) {
+                    // hidden-side convolution with the gate arithmetic in its epilogue: h3 is never written
+                    if (!m->dry) {
+                        ConvParams p;
+                        std::memset(&p, 0, sizeof(p));
+                        p.nsrc = 1;
+                        p.src[0] = h.ptr();
+                        p.src_c[0] = 64;
+                        p.Cin = 64;
+                        p.B = B; p.H = feat.H; p.W = feat.W; p.Ho = feat.H; p.Wo = feat.W;
+                        p.KH = 3; p.KW = 3; p.stride = 1; p.pad = 1;
+                        p.K = 576; p.Kpad = 576; p.Kpad16 = 576;
+                        p.Cout = 192; p.CoutPad = 192;
+                        p.w16_hi = m->gru_h16_hi; p.w16_lo = m->gru_h16_lo;
+                        p.out = hn.ptr();
+                        p.gru_x3 = x3.ptr();
+                        p.gru_hprev = h.ptr();
+                        p.splitk = 1;
+                        auto launch = [&]() { return cp_launch_conv16_gru(p, s); };
+                        if (m->profile) {
+                            cp_model::ProfRec r;
+                            r.variant = CP_VARIANT_GRU;
+                            r.flops = 2.0 * (double)M * 192 * 576;
+                            r.bytes = 4.0 * ((double)M * (64 + 192 + 64 + 64) + 576.0 * 192);
+                            r.M = (int)M; r.N = 192; r.K = 576; r.kh = 3; r.stride = 1;
+                            r.e0 = m->get_event();
+                            r.e1 = m->get_event();
+                            (void)hipEventRecord(r.e0, s);
+                            chk(launch());
+                            (void)hipEventRecord(r.e1, s);
+                            m->prof.push_back(r);
+                        } else {
+                            chk(launch());
+                        }
+                    }
                 } else {
                     Tensor h3 = conv(m->gru_h, {&h}, 1, 1, CP_ACT_NONE);
                     if (!m->dry) chk(cp_launch_gru_gate(x3.ptr(), h3.ptr(), h.ptr(), hn.ptr(), M, s));

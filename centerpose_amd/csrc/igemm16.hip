@@ -433,9 +433,13 @@ __device__ unsigned long long g_cp_clk[2];  // shader-clock / 100 MHz-clock tick
 // range (hidden-channel halves) are summed through LDS, the N-tiles of the hidden dimension through fuse_out slices.
 // GNIN (1x1 layers whose input is a GroupNorm'd tensor, dlav1 heads): the A loader applies the pre-folded
 // normalisation + ReLU y = max(a*x + d, 0) (a, d per image and channel) before the hi/lo split; an output tile lies in one image.
-template <int MT, int NT, int WM, int WN, bool MULTISRC, bool FUSE = false, bool GNIN = false>
+// GRU (128x96 tiles: MT 1, NT 3, 4x1 waves): fused ConvGRU gate epilogue, see ConvParams::gru_x3.  Fragment j of a
+// wave's accumulators is gate j (r, z, n) of the same 32 channels, so a lane holds all three pre-activations of its
+// (pixel, channel) pairs and the gate arithmetic needs no exchange.
+template <int MT, int NT, int WM, int WN, bool MULTISRC, bool FUSE = false, bool GNIN = false, bool GRU = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     static_assert(!FUSE || (MT == 2 && NT == 2 && WM == 2 && WN == 2 && !MULTISRC), "fused head: 128x128 tiles");
+    static_assert(!GRU || (MT == 1 && NT == 3 && WM == 4 && WN == 1 && !MULTISRC && !FUSE), "GRU: 128x96 tiles");
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
@@ -800,6 +804,43 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
         (void)g;
         return;
     }
+    if constexpr (GRU) {
+        // r = sig(x_r + h_r); z = sig(x_z + h_z); n = tanh(x_n + r * h_n); h' = (1 - z) * n + z * h   (convGRU.py:32-39,
+        // the same float expressions as gru_gate_kernel)
+        const int mbase = __builtin_amdgcn_readfirstlane(tm * BM + wm * 32);
+        const int ch = tn * 32 + (lane & 31);
+        if (mbase + 32 <= M) {
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.gru_x3 + (size_t)mbase * 192, 32u * 192u * 4u);
+            const __amdgpu_buffer_rsrc_t rh = make_rsrc(p.gru_hprev + (size_t)mbase * 64, 32u * 64u * 4u);
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + (size_t)mbase * 64, 32u * 64u * 4u);
+            const int vx = (F::row(0, lane) * 192 + ch) * 4, vh = (F::row(0, lane) * 64 + ch) * 4;
+#pragma unroll
+            for (int r = 0; r < F::NACC; ++r) {
+                const int sx = F::row(r, 0) * 192 * 4, sh = F::row(r, 0) * 64 * 4;
+                const float xr = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx, sx, 0));
+                const float xz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx + 64 * 4, sx, 0));
+                const float xn = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx + 128 * 4, sx, 0));
+                const float hp = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rh, vh, sh, 0));
+                const float rg = 1.f / (1.f + expf(-(xr + acc[0][0][r])));
+                const float zg = 1.f / (1.f + expf(-(xz + acc[0][1][r])));
+                const float ng = tanhf(xn + rg * acc[0][2][r]);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((1.f - zg) * ng + zg * hp), ro, vh, sh, 0);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < F::NACC; ++r) {
+                const int m = mbase + F::row(r, lane);
+                if (m >= M) continue;
+                const float* x3 = p.gru_x3 + (size_t)m * 192 + ch;
+                const float hp = p.gru_hprev[(size_t)m * 64 + ch];
+                const float rg = 1.f / (1.f + expf(-(x3[0] + acc[0][0][r])));
+                const float zg = 1.f / (1.f + expf(-(x3[64] + acc[0][1][r])));
+                const float ng = tanhf(x3[128] + rg * acc[0][2][r]);
+                p.out[(size_t)m * 64 + ch] = (1.f - zg) * ng + zg * hp;
+            }
+        }
+        return;
+    }
     if (p.splitk > 1) igemm_store_partial<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane, blockIdx.y);
     else igemm_epilogue<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane);
 #if CP_EXP & 256
@@ -984,3 +1025,16 @@ extern "C" int cp_debug_read_clk(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cp_clk), sizeof(unsigned long long) * 2) == hipSuccess ? 0 : -1;
 }
 #endif
+
+// hidden-side ConvGRU convolution (64 -> [r|z|n] x 64, 3x3) with the gate arithmetic fused (ConvParams::gru_x3)
+int cp_launch_conv16_gru(const ConvParams& p, hipStream_t stream) {
+    if (!p.w16_hi || !p.w16_lo || !p.gru_x3 || !p.gru_hprev || !p.out || p.Cin != 64 || p.nsrc != 1 || p.src_c[0] != 64 ||
+        p.CoutPad != 192 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.Kpad16 != 576 || p.splitk > 1 ||
+        (size_t)p.B * p.H * p.W * 192 * 4 >= (size_t)0xf0000000u)
+        return CP_ERR_INVALID;
+    const int M = p.B * p.Ho * p.Wo;
+    const int tiles_m = (M + 127) / 128, tiles_n = 2;
+    hipLaunchKernelGGL((igemm16p_kernel<1, 3, 4, 1, false, false, false, true>), dim3(tiles_m * tiles_n), dim3(NT16), 0,
+                       stream, p, tiles_m, tiles_n);
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}
