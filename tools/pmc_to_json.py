@@ -19,10 +19,12 @@ def variant(kname):
         dcn, cat = m16.group(5) == "true", m16.group(6) == "true"
         pre = "dcn_igemm16" if dcn else "igemm16_cat" if cat else "igemm16"
         return "%s_f16x3_m%dn%d" % (pre, 32 * mt * wm, 32 * nt * wn)
-    mp = re.search(r"igemm16p_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", kname)
-    if mp:
+    mp = re.search(r"igemm16p_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)((?:, (?:true|false))*)>", kname)
+    if mp:  # <MT, NT, WM, WN, MULTISRC, FUSE[, GNIN[, GRU]]>
         mt, nt, wm, wn = (int(mp.group(i)) for i in range(1, 5))
-        pre = "igemm16_head" if mp.group(6) == "true" else "igemm16_cat" if mp.group(5) == "true" else "igemm16"
+        extra = [x.strip() == "true" for x in mp.group(7).split(",")[1:]] if mp.group(7) else []
+        gru = len(extra) > 1 and extra[1]
+        pre = "igemm16_gru" if gru else "igemm16_head" if mp.group(6) == "true" else "igemm16_cat" if mp.group(5) == "true" else "igemm16"
         return "%s_f16x3_m%dn%d" % (pre, 32 * mt * wm, 32 * nt * wn)
     ml = re.search(r"lowc_kernel<(\d+), (\d+), (\d+), ", kname)
     if ml:
