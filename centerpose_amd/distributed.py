@@ -73,3 +73,23 @@ def allgather_detections_ragged(det, counts_hint=None, group=None):
     pad[: det.shape[0]] = det
     full = allgather_detections(pad, group).view((world, m) + tuple(det.shape[1:]))
     return torch.cat([full[r, : ns[r]] for r in range(world)], 0)
+
+
+def allgather_detections_compact(det, thresh, score_index=4, group=None):
+    """Tracker bookkeeping only needs the detections that can start or continue a track: keep the records whose score
+    (field ``score_index`` of the 118-float record, hip.DET_FIELDS['scores']) exceeds ``thresh`` -- typically < 10 of
+    the K = 100 slots per image -- tag each with its global image index, and gather the ragged lists.
+    det: [b, K, F] on this rank, the same b on every rank.  Returns (records [n, F], image_index [n] int64), ordered
+    by rank, then image, then slot (the decode order), identical on every rank."""
+    b, K = det.shape[0], det.shape[1]
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    keep = det[..., score_index] > thresh
+    img = torch.arange(b, device=det.device, dtype=torch.int64).view(b, 1).expand(b, K) + rank * b
+    rec = det[keep]
+    idx = img[keep]
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return rec, idx
+    # one ragged gather: the image index rides along as an extra float64-exact column (indices < 2^24)
+    packed = torch.cat([rec, idx.to(rec.dtype).unsqueeze(1)], 1)
+    out = allgather_detections_ragged(packed, group=group)
+    return out[:, :-1].contiguous(), out[:, -1].to(torch.int64)

@@ -41,9 +41,16 @@ def _worker(rank, world, port, q):
     full = torch.arange(n_global * 4 * 118, dtype=torch.float32).view(n_global, 4, 118)
     got = d.allgather_detections_ragged(full[s:e].clone())
     ok2 = torch.equal(got, full)
+    # compact gather: only records above the score threshold travel, tagged with their global image index
+    g = torch.Generator().manual_seed(5)
+    full = torch.rand(4, 10, 118, generator=g)
+    mine = full[rank * 2:(rank + 1) * 2].clone()
+    rec, idx = d.allgather_detections_compact(mine, 0.7)
+    keep = full[..., 4] > 0.7
+    ok3 = torch.equal(rec, full[keep]) and torch.equal(idx, torch.arange(4).view(4, 1).expand(4, 10)[keep])
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
-    q.put((rank, ok1, ok2))
+    q.put((rank, ok1, ok2 and ok3))
 
 
 def test_allgather_detections_world2_gloo():
