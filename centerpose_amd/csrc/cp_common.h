@@ -187,6 +187,6 @@ int cp_launch_preprocess(const unsigned char* img, int H, int W, const float* mi
                          const float* std3, float* out, int OH, int OW, hipStream_t s);
 
 // device post-process + soft-NMS (post.hip); record layout CP_POST_* in include/centerpose_hip.h
-int cp_launch_postprocess(const float* det, int B, int K, const double* meta, float vis_thresh, int nms,
+int cp_launch_postprocess(const float* det, int B, int K, const double* meta, double vis_thresh, int nms,
                           float div_scale, double* out, int* count, double* ws, hipStream_t s);
 int cp_launch_render_gaussians(const double* recs, int N, float* out, int C, int H, int W, hipStream_t s);

@@ -1418,7 +1418,7 @@ size_t cp_postprocess_workspace_bytes(int B, int K) {
     return B > 0 && K > 0 ? (size_t)B * K * CP_POST_STRIDE * sizeof(double) : 0;
 }
 
-int cp_postprocess(cp_stream_t stream, const float* det, int B, int K, const double* meta, float vis_thresh, int nms,
+int cp_postprocess(cp_stream_t stream, const float* det, int B, int K, const double* meta, double vis_thresh, int nms,
                    float div_scale, double* out, int* count, void* workspace, size_t workspace_bytes) {
     if (!det || !meta || !out || !count || !workspace || B < 1) return fail(CP_ERR_INVALID, "bad argument");
     if (K < 1 || K > 128) return fail(CP_ERR_INVALID, "K must be in [1, 128]");

@@ -35,7 +35,7 @@ __device__ __forceinline__ void xform(const double* t, float x, float y, double*
 }
 
 __global__ __launch_bounds__(64) void postprocess_kernel(const float* __restrict__ det, int K,
-                                                         const double* __restrict__ meta, float vis_thresh, int nms,
+                                                         const double* __restrict__ meta, double vis_thresh, int nms,
                                                          float div_scale, double* __restrict__ out,
                                                          int* __restrict__ count, double* __restrict__ ws) {
     __shared__ double s_score[MAXK];
@@ -90,14 +90,14 @@ __global__ __launch_bounds__(64) void postprocess_kernel(const float* __restrict
     if (lane == 0) {
         int N = 0;
         for (int k = 0; k < K; ++k)
-            if (s_score[k] > (double)vis_thresh) {
+            if (s_score[k] > vis_thresh) {
                 s_score[N] = s_score[k];
                 for (int i = 0; i < 4; ++i) s_box[N][i] = s_box[k][i];
                 s_idx[N] = k;
                 ++N;
             }
         if (nms) {
-            const double sigma = 0.5, threshold = (double)vis_thresh;
+            const double sigma = 0.5, threshold = vis_thresh;
             for (int i = 0; i < N; ++i) {
                 double maxscore = s_score[i];
                 int maxpos = i;
@@ -181,7 +181,7 @@ int cp_launch_render_gaussians(const double* recs, int N, float* out, int C, int
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
-int cp_launch_postprocess(const float* det, int B, int K, const double* meta, float vis_thresh, int nms,
+int cp_launch_postprocess(const float* det, int B, int K, const double* meta, double vis_thresh, int nms,
                           float div_scale, double* out, int* count, double* ws, hipStream_t s) {
     if (K < 1 || K > MAXK) return CP_ERR_INVALID;
     hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(64), 0, s, det, K, meta, vis_thresh, nms, div_scale, out,

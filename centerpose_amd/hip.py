@@ -65,7 +65,7 @@ def lib():
     _sig(L.cp_set_debug, c_int, c_int)
     _sig(L.cp_render_gaussians, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int)
     _sig(L.cp_postprocess_workspace_bytes, c_size_t, c_int, c_int)
-    _sig(L.cp_postprocess, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.c_float, c_int, ctypes.c_float,
+    _sig(L.cp_postprocess, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.c_double, c_int, ctypes.c_float,
          c_void_p, c_void_p, c_void_p, c_size_t)
     _sig(L.cp_preprocess, c_int, c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_float),
          ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_void_p, c_int, c_int)

@@ -194,12 +194,13 @@ int cp_preprocess(cp_stream_t stream, const unsigned char* image_hwc_bgr, int H,
  *        kps_displacement_std 8 | bbox 24 | ct 28 | kps 30 | tracking 46 | tracking_hp 48 | kps_displacement_mean 64 |
  *        kps_heatmap_mean 80 | kps_heatmap_std 96 | kps_heatmap_height 112.
  * count: DEVICE int32 [B].   nms: 0 = threshold filter only (opt.nms False), 1 = Gaussian soft-NMS.
+ * vis_thresh is a double because the reference compares float64 scores with the Python float opt.vis_thresh.
  * div_scale: the `scale` of multi-scale testing (object_pose.py:171-176), 1 for the demo configuration.
  * workspace: cp_postprocess_workspace_bytes(B, K) bytes.
  * ------------------------------------------------------------------------------------------ */
 #define CP_POST_STRIDE 120
 size_t cp_postprocess_workspace_bytes(int B, int K);
-int cp_postprocess(cp_stream_t stream, const float* det, int B, int K, const double* meta, float vis_thresh, int nms,
+int cp_postprocess(cp_stream_t stream, const float* det, int B, int K, const double* meta, double vis_thresh, int nms,
                    float div_scale, double* out, int* count, void* workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------
