@@ -154,6 +154,86 @@ def render_goldens():
     print("render_ref.npz: nonzero", int((hm > 0).sum()))
 
 
+class TrackOpt:
+    """What Tracker reads from opt (opts.py:242-300 defaults; filters on, PnP off: pnp needs cv2)."""
+    new_thresh = 0.3
+    max_age = 2
+    R = 20.0
+    kalman = True
+    scale_pool = True
+    use_pnp = False
+    show_axes = False
+    c = "cup"
+    conf_border = {"cup": [3, 9]}
+
+    def __init__(self, hungarian):
+        self.hungarian = hungarian
+
+
+def tracker_frames(seed=9, n_frames=5, n_obj=6):
+    """Seeded detection dicts of a short video: objects drift, one leaves at frame 2, one appears at frame 3, one
+    detection is weak (never starts a track)."""
+    rng = np.random.RandomState(seed)
+    base = rng.uniform(100, 400, (n_obj, 2))
+    vel = rng.uniform(-6, 6, (n_obj, 2))
+    size = rng.uniform(40, 90, n_obj)
+    frames = []
+    for f in range(n_frames):
+        dets = []
+        for o in range(n_obj):
+            if (o == 1 and f >= 2) or (o == 4 and f < 3):
+                continue
+            ct = base[o] + vel[o] * f + rng.randn(2) * 0.5
+            kps = ct[None, :] + rng.uniform(-0.5, 0.5, (8, 2)) * size[o]
+            dets.append({
+                "score": 0.2 if o == 5 else float(rng.uniform(0.5, 0.99)), "cls": 0,
+                "bbox": [ct[0] - size[o] / 2, ct[1] - size[o] / 2, ct[0] + size[o] / 2, ct[1] + size[o] / 2],
+                "ct": [float(ct[0]), float(ct[1])],
+                "tracking": (-vel[o] + rng.randn(2) * 0.3).astype(np.float32),
+                "tracking_hp": (np.tile(-vel[o], 8) + rng.randn(16) * 0.3).astype(np.float32),
+                "kps": kps.reshape(-1).astype(np.float32),
+                "kps_fusion_mean": kps.reshape(-1) + rng.randn(16) * 0.2,
+                "kps_fusion_std": rng.uniform(0.5, 3.0, 16),
+                "obj_scale": rng.uniform(0.5, 1.5, 3).astype(np.float32),
+                "obj_scale_uncertainty": rng.uniform(0.05, 0.3, 3).astype(np.float32),
+            })
+        frames.append(dets)
+    return frames
+
+
+def tracker_summary(tracks):
+    out = []
+    for t in tracks:
+        out.append({"tracking_id": int(t["tracking_id"]), "age": int(t["age"]), "active": int(t["active"]),
+                    "ct": [float(t["ct"][0]), float(t["ct"][1])],
+                    "kps_mean_kf": np.asarray(t["kps_mean_kf"], float).reshape(-1).tolist(),
+                    "kps_std_kf": [float(v) for v in t["kps_std_kf"]],
+                    "obj_scale_kf": np.asarray(t["obj_scale_kf"], float).tolist(),
+                    "obj_scale_uncertainty_kf": np.asarray(t["obj_scale_uncertainty_kf"], float).tolist()})
+    return out
+
+
+def run_tracker(cls, hungarian):
+    import copy
+
+    tr = cls(TrackOpt(hungarian))
+    tr.init_track({"id": 0})
+    res = []
+    for dets in tracker_frames():
+        tracks, _ = tr.step(copy.deepcopy(dets))
+        res.append(tracker_summary(tracks))
+    return res
+
+
+def tracker_goldens():
+    """Reference Tracker.step (utils/tracker.py:112-302) on the seeded video, greedy and Hungarian -> tracker_ref.json."""
+    ref = rh.reference_tracker()
+    out = {"greedy": run_tracker(ref, False), "hungarian": run_tracker(ref, True)}
+    with open(os.path.join(GOLD, "tracker_ref.json"), "w") as f:
+        json.dump(out, f)
+    print("tracker_ref.json: tracks per frame", [len(x) for x in out["greedy"]])
+
+
 OPTS_SCENARIOS = [
     [],
     ["--arch", "dlav1_34", "--c", "cup", "--rep_mode", "1"],
@@ -247,6 +327,7 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "decode_pose_uint8_rep0.npz"), **r)
     host_goldens()
     render_goldens()
+    tracker_goldens()
     opts_goldens()
     print("done ->", GOLD)
 

@@ -125,13 +125,36 @@ def install_host_shims():
     fake("progress.bar", Bar=object)
     fake("simplejson", dump=_json.dump, dumps=_json.dumps, load=_json.load)
     fake("pyrr", Quaternion=object)
+    # filterpy>=1.4.5 (requirements.txt:14) is absent: the reference tracker runs on this repo's restatement of its
+    # published KalmanFilter (centerpose_amd/lib/utils/kalman.py), so tracker goldens pin the TRACKER logic; the filter
+    # arithmetic itself is checked against the textbook equations in tests/test_host_mirror.py
+    from centerpose_amd.lib.utils.kalman import KalmanFilter as _KF
+
     fake("filterpy")
-    fake("filterpy.kalman", KalmanFilter=object)
+    fake("filterpy.kalman", KalmanFilter=_KF)
     fake("filterpy.common", Q_discrete_white_noise=None)
     fake("numba", jit=lambda *a, **k: (lambda f: f))
     import sklearn.utils  # noqa: F401
 
-    fake("sklearn.utils.linear_assignment_", linear_assignment=None)
+    def linear_assignment(cost):  # scikit-learn 0.22.2's API (removed in 0.23): [n, 2] array of (row, col) pairs
+        from scipy.optimize import linear_sum_assignment
+
+        r, c = linear_sum_assignment(cost)
+        return np.stack([r, c], 1)
+
+    fake("sklearn.utils.linear_assignment_", linear_assignment=linear_assignment)
+
+
+def reference_tracker():
+    """The reference's ``Tracker`` class (utils/tracker.py) under the host shims."""
+    setup()
+    install_host_shims()
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from lib.utils.tracker import Tracker
+    return Tracker
 
 
 def reference_host_modules():
