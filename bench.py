@@ -11,12 +11,18 @@ configs[2] instead (dla_34, batch 64, backbone + decode + batched PnP).
 One "step" = one batch through that chain, inputs resident in HBM before the timed region.
 Images shard by batch across ranks (weak scaling, no data-path collective: the chain is per-image).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel (the f32-MFMA implicit-GEMM convolution): algorithmic FLOPs of its
-                launches inside the timed region / their HIP-event durations, vs the 157.3 TFLOP/s
-                dense f32 matrix peak of gfx950 (MI355X_MICROARCH.md)
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline      dominant kernel: algorithmic FLOPs of its launches inside the timed region / their
+                HIP-event durations vs the dense matrix peak of gfx950 (MI355X_MICROARCH.md), plus the
+                figures BASELINE.json's north_star names: roofline.dcn (DCNv2 + offset convolutions
+                against SURVEY 8(d)'s 95.36 MB/img and the 8 TB/s HBM peak), roofline.conv1x1 (MFMA
+                rate of the 1x1 convolutions), roofline.decode (microseconds and GB/s against 0.66 MB/img)
+  configs2      BASELINE configs[2] (dla_34, batch 64, backbone + decode + batched PnP) timed in the
+                same run at N=1, with its own dcn / conv1x1 / decode figures
   cpu_baseline  the oracle (CPU restatement of the reference graph, oracle/) timed on this host's
-                cores on a bounded sample of the same workload
+                cores on a bounded sample of the same workload: 1 warm-up image excluded, median over
+                the timed images; "fair" (OpenMP im2col + torch CPU convolutions, all cores) is `value`,
+                "faithful" (the reference's scalar single-thread im2col, as shipped) rides beside it
 """
 import argparse
 import json
@@ -34,6 +40,10 @@ from centerpose_amd import hip, synth  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, dense f32 matrix
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense f16/bf16 matrix
+PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md, HBM3E
+DCN_MB_PER_IMG = 95.36  # sum over the 16 DCNv2 layers of (Cin + 27 + Cout) * HW * 4 + weights, 512x512
+DCN_GFLOP_PER_IMG = 14.19  # contraction of the 16 DCNv2 layers; + 4.65 for the conv_offset_mask convolutions
+DECODE_MB_PER_IMG = 0.66  # one read of hm + hm_hp, gathers, 47 KB of records
 GFLOP_PER_IMG = {"dlav1_34": 106.85, "dla_34": 85.11, "dla_34_track": 109.68,
                  "dlav1_34_track": 138.7, "hourglass": 603.7}  # BASELINE.md section 2, SURVEY 8(a) M9 / 8(f) N4
 # hourglass: 739.0 GFLOP/img for the reference module minus the 135.3 of the first stack's seven heads, which do not feed
@@ -55,6 +65,7 @@ def parse():
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
                     help="f32: exact float32 MFMA; f16x3: split-binary16 MFMA (float32-class accuracy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs2", action="store_true", help="skip the BASELINE configs[2] leg of the default run")
     ap.add_argument("--no-latency", action="store_true")
     return ap.parse_args()
 
@@ -92,15 +103,15 @@ class Pipeline(object):
         if self.workload in ("decode", "hourglass"):
             # backbone + sigmoid + decode in one library call (hipGraph replay when graph=True)
             return self.model.detect(x, K=100, rep_mode=1, fit_gaussian=False, balance=2.0, graph=graph)[1]
-        z = self.model(x, sigmoid_hm=True, **extra)
-        if self.track:
+        if self.workload == "full":
+            det = self.model.detect(x, K=100, rep_mode=1, fit_gaussian=False, balance=2.0, graph=graph)[1]
+        elif self.track:
+            z = self.model(x, sigmoid_hm=True, **extra)
             det = hip.decode_raw(z["hm"], z["hps"], z["wh"], z["hm_hp"], z["hps_uncertainty"], z["scale"],
                                  z["scale_uncertainty"], z["reg"], z["hp_offset"], z["tracking"], z["tracking_hp"],
                                  K=100, rep_mode=1, fit_gaussian=True, balance=2.0)
             # the tracker of every video needs all detections: one RCCL all-gather of the fixed-size records
             return cpd.allgather_detections(det)
-        det = hip.decode_raw(z["hm"], z["hps"], z["wh"], z["hm_hp"], None, z["scale"], None, z["reg"],
-                             z["hp_offset"], None, None, K=100, rep_mode=1, fit_gaussian=False, balance=2.0)
         if self.workload != "full":
             return det
         # PnP input assembly for rep_mode 1 (base_detector.py:558-566): per vertex (displacement, heat-map),
@@ -116,30 +127,121 @@ class Pipeline(object):
         return det, poses
 
 
-def cpu_baseline(workload, arch, budget_s=12.0, max_imgs=16):
-    """Oracle (CPU port of the reference graph) on a bounded sample of the same workload."""
+def cpu_baseline(workload, arch, budget_s=40.0, n_fair=10, n_faithful=3):
+    """Oracle (CPU port of the reference graph) on a bounded sample of the same workload: the first
+    image is a warm-up and is not counted, `value` is 1 / median seconds per image."""
     if workload in ("track", "track_gru", "hourglass"):
         return None
+    import statistics
+
     from oracle import backbone as ob
+    from oracle import dcn as odcn
     from oracle import decode as odec
 
     heads = synth.HEADS_POSE
     sd = synth.make_state_dict(arch, heads, False)
     cores = torch.get_num_threads()
-    n, t0 = 0, time.time()
-    while n < max_imgs and (time.time() - t0 < budget_s or n < 2):
-        x = synth.frames(1, seed=1000 + n)
-        z = ob.dlaseg_forward(sd, x, heads, arch=arch.split("_")[0])
+
+    def one(i, kind):
+        x = synth.frames(1, seed=1000 + i)
+        t1 = time.perf_counter()
+        z = ob.dlaseg_forward(sd, x, heads, arch=arch.split("_")[0], dcn_kind=kind)
         hm = torch.sigmoid(z["hm"]).numpy()
         hm_hp = torch.sigmoid(z["hm_hp"]).numpy()
         odec.object_pose_decode(hm, z["hps"].numpy(), wh=z["wh"].numpy(), obj_scale=z["scale"].numpy(),
                                 reg=z["reg"].numpy(), hm_hp=hm_hp, hp_offset=z["hp_offset"].numpy(), K=100,
                                 rep_mode=1)
-        n += 1
-    dt = time.time() - t0
-    return {"value": round(n / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d images of the same workload (oracle: %s forward with OpenMP im2col + torch CPU convs, "
-                      "numpy decode), %.1f s" % (n, arch, dt)}
+        return time.perf_counter() - t1
+
+    def leg(kind, n_max, n_min, budget):
+        one(0, kind)  # warm-up: page-in, thread pools, im2col scratch
+        ts, t0 = [], time.perf_counter()
+        while len(ts) < n_max and (len(ts) < n_min or time.perf_counter() - t0 < budget):
+            ts.append(one(1 + len(ts), kind))
+        return ts
+
+    fair = leg("port", n_fair, 5, budget_s)
+    med = statistics.median(fair)
+    out = {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": "%d images of the same workload after 1 warm-up image (oracle: %s forward with OpenMP im2col + "
+                     "torch CPU convolutions on %d threads, numpy decode), median %.3f s/img, min %.3f, max %.3f" % (
+                         len(fair), arch, cores, med, min(fair), max(fair))}
+    # faithful: the reference's CPU path as shipped -- scalar single-thread im2col (oracle/_ref, built from the
+    # reference's own source where that tree exists; otherwise this repo's C port pinned to one OpenMP thread)
+    kind = "reference" if odcn.have_reference() else "port"
+    if kind == "port":
+        try:
+            import ctypes
+
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
+        except OSError:
+            kind = None
+    if kind:
+        ff = leg(kind, n_faithful, 2, budget_s / 2)
+        fm = statistics.median(ff)
+        out["faithful"] = {"value": round(1.0 / fm, 4), "unit": "images/sec", "kind": kind,
+                           "sample": "%d images after 1 warm-up, scalar single-thread deformable im2col (%s) + torch CPU "
+                                     "convolutions, median %.3f s/img" % (
+                                         len(ff), "the reference's own dcn_v2_im2col_cpu.cpp" if kind == "reference"
+                                         else "C port, 1 OpenMP thread", fm)}
+    return out
+
+
+def timed_region(pipe, steps, warmup, barrier):
+    """W untimed steps, then exactly `steps` timed ones between barriers; per-launch HIP events on every 4th step."""
+    for _ in range(warmup):
+        pipe.step()
+    every = 4 if steps >= 8 else 1
+    sampled = 0
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        on = i % every == 0
+        pipe.model.profile(on)
+        sampled += int(on)
+        pipe.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    pipe.model.profile(False)
+    prof = pipe.model.profile_read()
+    roles = pipe.model.profile_roles()
+    return dt, prof, roles, sampled
+
+
+def north_star_figures(roles, sampled, batch, precision):
+    """roofline.dcn / conv1x1 / decode from the per-role event times (cp_model_profile_roles)."""
+    out = {}
+    per = lambda r: roles[r]["ms"] / sampled if r in roles else 0.0
+    t_main, t_off = per("dcn"), per("dcn_offset")
+    if t_main > 0:
+        t = t_main + t_off
+        gbps = DCN_MB_PER_IMG * batch / t  # MB / ms = GB/s
+        out["dcn"] = {"bound": "hbm", "ms_per_step": round(t, 3), "main_ms": round(t_main, 3), "offset_conv_ms": round(t_off, 3),
+                      "algorithmic_mb_per_img": DCN_MB_PER_IMG, "hbm_gbps": round(gbps, 1), "peak_gbps": PEAK_HBM_GBPS,
+                      "frac_hbm": round(gbps / PEAK_HBM_GBPS, 4),
+                      "main_only_hbm_gbps": round(DCN_MB_PER_IMG * batch / t_main, 1),
+                      "tflops": round((roles["dcn"]["flops"] + roles.get("dcn_offset", {"flops": 0})["flops"]) /
+                                      sampled / (t * 1e-3) / 1e12, 1),
+                      "main_only_tflops": round(roles["dcn"]["flops"] / sampled / (t_main * 1e-3) / 1e12, 1)}
+    peak = PEAK_F16_MFMA_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
+    for key, names in (("conv1x1", ("conv1x1", "head_final")),):
+        ms = sum(per(n) for n in names)
+        if ms > 0:
+            fl = sum(roles[n]["flops"] for n in names if n in roles) / sampled
+            by = sum(roles[n]["bytes"] for n in names if n in roles) / sampled
+            tf = fl / (ms * 1e-3) / 1e12
+            out[key] = {"bound": "mfma", "ms_per_step": round(ms, 3), "tflops": round(tf, 1), "peak_tflops": peak,
+                        "mfma_utilisation": round(tf / peak, 4),
+                        "issued_utilisation": round((3 if precision == "f16x3" else 1) * tf / peak, 4),
+                        "algorithmic_gbps": round(by / 1e6 / ms, 1),
+                        "launches_per_step": sum(roles[n]["launches"] for n in names if n in roles) // sampled}
+    if "decode" in roles:
+        us = per("decode") * 1e3
+        out["decode"] = {"bound": "hbm", "us_per_step": round(us, 1), "algorithmic_mb_per_img": DECODE_MB_PER_IMG,
+                         "hbm_gbps": round(DECODE_MB_PER_IMG * batch / (us * 1e-3), 1),
+                         "floor_us_at_hbm_peak": round(DECODE_MB_PER_IMG * batch / PEAK_HBM_GBPS * 1e3, 2)}
+    out["ms_per_step_by_role"] = {r: round(v["ms"] / sampled, 3) for r, v in roles.items()}
+    return out
 
 
 def main():
@@ -175,23 +277,7 @@ def main():
 
     side = torch.cuda.Stream(device=device)  # a non-default stream (hipGraph capture needs one)
     torch.cuda.set_stream(side)
-    for _ in range(args.warmup):
-        pipe.step()
-    # live per-launch HIP-event timing of the conv kernels (two events per launch, ~300 per step) costs ~4 % of a step,
-    # so it is armed on every 4th step of the timed region only; the roofline figures are averages over those launches
-    every = 4 if args.steps >= 8 else 1
-    sampled = 0
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        on = i % every == 0
-        pipe.model.profile(on)
-        sampled += int(on)
-        pipe.step()
-    barrier()
-    dt = time.perf_counter() - t0
-    pipe.model.profile(False)
-    prof = pipe.model.profile_read()
+    dt, prof, roles, sampled = timed_region(pipe, args.steps, args.warmup, barrier)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -224,6 +310,7 @@ def main():
                                              "launches_per_step": v["launches"] // sampled}
                                          for k, v in prof.items()},
                     "conv_ms_per_step": round(total_ms / sampled, 3)}
+            roof.update(north_star_figures(roles, sampled, batch, args.precision))
             tr = os.path.join(REPO, "profiles", "pmc_traffic.json")
             if os.path.exists(tr):
                 with open(tr) as f:
@@ -246,6 +333,24 @@ def main():
                 ts.append((time.perf_counter() - t1) * 1e3)
             ts.sort()
             lat = round(ts[len(ts) // 2], 3)
+        cfg2 = None
+        if world == 1 and args.workload == "decode" and not args.no_configs2:
+            # BASELINE configs[2] in the same run: dla_34, batch 64, backbone + decode + batched PnP
+            del pipe.model
+            torch.cuda.empty_cache()
+            p2 = Pipeline("full", 64, device, seed=317, precision=args.precision)
+            k2 = max(4, min(args.steps, 12))
+            dt2, prof2, roles2, sampled2 = timed_region(p2, k2, max(1, min(args.warmup, 2)), barrier)
+            n2, r2 = max(prof2.items(), key=lambda kv: kv[1]["ms"])
+            cfg2 = {"workload": "dla_34 512x512 batch=64, Objectron-shaped synthetic frames, backbone + sigmoid + decode + "
+                                "batched PnP (BASELINE configs[2])",
+                    "value": round(64 * k2 / dt2, 2), "unit": "images/sec", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 3),
+                    "whole_step_tflops": round(64 * k2 / dt2 * GFLOP_PER_IMG["dla_34"] / 1e3, 2),
+                    "dominant_kernel": {"kernel": n2, "tflops": round(r2["flops"] / (r2["ms"] * 1e-3) / 1e12, 1),
+                                        "avg_launch_us": round(r2["ms"] * 1e3 / r2["launches"], 2)}}
+            cfg2.update(north_star_figures(roles2, sampled2, 64, args.precision))
+            del p2
+            torch.cuda.empty_cache()
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.workload, pipe.arch)
@@ -269,7 +374,7 @@ def main():
                        "gflop_per_image": gf},
             "p50_frame_ms_batch1": lat,
             "whole_step_tflops": round(value * gf / 1e3 / world, 2),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "configs2": cfg2, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

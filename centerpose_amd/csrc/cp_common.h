@@ -29,6 +29,29 @@ enum CpStore : int {
 
 #define CP_MAX_SRC 4
 
+#ifdef __HIPCC__
+// ---- |max| tracking and power-of-two operand scaling for the split-f16 kernels (see ConvParams::in_amax) ----
+// amax bits -> (2^e, 2^-e) with amax * 2^e in [2^14, 2^15): e = 14 - floor(log2(amax)).  Exponents are clamped so that
+// both factors stay normal float32 numbers (amax = 0 or < 2^-111: 2^125; inf / NaN inputs stay inf / NaN).
+__device__ __forceinline__ void cp_amax_to_scale(unsigned amax_bits, float* fwd, float* inv) {
+    int e = (int)((amax_bits >> 23) & 0xffu);
+    e = e < 16 ? 16 : (e > 253 ? 253 : e);
+    *fwd = __uint_as_float((unsigned)(268 - e) << 23);
+    *inv = __uint_as_float((unsigned)(e - 14) << 23);
+}
+// wave-reduce a lane's local max|v| and fold it into the slot (float bits of non-negative numbers order like unsigned
+// integers).  The slot is read first: once a few waves have reported, almost every later one finds its maximum already
+// covered and issues no atomic.
+__device__ __forceinline__ void cp_amax_commit(unsigned* slot, float local) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local = fmaxf(local, __shfl_xor(local, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned b = __float_as_uint(local);
+        if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+    }
+}
+#endif
+
 // One implicit-GEMM convolution:  out[m, n] = act( (sum_k A[m,k] * Wp[k,n]) * scale[n] + shift[n] + res[m,n] )
 //   m = output pixel (b, ho, wo);  k = (tap, ci) with ci fastest;  n = output channel.
 // A is read on the fly from up to CP_MAX_SRC NHWC sources that form a virtual channel concat
@@ -90,6 +113,17 @@ struct ConvParams {
     const void* fuse_w2_lo;
     float* fuse_out;
     int fuse_c2;
+    // ---- range-safe split-f16 arithmetic (f16x3 kernels) ----
+    // Binary16 only has 5 exponent bits, so the hi/lo split is exact to 2^-21 only while the operand sits well inside
+    // the normal range.  Both operands are therefore pre-scaled by exact powers of two: weights per output channel at
+    // pack time (the inverse is folded into `scale`, which for f16x3 launches points at scale * 2^-e_w), activations per
+    // tensor at run time from the tensor's running |max| (in_amax: float bits of max|x| written by the producing
+    // kernel's epilogue into a 4-byte slot; several sources of a virtual concat share the largest).  The loader
+    // multiplies by 2^e_a before the split and the epilogue by 2^-e_a: every partial sum is scaled by the same power
+    // of two, so results are bit-identical to the unscaled arithmetic wherever that one was inside the normal range.
+    const unsigned* in_amax[CP_MAX_SRC];  // nullptr: operand used as is (scale 1)
+    unsigned* out_amax;                   // nullptr: the output's |max| is not tracked
+    const float* fuse_w2_inv;             // fused head: 2^-e of the 1x1 weights per final channel [32]
     int dbg;  // tuning ablations (tools/conv_bench.py --dbg): 1 skip A loads, 2 skip B loads, 4 skip LDS stores, 8 skip MFMA
     const float* offmask;  // DCN mode: NHWC [B,H,W,32] = 18 offsets (dh,dw interleaved per tap) + 9 masks (already sigmoided) + 5 pad
 };
@@ -108,13 +142,22 @@ const char* cp_conv_variant_name(int v);
 bool cp_conv16_supported(const ConvParams& p);
 int cp_launch_conv16(const ConvParams& p, hipStream_t stream);
 int cp_conv16_variant(const ConvParams& p);
+// `fwd` (may be nullptr = 1): per-output-channel power-of-two factor applied before the split, indexed [coff + co]
 int cp_launch_pack_weight16(const float* w, void* hi, void* lo, int Cout, int Cin, int taps, int Kpad16, int coff,
-                            hipStream_t s);
+                            const float* fwd, hipStream_t s);
+// per-output-channel power-of-two scale of a [Cout][per] weight: fwd[co] = 2^e with max|w[co,:]| * 2^e in [2^14, 2^15),
+// inv[co] = 2^-e (all-zero rows: 1)
+int cp_launch_weight_scale(const float* w, int Cout, int per, float* fwd, float* inv, hipStream_t s);
+// out[i] = (scale ? scale[i] : 1) * inv[i]
+int cp_launch_scale16(const float* scale, const float* inv, float* out, int n, hipStream_t s);
+// slot = max(slot, float bits of max|x[0..n)|)  (slot zeroed by the caller); n % 4 == 0, 16-byte aligned
+int cp_launch_absmax(const float* x, size_t n, unsigned* slot, hipStream_t s);
 // fused head (see ConvParams::fuse_*): is this 3x3 (+ReLU) -> 1x1 pair eligible; launch; 1x1 weight packing
 // (w1: [C2][Chid] float32 -> two arrays of Chid*32 binary16); slice reduction + bias (+ sigmoid) -> NCHW
 bool cp_head_fuse_supported(const ConvParams& p, int c2);
 int cp_launch_conv16_fused_head(const ConvParams& p, hipStream_t stream);
-int cp_launch_pack_head_w2(const float* w1, void* hi, void* lo, int C2, int Chid, hipStream_t s);
+// w2_inv: [32] floats, receives 2^-e per final channel (the packed rows are scaled by 2^e)
+int cp_launch_pack_head_w2(const float* w1, void* hi, void* lo, float* w2_inv, int C2, int Chid, hipStream_t s);
 int cp_launch_head_reduce(const float* slabs, const float* bias, float* out_nchw, int slices, int C2, int B, int HW,
                           int sigmoid, hipStream_t s);
 int cp_launch_conv16_gru(const ConvParams& p, hipStream_t stream);
@@ -122,9 +165,12 @@ int cp_launch_conv16_gru(const ConvParams& p, hipStream_t stream);
 // direct low-channel convolutions of the network's first three layers in f16x3 mode (lowc.hip).
 // kind: 0 stem 7x7 (NCHW input, `planes` <= 4) -> 16; 1 level0 3x3 16->16; 2 level1 3x3 stride 2 16->32
 size_t cp_lowc_weight_halfs(int kind);
-int cp_launch_pack_lowc(int kind, const float* w, void* hi, void* lo, int cin, hipStream_t s);
+// fwd: per-output-channel power-of-two weight pre-scale (cp_launch_weight_scale) or nullptr; `scale` of cp_launch_lowc
+// must then carry the inverse.  in_amax / out_amax: see ConvParams.
+int cp_launch_pack_lowc(int kind, const float* w, void* hi, void* lo, const float* fwd, int cin, hipStream_t s);
 int cp_launch_lowc(int kind, const float* in, float* out, const void* w_hi, const void* w_lo, const float* scale,
-                   const float* shift, int B, int H, int W, int planes, hipStream_t s);
+                   const float* shift, const unsigned* in_amax, unsigned* out_amax, int B, int H, int W, int planes,
+                   hipStream_t s);
 #define CP_VARIANT_LOWC0 23
 #define CP_PREC_F32 0
 #define CP_PREC_F16X3 1
@@ -133,23 +179,27 @@ int cp_launch_lowc(int kind, const float* in, float* out, const void* w_hi, cons
 int cp_launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, int Cpad, hipStream_t s);
 int cp_launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, int ldi, hipStream_t s);
 int cp_launch_maxpool2(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
+// the element-wise producers below take an optional |max| slot for their output (ConvParams::out_amax)
 // depth-wise ConvTranspose2d(k=2f, stride=f, pad=f/2) of `in` [B,H,W,C] plus `add` [B,fH,fW,C] -> out
 int cp_launch_upsample_add(const float* in, const float* w, const float* add, float* out, int B, int H, int W,
-                           int C, int f, hipStream_t s);
+                           int C, int f, unsigned* out_amax, hipStream_t s);
 int cp_launch_add_relu_sum(const float* a, const float* b, const float* c, const float* d, float* out, size_t n,
-                           hipStream_t s);
+                           unsigned* out_amax, hipStream_t s);
 // hourglass merge: out[B,2H,2W,C] = up1 + nearest-x2(low[B,H,W,C])  (large_hourglass.py:186-188)
 int cp_launch_upsample2_nearest_add(const float* up1, const float* low, float* out, int B, int H, int W, int C,
-                                    hipStream_t s);
+                                    unsigned* out_amax, hipStream_t s);
 // ConvGRU gates (convGRU.py:32-39).  x3/h3: [M,192] = (r,z,n) pre-activations, h: [M,64]
-int cp_launch_gru_gate(const float* x3, const float* h3, const float* hprev, float* hout, size_t M, hipStream_t s);
+int cp_launch_gru_gate(const float* x3, const float* h3, const float* hprev, float* hout, size_t M, unsigned* out_amax,
+                       hipStream_t s);
 // GroupNorm(32 groups) over NHWC [B, HW, C]: stats then in-place normalise + affine + ReLU
 int cp_launch_groupnorm_relu(float* x, const float* gamma, const float* beta, double* stats_ws, int B, int HW, int C,
-                             int groups, float eps, hipStream_t s);
+                             int groups, float eps, unsigned* out_amax, hipStream_t s);
 // (sum, sumsq) doubles -> (mean, rstd) floats per (image, group)
 // (sum, sum of squares) per (image, group) -> per (image, channel) affine a = rstd*gamma, d = beta - mean*rstd*gamma
+// x_amax / y_amax (optional): |max| slot of the un-normalised tensor, and the slot that receives the bound
+// max over (image, channel) of |a| * max|x| + |d| >= max|relu(a*x + d)| for the consumer's activation pre-scale
 int cp_launch_gn_affine(const double* stats, const float* gamma, const float* beta, float* a, float* d, int B, int C,
-                        int groups, double count, float eps, hipStream_t s);
+                        int groups, double count, float eps, const unsigned* x_amax, unsigned* y_amax, hipStream_t s);
 int cp_launch_gn_finalize(const double* stats, float* mr, int n, double count, float eps, hipStream_t s);
 // PyTorch [Cout][Cin][taps] weights -> packed GEMM operand (buffer must be pre-zeroed for padding)
 int cp_launch_pack_weight(const float* w, float* wp, int Cout, int Cin, int taps, int CinP, int CoutPad, int coff,

@@ -99,6 +99,7 @@ struct Block {
 struct Tensor {
     std::shared_ptr<Block> blk;
     int C = 0, H = 0, W = 0;
+    unsigned* amax = nullptr;  // 4-byte slot holding the float bits of max|x| (f16x3 mode; ConvParams::in_amax)
     float* ptr() const { return blk->a->base ? (float*)(blk->a->base + blk->off) : nullptr; }
     bool valid() const { return (bool)blk; }
 };
@@ -111,6 +112,17 @@ struct ConvW {
     void* w16_hi = nullptr;  // split-f16 copies [CoutPad][K] (only when every K-step of 32 stays inside one tap)
     void* w16_lo = nullptr;
     int Kpad16 = 0;
+    // per-output-channel power-of-two pre-scale of the split-f16 copies: rows are stored times wfwd[co] = 2^e,
+    // winv = 2^-e, scale16 = (scale or 1) * winv is what the f16x3 kernels' epilogue multiplies with
+    float* wfwd = nullptr;
+    float* winv = nullptr;
+    float* scale16 = nullptr;
+};
+
+struct LowcW {
+    void* hi = nullptr;
+    void* lo = nullptr;
+    float* scale16 = nullptr;  // folded BatchNorm scale x 2^-e of the fragment rows
 };
 
 int g_default_precision = CP_PREC_F32;
@@ -130,6 +142,7 @@ struct HeadW {
     ConvW c0, c1;
     void* w2_hi = nullptr;  // fused-head form of c1 (cp_launch_pack_head_w2); null when the pair is not eligible
     void* w2_lo = nullptr;
+    float* w2_inv = nullptr;  // [32] 2^-e per final channel (+ [32] 2^e used while packing)
     float* gn_gamma = nullptr;
     float* gn_beta = nullptr;
 };
@@ -147,10 +160,12 @@ struct cp_model {
     std::map<std::string, DeformW> deforms;
     std::map<std::string, float*> ups;
     std::vector<HeadW> headw;
-    std::map<std::string, std::pair<void*, void*>> lowc;  // hi / lo weight fragments of the lowc.hip layers
+    std::map<std::string, LowcW> lowc;  // hi / lo weight fragments of the lowc.hip layers
     ConvW gru_x, gru_h;
     void* gru_h16_hi = nullptr;  // hidden-side GRU weights re-ordered [tile][r|z|n][32] for the fused-gate kernel
     void* gru_h16_lo = nullptr;
+    float* gru_h16_fwd = nullptr;  // [192] per-row 2^e of the fused-order copies, and the matching 2^-e
+    float* gru_h16_inv = nullptr;
     std::vector<void*> device_allocs;
     Arena arena;
     // forward-call state
@@ -164,6 +179,7 @@ struct cp_model {
     // optional per-launch profiling of the implicit-GEMM kernels (HIP events on the launch stream)
     struct ProfRec {
         int variant;
+        int role = 0;  // CP_ROLE_*
         double flops, bytes;
         int M, N, K, kh, stride;
         hipEvent_t e0, e1;
@@ -171,6 +187,7 @@ struct cp_model {
     std::map<std::vector<uint64_t>, hipGraphExec_t> graphs;  // captured detect() launches, keyed by every argument
     bool profile = false;
     std::vector<ProfRec> prof;
+    double roles[CP_NUM_ROLES * 4] = {0};  // per-role totals of the last cp_model_profile_read
     std::vector<hipEvent_t> event_pool;
     hipEvent_t get_event() {
         if (!event_pool.empty()) {
@@ -245,6 +262,11 @@ struct Packer {
             const size_t halfs = (size_t)c.CoutPad * c.Kpad16;
             c.w16_hi = dev_alloc((halfs + 1) / 2);
             c.w16_lo = dev_alloc((halfs + 1) / 2);
+            const std::vector<float> ones(c.CoutPad, 1.f);
+            c.wfwd = upload(ones);
+            c.winv = upload(ones);
+            c.scale16 = upload(ones);
+            if (!c.w16_hi || !c.w16_lo || !c.wfwd || !c.winv || !c.scale16) return c;
         }
         for (size_t i = 0; i < wnames.size(); ++i) {
             const auto* w = get(wnames[i], (size_t)cout_each * cin * kh * kw);
@@ -257,11 +279,20 @@ struct Packer {
             hip_ok(hipMemcpy(tmp, w->data(), w->size() * sizeof(float), hipMemcpyHostToDevice));
             int rc = cp_launch_pack_weight(tmp, c.wp, cout_each, cin, kh * kw, c.CinP, c.CoutPad, (int)i * cout_each,
                                            nullptr);
-            if (rc == CP_OK && c.w16_hi && c.w16_lo)
-                rc = cp_launch_pack_weight16(tmp, c.w16_hi, c.w16_lo, cout_each, cin, kh * kw, c.Kpad16,
-                                             (int)i * cout_each, nullptr);
+            if (rc == CP_OK && c.w16_hi && c.w16_lo) {
+                const int coff = (int)i * cout_each;
+                rc = cp_launch_weight_scale(tmp, cout_each, cin * kh * kw, c.wfwd + coff, c.winv + coff, nullptr);
+                if (rc == CP_OK)
+                    rc = cp_launch_pack_weight16(tmp, c.w16_hi, c.w16_lo, cout_each, cin, kh * kw, c.Kpad16, coff, c.wfwd,
+                                                 nullptr);
+            }
             hip_ok(hipDeviceSynchronize());
             (void)hipFree(tmp);
+            if (rc != CP_OK) status = rc;
+        }
+        if (c.scale16 && status == CP_OK) {  // no affine yet: scale16 = winv (set_affine folds a scale in later)
+            const int rc = cp_launch_scale16(nullptr, c.winv, c.scale16, c.CoutPad, nullptr);
+            hip_ok(hipDeviceSynchronize());
             if (rc != CP_OK) status = rc;
         }
         return c;
@@ -275,6 +306,11 @@ struct Packer {
             std::vector<float> sc(c.CoutPad, 1.f);
             for (size_t i = 0; i < scale->size(); ++i) sc[i] = (*scale)[i];
             c.scale = upload(sc);
+            if (c.scale && c.scale16) {
+                const int rc = cp_launch_scale16(c.scale, c.winv, c.scale16, c.CoutPad, nullptr);
+                hip_ok(hipDeviceSynchronize());
+                if (rc != CP_OK) status = rc;
+            }
         }
     }
     // eval-mode BatchNorm folded to y = x*scale + shift; optional conv bias folded in as well
@@ -383,8 +419,9 @@ struct Packer {
                     float* tmp = upload(*w1);
                     hw.w2_hi = dev_alloc((size_t)256 * 32 / 2);
                     hw.w2_lo = dev_alloc((size_t)256 * 32 / 2);
-                    if (tmp && hw.w2_hi && hw.w2_lo) {
-                        const int rc = cp_launch_pack_head_w2(tmp, hw.w2_hi, hw.w2_lo, h.second, 256, nullptr);
+                    hw.w2_inv = dev_alloc(64);
+                    if (tmp && hw.w2_hi && hw.w2_lo && hw.w2_inv) {
+                        const int rc = cp_launch_pack_head_w2(tmp, hw.w2_hi, hw.w2_lo, hw.w2_inv, h.second, 256, nullptr);
                         hip_ok(hipDeviceSynchronize());
                         if (rc != CP_OK) status = rc;
                     }
@@ -402,21 +439,24 @@ struct Packer {
         const size_t halfs = cp_lowc_weight_halfs(kind);
         void* hi = dev_alloc(halfs / 2);
         void* lo = dev_alloc(halfs / 2);
-        if (!tmp || !hi || !lo) return;
-        const int rc = cp_launch_pack_lowc(kind, tmp, hi, lo, cin, nullptr);
+        float* fwd = dev_alloc(cout);
+        float* inv = dev_alloc(cout);
+        LowcW lw;
+        lw.hi = hi;
+        lw.lo = lo;
+        lw.scale16 = dev_alloc(cout);
+        if (!tmp || !hi || !lo || !fwd || !inv || !lw.scale16) return;
+        int rc = cp_launch_weight_scale(tmp, cout, cin * k * k, fwd, inv, nullptr);
+        if (rc == CP_OK) rc = cp_launch_pack_lowc(kind, tmp, hi, lo, fwd, cin, nullptr);
+        // the folded BatchNorm of the same layer lives in the ConvW packed under the same name (conv_bn ran first)
+        auto it = m->convs.find(name);
+        if (rc == CP_OK) rc = cp_launch_scale16(it != m->convs.end() ? it->second.scale : nullptr, inv, lw.scale16, cout, nullptr);
         hip_ok(hipDeviceSynchronize());
         if (rc != CP_OK) status = rc;
-        m->lowc[name] = {hi, lo};
+        m->lowc[name] = lw;
     }
     void run() {
         conv_bn("base.base_layer", "base.base_layer.0", "base.base_layer.1", 16, 3, 7, 4);
-        lowc("base.base_layer", "base.base_layer.0", 0, 16, 3, 7);
-        lowc("base.level0", "base.level0.0", 1, 16, 16, 3);
-        lowc("base.level1", "base.level1.0", 2, 32, 16, 3);
-        if (m->tracking) {
-            lowc("base.pre_img_layer", "base.pre_img_layer.0", 0, 16, 3, 7);
-            lowc("base.pre_hm_layer", "base.pre_hm_layer.0", 0, 16, 1, 7);
-        }
         if (m->tracking) {
             conv_bn("base.pre_img_layer", "base.pre_img_layer.0", "base.pre_img_layer.1", 16, 3, 7, 4);
             conv_bn("base.pre_hm_layer", "base.pre_hm_layer.0", "base.pre_hm_layer.1", 16, 1, 7, 4);
@@ -424,6 +464,14 @@ struct Packer {
         }
         conv_bn("base.level0", "base.level0.0", "base.level0.1", 16, 16, 3);
         conv_bn("base.level1", "base.level1.0", "base.level1.1", 32, 16, 3);
+        // f16x3 fragments of the same layers (after conv_bn: they take the folded BatchNorm from the ConvW)
+        lowc("base.base_layer", "base.base_layer.0", 0, 16, 3, 7);
+        lowc("base.level0", "base.level0.0", 1, 16, 16, 3);
+        lowc("base.level1", "base.level1.0", 2, 32, 16, 3);
+        if (m->tracking) {
+            lowc("base.pre_img_layer", "base.pre_img_layer.0", 0, 16, 3, 7);
+            lowc("base.pre_hm_layer", "base.pre_hm_layer.0", 0, 16, 1, 7);
+        }
         tree("base.level2", 1, 32, 64, false);
         tree("base.level3", 2, 64, 128, true);
         tree("base.level4", 2, 128, 256, true);
@@ -446,15 +494,21 @@ struct Packer {
                 const size_t halfs = (size_t)192 * 576;
                 m->gru_h16_hi = dev_alloc(halfs / 2);
                 m->gru_h16_lo = dev_alloc(halfs / 2);
+                m->gru_h16_fwd = dev_alloc(192);
+                m->gru_h16_inv = dev_alloc(192);
                 const char* gates[3] = {"Whr", "Whz", "Whn"};
-                for (int g = 0; g < 3 && m->gru_h16_hi && m->gru_h16_lo; ++g) {
+                for (int g = 0; g < 3 && m->gru_h16_hi && m->gru_h16_lo && m->gru_h16_fwd && m->gru_h16_inv; ++g) {
                     const auto* w = get(c + gates[g] + ".weight", (size_t)64 * 64 * 9);
                     if (!w) break;
                     float* tmp = upload(*w);
                     if (!tmp) break;
                     for (int t = 0; t < 2; ++t) {
-                        const int rc = cp_launch_pack_weight16(tmp + (size_t)32 * t * 64 * 9, m->gru_h16_hi, m->gru_h16_lo, 32,
-                                                               64, 9, 576, t * 96 + g * 32, nullptr);
+                        const int row = t * 96 + g * 32;
+                        int rc = cp_launch_weight_scale(tmp + (size_t)32 * t * 64 * 9, 32, 64 * 9, m->gru_h16_fwd + row,
+                                                        m->gru_h16_inv + row, nullptr);
+                        if (rc == CP_OK)
+                            rc = cp_launch_pack_weight16(tmp + (size_t)32 * t * 64 * 9, m->gru_h16_hi, m->gru_h16_lo, 32, 64, 9,
+                                                         576, row, m->gru_h16_fwd, nullptr);
                         if (rc != CP_OK) status = rc;
                     }
                     hip_ok(hipDeviceSynchronize());
@@ -477,8 +531,9 @@ struct Packer {
                     float* tmp = upload(*w1);
                     hw.w2_hi = dev_alloc((size_t)hc * 32 / 2);
                     hw.w2_lo = dev_alloc((size_t)hc * 32 / 2);
-                    if (tmp && hw.w2_hi && hw.w2_lo) {
-                        const int rc = cp_launch_pack_head_w2(tmp, hw.w2_hi, hw.w2_lo, h.second, hc, nullptr);
+                    hw.w2_inv = dev_alloc(64);
+                    if (tmp && hw.w2_hi && hw.w2_lo && hw.w2_inv) {
+                        const int rc = cp_launch_pack_head_w2(tmp, hw.w2_hi, hw.w2_lo, hw.w2_inv, h.second, hc, nullptr);
                         hip_ok(hipDeviceSynchronize());
                         if (rc != CP_OK) status = rc;
                     }
@@ -509,6 +564,34 @@ struct Fwd {
     const float* gn_in_d = nullptr;
     const float* gn_in_gamma = nullptr;
     const float* gn_in_beta = nullptr;
+    int role = -1;  // CP_ROLE_* of the next conv() call when the shape does not say it (heads, GRU); reset after use
+    const unsigned* gn_in_amax = nullptr;  // bound on max|relu(a*x + d)| for the GNIN loader's pre-scale
+    // |max| slots of this forward's tensors (f16x3 range-safe scaling, ConvParams::in_amax): one zeroed block at the
+    // start of the arena, a slot per Tensor in creation order
+    static constexpr int kMaxSlots = 4096;
+    Tensor slots_t;
+    unsigned* slots = nullptr;
+    int nslots = 0;
+    void init_slots() {
+        slots_t.blk = std::make_shared<Block>(&m->arena, (size_t)kMaxSlots * sizeof(unsigned));
+        if (m->dry || m->precision != CP_PREC_F16X3) return;
+        slots = (unsigned*)slots_t.ptr();
+        if (hipMemsetAsync(slots, 0, (size_t)kMaxSlots * sizeof(unsigned), s) != hipSuccess) chk(CP_ERR_LAUNCH);
+    }
+    unsigned* new_slot() {
+        if (!slots) return nullptr;
+        if (nslots >= kMaxSlots) {
+            chk(fail(CP_ERR_STATE, "out of |max| slots"));
+            return nullptr;
+        }
+        return slots + nslots++;
+    }
+    // |max| of a caller-owned input (network images): one extra read of the tensor
+    unsigned* input_slot(const float* x, size_t n) {
+        unsigned* sl = new_slot();
+        if (sl) chk(cp_launch_absmax(x, n, sl, s));
+        return sl;
+    }
 
     void chk(int rc) {
         if (rc != CP_OK && m->status == CP_OK) m->status = rc;
@@ -519,6 +602,7 @@ struct Fwd {
         t.H = H;
         t.W = W;
         t.blk = std::make_shared<Block>(&m->arena, (size_t)B * H * W * C * sizeof(float));
+        t.amax = new_slot();
         return t;
     }
     void tap(const char* name, const Tensor& t, int c_valid = 0) {
@@ -558,8 +642,10 @@ struct Fwd {
         p.wp = w.wp;
         p.Cout = w.Cout;
         p.CoutPad = w.CoutPad;
-        p.scale = w.scale;
+        p.scale = w.scale16;
         p.shift = w.shift;
+        p.in_amax[0] = x.amax;
+        p.fuse_w2_inv = hw.w2_inv;
         p.act = CP_ACT_RELU;
         p.w16_hi = w.w16_hi;
         p.w16_lo = w.w16_lo;
@@ -587,6 +673,7 @@ struct Fwd {
         if (m->profile) {
             cp_model::ProfRec r;
             r.variant = CP_VARIANT_FUSED_HEAD;
+            r.role = CP_ROLE_HEAD;
             const double M = (double)B * p.Ho * p.Wo;
             r.flops = 2.0 * M * w.Cout * (double)(w.KH * w.KW * w.Cin) + 2.0 * M * hw.classes * (double)w.Cout;
             // algorithmic bytes: input once + final maps once + both weight sets (the hidden tensor is not counted:
@@ -664,6 +751,11 @@ struct Fwd {
         p.w16_lo = w.w16_lo;
         p.Kpad16 = w.Kpad16;
         const bool use16 = m->precision == CP_PREC_F16X3 && cp_conv16_supported(p);
+        if (use16) {
+            p.scale = w.scale16;
+            for (int i = 0; i < p.nsrc; ++i) p.in_amax[i] = srcs[i]->amax;
+            if (p.gn_in_a) p.in_amax[0] = gn_in_amax;
+        }
         if (p.gn_in_a && !use16) {  // the per-channel affine form only exists in the f16x3 1x1 kernel
             chk(fail(CP_ERR_INVALID, "conv: GroupNorm affine input without an f16x3 kernel"));
             return Tensor();
@@ -679,6 +771,7 @@ struct Fwd {
             const int cstore = (act == CP_ACT_SIGMOID_FROM) ? w.CoutPad : w.Cout;
             out = make(cstore, p.Ho, p.Wo);
             p.out = out.ptr();
+            p.out_amax = act == CP_ACT_SIGMOID_FROM ? nullptr : out.amax;  // offset/mask maps are never a GEMM operand
             p.store = CP_STORE_NHWC;
             p.ldo = cstore;
             p.coff = 0;
@@ -714,6 +807,8 @@ struct Fwd {
             if (m->profile) {
                 cp_model::ProfRec r;
                 r.variant = use16 ? cp_conv16_variant(p) : cp_conv_variant(p);
+                r.role = role >= 0 ? role : offmask ? CP_ROLE_DCN : act == CP_ACT_SIGMOID_FROM ? CP_ROLE_DCN_OFFSET
+                         : (w.KH == 1 && w.KW == 1) ? CP_ROLE_CONV1X1 : CP_ROLE_CONV;
                 const double M = (double)B * p.Ho * p.Wo;
                 const int cin_real = w.Cin;  // un-padded input channels
                 r.flops = 2.0 * M * w.Cout * (double)(w.KH * w.KW * cin_real);
@@ -736,12 +831,15 @@ struct Fwd {
         gn_in_mr = nullptr;
         gn_in_a = nullptr;
         gn_in_d = nullptr;
+        gn_in_amax = nullptr;
+        role = -1;
         return out;
     }
     const ConvW& cw(const std::string& k) { return m->convs.at(k); }
 
     Tensor maxpool(const Tensor& x) {
         Tensor o = make(x.C, x.H / 2, x.W / 2);
+        o.amax = x.amax;  // max|maxpool(x)| <= max|x|: the input's slot is a valid bound
         if (!m->dry) chk(cp_launch_maxpool2(x.ptr(), o.ptr(), B, x.H, x.W, x.C, s));
         return o;
     }
@@ -798,7 +896,8 @@ struct Fwd {
     }
     Tensor upsample_add(const std::string& p, const Tensor& x, int f, const Tensor& add) {
         Tensor o = make(x.C, x.H * f, x.W * f);
-        if (!m->dry) chk(cp_launch_upsample_add(x.ptr(), m->ups.at(p), add.ptr(), o.ptr(), B, x.H, x.W, x.C, f, s));
+        if (!m->dry)
+            chk(cp_launch_upsample_add(x.ptr(), m->ups.at(p), add.ptr(), o.ptr(), B, x.H, x.W, x.C, f, o.amax, s));
         return o;
     }
     // IDAUp.forward: layers[i] = node(up(proj(layers[i])) + layers[i-1])
@@ -813,7 +912,7 @@ struct Fwd {
     }
 
     // the network's first layers through lowc.hip (f16x3 mode only); returns an invalid Tensor when not applicable
-    Tensor lowc(const std::string& name, int kind, const float* in, int H, int W, int planes) {
+    Tensor lowc(const std::string& name, int kind, const float* in, int H, int W, int planes, const unsigned* in_amax) {
         auto it = m->lowc.find(name);
         if (m->precision != CP_PREC_F16X3 || it == m->lowc.end() || (g_dbg & 64)) return Tensor();
         const ConvW& w = cw(name);
@@ -822,12 +921,13 @@ struct Fwd {
         Tensor out = make(cout, Ho, Wo);
         if (m->dry) return out;
         auto launch = [&]() {
-            return cp_launch_lowc(kind, in, out.ptr(), it->second.first, it->second.second, w.scale, w.shift, B, H, W,
-                                  planes, s);
+            return cp_launch_lowc(kind, in, out.ptr(), it->second.hi, it->second.lo, it->second.scale16, w.shift, in_amax,
+                                  out.amax, B, H, W, planes, s);
         };
         if (m->profile) {
             cp_model::ProfRec r;
             r.variant = CP_VARIANT_LOWC0 + kind;
+            r.role = CP_ROLE_LOWC;
             const double M = (double)B * Ho * Wo;
             r.flops = 2.0 * M * cout * (double)(k * k * cin);
             r.bytes = 4.0 * ((double)B * H * W * cin + M * cout + (double)k * k * cin * cout);
@@ -846,6 +946,7 @@ struct Fwd {
 
     Tensor to_nhwc(const float* nchw, int C, int Cpad, int H, int W) {
         Tensor t = make(Cpad, H, W);
+        t.amax = nullptr;  // re-laid network inputs only feed the exact-f32 stems
         if (!m->dry) chk(cp_launch_nchw_to_nhwc(nchw, t.ptr(), B, C, H, W, Cpad, s));
         return t;
     }
@@ -870,12 +971,14 @@ struct Fwd {
         low = n > 1 ? hg_kp(p + ".low2", low, n - 1, mods + 1) : hg_seq(p + ".low2", low, nm, 1);
         low = hg_seq(p + ".low3", low, cm, 1);
         Tensor out = make(up1.C, up1.H, up1.W);
-        if (!m->dry) chk(cp_launch_upsample2_nearest_add(up1.ptr(), low.ptr(), out.ptr(), B, low.H, low.W, low.C, s));
+        if (!m->dry)
+            chk(cp_launch_upsample2_nearest_add(up1.ptr(), low.ptr(), out.ptr(), B, low.H, low.W, low.C, out.amax, s));
         tap(p, out);
         return out;
     }
     void run_hourglass(int H, int W, const float* images, float* const* head_out, int sigmoid_hm) {
         static const int mods[6] = {2, 2, 2, 2, 2, 4};
+        init_slots();
         Tensor inter;
         {
             Tensor in = to_nhwc(images, 3, 4, H, W);
@@ -901,7 +1004,9 @@ struct Fwd {
             if (hw.w2_hi && m->precision == CP_PREC_F16X3 && !m->tap_name && !(g_dbg & 32) &&
                 fused_head(hw, cnv, sg, m->dry ? (float*)0x1000 : head_out[i]))
                 continue;
+            role = CP_ROLE_HEAD;
             Tensor hid = conv(hw.c0, {&cnv}, 1, 1, CP_ACT_RELU);
+            role = CP_ROLE_HEAD_FINAL;
             conv(hw.c1, {&hid}, 1, 0, sg ? CP_ACT_SIGMOID : CP_ACT_NONE, nullptr, nullptr, 0,
                  m->dry ? (float*)0x1000 : head_out[i], hw.classes);
         }
@@ -909,7 +1014,10 @@ struct Fwd {
 
     void run(int H, int W, const float* images, const float* pre_img, const float* pre_hm, const float* pre_hm_hp,
              float* const* head_out, int sigmoid_hm) {
-        Tensor x0 = lowc("base.base_layer", 0, images, H, W, 3);
+        init_slots();
+        const bool use_lowc = m->precision == CP_PREC_F16X3 && !(g_dbg & 64) && m->lowc.count("base.base_layer");
+        Tensor x0 = lowc("base.base_layer", 0, images, H, W, 3,
+                         use_lowc && !m->dry ? input_slot(images, (size_t)B * 3 * H * W) : nullptr);
         if (!x0.valid()) {
             Tensor in = to_nhwc(images, 3, 4, H, W);
             x0 = conv(cw("base.base_layer"), {&in}, 1, 3, CP_ACT_RELU);
@@ -917,14 +1025,16 @@ struct Fwd {
         if (m->tracking && (pre_img || pre_hm || pre_hm_hp)) {
             Tensor a, b, c;
             if (pre_img) {
-                a = lowc("base.pre_img_layer", 0, pre_img, H, W, 3);
+                a = lowc("base.pre_img_layer", 0, pre_img, H, W, 3,
+                         use_lowc && !m->dry ? input_slot(pre_img, (size_t)B * 3 * H * W) : nullptr);
                 if (!a.valid()) {
                     Tensor in = to_nhwc(pre_img, 3, 4, H, W);
                     a = conv(cw("base.pre_img_layer"), {&in}, 1, 3, CP_ACT_RELU);
                 }
             }
             if (pre_hm) {
-                b = lowc("base.pre_hm_layer", 0, pre_hm, H, W, 1);
+                b = lowc("base.pre_hm_layer", 0, pre_hm, H, W, 1,
+                         use_lowc && !m->dry ? input_slot(pre_hm, (size_t)B * H * W) : nullptr);
                 if (!b.valid()) {
                     Tensor in = to_nhwc(pre_hm, 1, 4, H, W);
                     b = conv(cw("base.pre_hm_layer"), {&in}, 1, 3, CP_ACT_RELU);
@@ -942,15 +1052,15 @@ struct Fwd {
             if (!m->dry)
                 chk(cp_launch_add_relu_sum(x0.ptr(), adds[0]->ptr(), adds.size() > 1 ? adds[1]->ptr() : nullptr,
                                            adds.size() > 2 ? adds[2]->ptr() : nullptr, sum.ptr(),
-                                           (size_t)B * H * W * 16, s));
+                                           (size_t)B * H * W * 16, sum.amax, s));
             x0 = sum;
         }
         tap("base.base_layer", x0);
-        Tensor l0 = lowc("base.level0", 1, x0.ptr(), H, W, 16);
+        Tensor l0 = lowc("base.level0", 1, x0.ptr(), H, W, 16, x0.amax);
         if (!l0.valid()) l0 = conv(cw("base.level0"), {&x0}, 1, 1, CP_ACT_RELU);
         tap("base.level0", l0);
         x0 = Tensor();
-        Tensor l1 = lowc("base.level1", 2, l0.ptr(), H, W, 16);
+        Tensor l1 = lowc("base.level1", 2, l0.ptr(), H, W, 16, l0.amax);
         if (!l1.valid()) l1 = conv(cw("base.level1"), {&l0}, 2, 1, CP_ACT_RELU);
         tap("base.level1", l1);
         l0 = Tensor();
@@ -984,6 +1094,7 @@ struct Fwd {
         std::vector<Tensor> gru_out;
         if (m->gru) {
             const int steps = m->tracking ? 4 : 3;
+            role = CP_ROLE_GRU;
             Tensor x3 = conv(m->gru_x, {&feat}, 1, 1, CP_ACT_NONE);
             Tensor h;
             for (int st = 0; st < steps; ++st) {
@@ -991,7 +1102,7 @@ struct Fwd {
                 const size_t M = (size_t)B * feat.H * feat.W;
                 if (st == 0) {
                     // h0 = 0: the three hidden-side convolutions are identically zero (convGRU.py:51,80-84)
-                    if (!m->dry) chk(cp_launch_gru_gate(x3.ptr(), nullptr, nullptr, hn.ptr(), M, s));
+                    if (!m->dry) chk(cp_launch_gru_gate(x3.ptr(), nullptr, nullptr, hn.ptr(), M, hn.amax, s));
                 } else if (m->precision == CP_PREC_F16X3 && m->gru_h16_hi && !(g_dbg & 256) &&
                            (size_t)M * 192 * 4 < (size_t)0xf0000000u) {
                     // hidden-side convolution with the gate arithmetic in its epilogue: h3 is never written
@@ -1007,6 +1118,9 @@ struct Fwd {
                         p.K = 576; p.Kpad = 576; p.Kpad16 = 576;
                         p.Cout = 192; p.CoutPad = 192;
                         p.w16_hi = m->gru_h16_hi; p.w16_lo = m->gru_h16_lo;
+                        p.scale = m->gru_h16_inv;  // 2^-e of the fused-order weight rows (the hidden-side convs have no affine)
+                        p.in_amax[0] = h.amax;
+                        p.out_amax = hn.amax;
                         p.out = hn.ptr();
                         p.gru_x3 = x3.ptr();
                         p.gru_hprev = h.ptr();
@@ -1015,6 +1129,7 @@ struct Fwd {
                         if (m->profile) {
                             cp_model::ProfRec r;
                             r.variant = CP_VARIANT_GRU;
+                            r.role = CP_ROLE_GRU;
                             r.flops = 2.0 * (double)M * 192 * 576;
                             r.bytes = 4.0 * ((double)M * (64 + 192 + 64 + 64) + 576.0 * 192);
                             r.M = (int)M; r.N = 192; r.K = 576; r.kh = 3; r.stride = 1;
@@ -1029,8 +1144,9 @@ struct Fwd {
                         }
                     }
                 } else {
+                    role = CP_ROLE_GRU;
                     Tensor h3 = conv(m->gru_h, {&h}, 1, 1, CP_ACT_NONE);
-                    if (!m->dry) chk(cp_launch_gru_gate(x3.ptr(), h3.ptr(), h.ptr(), hn.ptr(), M, s));
+                    if (!m->dry) chk(cp_launch_gru_gate(x3.ptr(), h3.ptr(), h.ptr(), hn.ptr(), M, hn.amax, s));
                 }
                 h = hn;
                 gru_out.push_back(h);
@@ -1054,7 +1170,10 @@ struct Fwd {
                     else if (n == "hm_hp" || n == "hp_offset" || n == "hps") r = 1;
                     else if (n == "scale") r = 2;
                 }
-                if (r < 0) continue;  // the reference leaves such heads out of z (:545-563)
+                if (r < 0) {  // unreachable: cp_model_create refuses heads outside the routing table
+                    chk(fail(CP_ERR_STATE, "head without a ConvGRU step"));
+                    continue;
+                }
                 src = &gru_out[r];
             }
             Tensor stats, mr, ad;
@@ -1074,6 +1193,7 @@ struct Fwd {
             if (!m->gru && hw.w2_hi && m->precision == CP_PREC_F16X3 && !m->tap_name && !(g_dbg & 32) &&
                 fused_head(hw, *src, sg, m->dry ? (float*)0x1000 : head_out[i]))
                 continue;
+            role = CP_ROLE_HEAD;
             Tensor hid = conv(hw.c0, {src}, 1, 1, m->gru ? CP_ACT_NONE : CP_ACT_RELU);
             if (m->gru) {
                 if (fuse_gn) {
@@ -1086,10 +1206,12 @@ struct Fwd {
                         if (!m->dry) {
                             float* ap = ad.ptr();
                             float* dp = ap + (size_t)B * hid.C;
+                            unsigned* bound = new_slot();
                             chk(cp_launch_gn_affine((const double*)stats.ptr(), hw.gn_gamma, hw.gn_beta, ap, dp, B, hid.C, 32,
-                                                    (double)hid.H * hid.W * (hid.C / 32), 1e-5f, s));
+                                                    (double)hid.H * hid.W * (hid.C / 32), 1e-5f, hid.amax, bound, s));
                             gn_in_a = ap;
                             gn_in_d = dp;
+                            gn_in_amax = bound;
                         }
                     } else if (!m->dry) {
                         chk(cp_launch_gn_finalize((const double*)stats.ptr(), mr.ptr(), B * 32,
@@ -1099,10 +1221,12 @@ struct Fwd {
                         gn_in_beta = hw.gn_beta;
                     }
                 } else if (!m->dry) {
+                    // in place: the slot keeps the larger of the raw and the normalised |max| -- a valid bound
                     chk(cp_launch_groupnorm_relu(hid.ptr(), hw.gn_gamma, hw.gn_beta, (double*)stats.ptr(), B,
-                                                 hid.H * hid.W, hid.C, 32, 1e-5f, s));
+                                                 hid.H * hid.W, hid.C, 32, 1e-5f, hid.amax, s));
                 }
             }
+            role = CP_ROLE_HEAD_FINAL;
             conv(hw.c1, {&hid}, 1, 0, sg ? CP_ACT_SIGMOID : CP_ACT_NONE, nullptr, nullptr, 0,
                  m->dry ? (float*)0x1000 : head_out[i], hw.classes);
         }
@@ -1150,6 +1274,25 @@ int cp_model_create(const char* arch, int tracking_task, int num_heads, const ch
     m->tracking = tracking_task != 0;
     m->head_conv = head_conv;
     for (int i = 0; i < num_heads; ++i) m->heads.push_back({head_names[i], head_classes[i]});
+    if (m->gru) {
+        // ConvGRU models route each head to a fixed step (pose_dla_dcn.py:545-563); the reference leaves any other head
+        // out of its output dict (the detector then fails with a KeyError).  Refuse it here instead of returning an
+        // unwritten tensor.
+        static const char* pose[] = {"hm", "wh", "reg", "hm_hp", "hp_offset", "hps", "scale"};
+        static const char* track[] = {"tracking", "tracking_hp", "hps_uncertainty", "scale_uncertainty"};
+        for (auto& h : m->heads) {
+            bool ok = false;
+            for (const char* n : pose) ok = ok || h.first == n;
+            if (m->tracking)
+                for (const char* n : track) ok = ok || h.first == n;
+            if (!ok) {
+                const std::string msg = "dlav1_34: head '" + h.first + "' has no ConvGRU step in the reference routing (" +
+                                        (m->tracking ? "tracking" : "non-tracking") + " table, pose_dla_dcn.py:545-563)";
+                delete m;
+                return fail(CP_ERR_INVALID, msg);
+            }
+        }
+    }
     *out = m;
     return CP_OK;
 }
@@ -1203,6 +1346,7 @@ int cp_model_profile(cp_model* m, int enable) {
 int cp_model_profile_read(cp_model* m, double* out, int num_variants) {
     if (!m || !out || num_variants < CP_NUM_CONV_VARIANTS) return fail(CP_ERR_INVALID, "bad argument");
     for (int i = 0; i < num_variants * 4; ++i) out[i] = 0.0;
+    for (int i = 0; i < CP_NUM_ROLES * 4; ++i) m->roles[i] = 0.0;
     const char* dump = getenv("CP_PROFILE_DUMP");  // optional per-launch CSV for kernel tuning
     FILE* df = dump ? fopen(dump, "a") : nullptr;
     for (auto& r : m->prof) {
@@ -1210,12 +1354,20 @@ int cp_model_profile_read(cp_model* m, double* out, int num_variants) {
         if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess)
             return fail(CP_ERR_LAUNCH, "event timing failed");
         if (df)
-            fprintf(df, "%s,%d,%d,%d,%d,%d,%.4f,%.2f\n", cp_conv_variant_name(r.variant), r.M, r.N, r.K, r.kh, r.stride, ms,
-                    r.flops / (ms * 1e-3) / 1e12);
-        out[r.variant * 4 + 0] += 1.0;
-        out[r.variant * 4 + 1] += ms;
-        out[r.variant * 4 + 2] += r.flops;
-        out[r.variant * 4 + 3] += r.bytes;
+            fprintf(df, "%s,%d,%d,%d,%d,%d,%.4f,%.2f,%s\n", r.variant >= 0 ? cp_conv_variant_name(r.variant) : "decode", r.M,
+                    r.N, r.K, r.kh, r.stride, ms, r.flops / (ms * 1e-3) / 1e12, cp_role_name(r.role));
+        if (r.variant >= 0) {
+            out[r.variant * 4 + 0] += 1.0;
+            out[r.variant * 4 + 1] += ms;
+            out[r.variant * 4 + 2] += r.flops;
+            out[r.variant * 4 + 3] += r.bytes;
+        }
+        if (r.role >= 0 && r.role < CP_NUM_ROLES) {
+            m->roles[r.role * 4 + 0] += 1.0;
+            m->roles[r.role * 4 + 1] += ms;
+            m->roles[r.role * 4 + 2] += r.flops;
+            m->roles[r.role * 4 + 3] += r.bytes;
+        }
         m->event_pool.push_back(r.e0);
         m->event_pool.push_back(r.e1);
     }
@@ -1225,6 +1377,18 @@ int cp_model_profile_read(cp_model* m, double* out, int num_variants) {
 }
 
 const char* cp_kernel_variant_name(int v) { return cp_conv_variant_name(v); }
+
+const char* cp_role_name(int role) {
+    static const char* names[CP_NUM_ROLES] = {"conv", "conv1x1", "dcn", "dcn_offset", "head", "head_final", "gru", "lowc",
+                                              "decode"};
+    return (role >= 0 && role < CP_NUM_ROLES) ? names[role] : "?";
+}
+
+int cp_model_profile_roles(cp_model* m, double* out, int num_roles) {
+    if (!m || !out || num_roles < CP_NUM_ROLES) return fail(CP_ERR_INVALID, "bad argument");
+    for (int i = 0; i < CP_NUM_ROLES * 4; ++i) out[i] = m->roles[i];
+    return CP_OK;
+}
 
 void cp_model_destroy(cp_model* m) {
     if (!m) return;
@@ -1283,9 +1447,29 @@ int cp_model_detect(cp_model* m, cp_stream_t stream, int B, int H, int W, const 
         m->tap_name = nullptr;
         int rc = forward_impl(m, s, B, H, W, images, pre_img, pre_hm, pre_hm_hp, head_out, 1, workspace, model_ws, false);
         if (rc != CP_OK) return rc;
-        return cp_launch_decode(s, B, 8, H / 4, W / 4, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7], hp[8],
-                                hp[9], hp[10], K, rep_mode, fit_gaussian, balance, legacy_bool_mask, 0, det,
-                                (char*)workspace + model_ws);
+        cp_model::ProfRec r;
+        if (m->profile) {
+            // algorithmic bytes of the decode: one read of hm + hm_hp, the gathers at the K centres
+            // (<= 60 channels) and at the 8K joint peaks (2 channels), the records written
+            const double hw = (double)(H / 4) * (W / 4);
+            r.variant = -1;
+            r.role = CP_ROLE_DECODE;
+            r.flops = 0.0;
+            r.bytes = (double)B * (9.0 * hw * 4 + K * 60.0 * 4 + 8.0 * K * 2 * 4 + (double)K * CP_DET_STRIDE * 4);
+            r.M = B; r.N = K; r.K = (int)hw; r.kh = 0; r.stride = 0;
+            r.e0 = m->get_event();
+            r.e1 = m->get_event();
+            (void)hipEventRecord(r.e0, s);
+        }
+        rc = cp_launch_decode(s, B, 8, H / 4, W / 4, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7], hp[8], hp[9],
+                              hp[10], K, rep_mode, fit_gaussian, balance, legacy_bool_mask, 0, det,
+                              (char*)workspace + model_ws);
+        if (m->profile) {
+            (void)hipEventRecord(r.e1, s);
+            m->prof.push_back(r);
+        }
+        if (rc != CP_OK) return fail(rc, "detect: decode failed (need K <= 128 <= H*W/16 <= 16384)");
+        return rc;
     };
     if (!use_graph || m->profile) return enqueue();
     std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)H, (uint64_t)W, (uint64_t)images, (uint64_t)pre_img,
@@ -1338,8 +1522,10 @@ int cp_model_forward_tap(cp_model* m, cp_stream_t stream, int B, int H, int W, c
 size_t cp_conv2d_workspace_bytes(int Cin, int Cout, int KH, int KW) {
     const size_t kpad = align_up((size_t)KH * KW * Cin, 16);
     const size_t cpad = align_up((size_t)Cout, cp_conv_tile_n(Cout));
-    // f32 packed weights + (split-f16 path) two binary16 copies
-    return align_up(kpad * cpad * sizeof(float), 256) + 2 * align_up(kpad * cpad * 2, 256);
+    // f32 packed weights + (split-f16 path) two binary16 copies + per-channel weight scales (2^e, 2^-e, scale * 2^-e)
+    // + the input's |max| slot
+    return align_up(kpad * cpad * sizeof(float), 256) + 2 * align_up(kpad * cpad * 2, 256) +
+           3 * align_up(cpad * sizeof(float), 256) + 256;
 }
 
 int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const float* scale, const float* shift,
@@ -1392,9 +1578,23 @@ int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const flo
         p.w16_hi = w16;
         p.w16_lo = w16 + sz;
         p.Kpad16 = p.K;
-        rc = cp_launch_pack_weight16(w, (void*)p.w16_hi, (void*)p.w16_lo, Cout, Cin, KH * KW, p.Kpad16, 0, s);
+        // range-safe operands: per-channel power-of-two weight scale, per-tensor activation scale from one |max| pass
+        const size_t csz = align_up((size_t)p.CoutPad * sizeof(float), 256);
+        float* wfwd = (float*)(w16 + 2 * sz);
+        float* winv = (float*)((char*)wfwd + csz);
+        float* sc16 = (float*)((char*)winv + csz);
+        unsigned* slot = (unsigned*)((char*)sc16 + csz);
+        if (hipMemsetAsync(wfwd, 0, 3 * csz + 256, s) != hipSuccess) return CP_ERR_LAUNCH;
+        rc = cp_launch_weight_scale(w, Cout, Cin * KH * KW, wfwd, winv, s);
+        if (rc == CP_OK) rc = cp_launch_pack_weight16(w, (void*)p.w16_hi, (void*)p.w16_lo, Cout, Cin, KH * KW, p.Kpad16, 0, wfwd, s);
+        if (rc == CP_OK) rc = cp_launch_scale16(scale, winv, sc16, Cout, s);
+        if (rc == CP_OK) rc = cp_launch_absmax(x, (size_t)B * H * W * Cin, slot, s);
         if (rc != CP_OK) return rc;
-        if (cp_conv16_supported(p)) return cp_launch_conv16(p, s);
+        if (cp_conv16_supported(p)) {
+            p.scale = sc16;
+            p.in_amax[0] = slot;
+            return cp_launch_conv16(p, s);
+        }
     }
     return cp_launch_conv(p, s);
 }
@@ -1463,7 +1663,8 @@ size_t cp_dcnv2_workspace_bytes(int B, int C, int H, int W, int Co) {
     const size_t px = (size_t)B * H * W;
     const size_t cpad = align_up((size_t)Co, cp_conv_tile_n(Co));
     return align_up(px * C * 4, 256) + align_up(px * 32 * 4, 256) + align_up(px * Co * 4, 256) +
-           align_up((size_t)9 * C * cpad * 4, 256) + align_up(cpad * 4, 256) + 2 * align_up((size_t)9 * C * cpad * 2, 256);
+           align_up((size_t)9 * C * cpad * 4, 256) + align_up(cpad * 4, 256) + 2 * align_up((size_t)9 * C * cpad * 2, 256) +
+           3 * align_up(cpad * 4, 256) + 256;
 }
 
 }  // extern "C"
@@ -1546,8 +1747,23 @@ extern "C" int cp_dcnv2_forward(cp_stream_t stream, const float* input, const fl
         p.w16_hi = w16;
         p.w16_lo = w16 + sz;
         p.Kpad16 = 9 * C;
-        rc = cp_launch_pack_weight16(weight, (void*)p.w16_hi, (void*)p.w16_lo, Co, C, 9, p.Kpad16, 0, s);
+        const size_t csz = align_up((size_t)cpad * 4, 256);
+        float* wfwd = (float*)(w16 + 2 * sz);
+        float* winv = (float*)((char*)wfwd + csz);
+        float* sc16 = (float*)((char*)winv + csz);
+        unsigned* slot = (unsigned*)((char*)sc16 + csz);
+        if (hipMemsetAsync(wfwd, 0, 3 * csz + 256, s) != hipSuccess) return CP_ERR_LAUNCH;
+        rc = cp_launch_weight_scale(weight, Co, C * 9, wfwd, winv, s);
+        if (rc == CP_OK) rc = cp_launch_pack_weight16(weight, (void*)p.w16_hi, (void*)p.w16_lo, Co, C, 9, p.Kpad16, 0, wfwd, s);
+        if (rc == CP_OK) rc = cp_launch_scale16(nullptr, winv, sc16, Co, s);
+        if (rc == CP_OK) rc = cp_launch_absmax(x_nhwc, px * C, slot, s);
         if (rc != CP_OK) return rc;
+        if (cp_conv16_supported(p)) {
+            p.scale = sc16;
+            p.in_amax[0] = slot;
+        } else {
+            p.w16_hi = p.w16_lo = nullptr;
+        }
     }
     rc = (p.w16_hi && cp_conv16_supported(p)) ? cp_launch_conv16(p, s) : cp_launch_conv(p, s);
     if (rc != CP_OK) return rc;

@@ -87,7 +87,7 @@ __global__ void maxpool2_kernel(const float* __restrict__ in, float* __restrict_
 // w is [C,1,k,k] exactly as in the checkpoint.
 __global__ void upsample_add_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                     const float* __restrict__ add, float* __restrict__ out, int B, int H, int W, int C,
-                                    int f) {
+                                    int f, unsigned* __restrict__ out_amax) {
     // per-channel kernels staged once per workgroup as [tap][channel] so a lane's 4 channels are one ds_read_b128
     extern __shared__ float wt[];
     const int k = 2 * f, kk = k * k;
@@ -99,6 +99,7 @@ __global__ void upsample_add_kernel(const float* __restrict__ in, const float* _
     // 32-bit index math throughout (B*Ho*Wo*C/4 < 2^31 for every supported shape)
     const int p = f / 2, Ho = H * f, Wo = W * f, C4 = C >> 2;
     const unsigned total = (unsigned)B * Ho * Wo * C4;
+    float amax = 0.f;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const unsigned c4 = i % (unsigned)C4;
         unsigned t = i / (unsigned)C4;
@@ -128,21 +129,27 @@ __global__ void upsample_add_kernel(const float* __restrict__ in, const float* _
             }
         }
         acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));
         reinterpret_cast<float4*>(out)[i] = acc;
     }
+    if (out_amax) cp_amax_commit(out_amax, amax);
 }
 
 // out = a + b (+ c) (+ d)   (tracking stems: x = base + pre_img + pre_hm + pre_hm_hp, pose_dla_dcn.py:312-318)
 __global__ void add_n_kernel(const float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ c,
-                             const float4* __restrict__ d, float4* __restrict__ out, size_t n4) {
+                             const float4* __restrict__ d, float4* __restrict__ out, size_t n4,
+                             unsigned* __restrict__ out_amax) {
+    float amax = 0.f;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 r = a[i];
         const float4 y = b[i];
         r.x += y.x; r.y += y.y; r.z += y.z; r.w += y.w;
         if (c) { const float4 z = c[i]; r.x += z.x; r.y += z.y; r.z += z.z; r.w += z.w; }
         if (d) { const float4 z = d[i]; r.x += z.x; r.y += z.y; r.z += z.z; r.w += z.w; }
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
         out[i] = r;
     }
+    if (out_amax) cp_amax_commit(out_amax, amax);
 }
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
@@ -151,8 +158,10 @@ __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); 
 //   x3 = [Wir x + b_ir | Wiz x + b_iz | Win x + b_in],  h3 = [Whr h | Whz h | Whn h]  (h3 == nullptr at step 0: h = 0)
 //   r = sig(x3r + h3r); z = sig(x3z + h3z); n = tanh(x3n + r * h3n); h' = (1 - z) * n + z * h
 __global__ void gru_gate_kernel(const float* __restrict__ x3, const float* __restrict__ h3,
-                                const float* __restrict__ hprev, float* __restrict__ hout, size_t M) {
+                                const float* __restrict__ hprev, float* __restrict__ hout, size_t M,
+                                unsigned* __restrict__ out_amax) {
     const size_t total = M * 16;  // 64 channels / 4
+    float amax = 0.f;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t m = i >> 4;
         const int c = (int)(i & 15) * 4;
@@ -176,8 +185,10 @@ __global__ void gru_gate_kernel(const float* __restrict__ x3, const float* __res
     }
         CP_GRU(x) CP_GRU(y) CP_GRU(z) CP_GRU(w)
 #undef CP_GRU
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
         *reinterpret_cast<float4*>(hout + m * 64 + c) = o;
     }
+    if (out_amax) cp_amax_commit(out_amax, amax);
 }
 
 // GroupNorm statistics: one workgroup per (b, slab of pixels); per-group sum / sum of squares in
@@ -212,10 +223,11 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, double* __restrict_
 
 __global__ void gn_apply_relu_kernel(float* __restrict__ x, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, const double* __restrict__ stats, int B, int HW,
-                                     int C, int groups, float eps) {
+                                     int C, int groups, float eps, unsigned* __restrict__ out_amax) {
     const int C4 = C >> 2, cpg = C / groups;
     const size_t total = (size_t)B * HW * C4;
     const double cnt = (double)HW * cpg;
+    float amax = 0.f;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
         const size_t b = i / ((size_t)HW * C4);
@@ -233,8 +245,10 @@ __global__ void gn_apply_relu_kernel(float* __restrict__ x, const float* __restr
         v.y = fmaxf((v.y - mu) * rstd * ga.y + be.y, 0.f);
         v.z = fmaxf((v.z - mu) * rstd * ga.z + be.z, 0.f);
         v.w = fmaxf((v.w - mu) * rstd * ga.w + be.w, 0.f);
+        amax = fmaxf(amax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
         reinterpret_cast<float4*>(x)[i] = v;
     }
+    if (out_amax) cp_amax_commit(out_amax, amax);
 }
 
 // PyTorch conv weight [Cout][Cin][KH*KW] -> implicit-GEMM B matrix wp[(tap*CinP + ci) * CoutPad + coff + co]
@@ -262,17 +276,26 @@ __global__ void gn_finalize_kernel(const double* __restrict__ stats, float* __re
 
 __global__ void gn_affine_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, float* __restrict__ a, float* __restrict__ d, int B, int C,
-                                 int groups, double count, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * C) return;
+                                 int groups, double count, float eps, const unsigned* __restrict__ x_amax,
+                                 unsigned* __restrict__ y_amax) {
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i0 < B * C;
+    const int i = live ? i0 : 0;
     const int b = i / C, c = i - b * C, g = c / (C / groups);
     const double mean = stats[2 * (b * groups + g)] / count;
     double var = stats[2 * (b * groups + g) + 1] / count - mean * mean;
     if (var < 0) var = 0;
     const float mu = (float)mean, rs = (float)(1.0 / sqrt(var + (double)eps));
-    const float av = rs * gamma[c];
-    a[i] = av;
-    d[i] = beta[c] - mu * av;
+    const float av = rs * gamma[c], dv = beta[c] - mu * av;
+    if (live) {
+        a[i] = av;
+        d[i] = dv;
+    }
+    if (y_amax) {
+        // |relu(a*x + d)| <= |a| * max|x| + |d|; a few ulps of slack for the rounding of the products
+        const float xm = x_amax ? __uint_as_float(*x_amax) : 0.f;
+        cp_amax_commit(y_amax, live ? (fabsf(av) * xm + fabsf(dv)) * 1.0001f : 0.f);
+    }
 }
 
 // BaseDetector.pre_process on device (base_detector.py:127-134): warpAffine(INTER_LINEAR, constant 0 border) of an
@@ -313,8 +336,10 @@ __global__ void preprocess_kernel(const unsigned char* __restrict__ img, int H, 
 // kp_module merge of the stacked hourglass (large_hourglass.py:186-188): out = up1 + Upsample(scale_factor=2)(low3),
 // nearest neighbour.  up1 / out: [B, 2H, 2W, C], low: [B, H, W, C]; one float4 per lane.
 __global__ void upsample2_nearest_add_kernel(const float* __restrict__ up1, const float* __restrict__ low,
-                                             float* __restrict__ out, int B, int H, int W, int C4) {
+                                             float* __restrict__ out, int B, int H, int W, int C4,
+                                             unsigned* __restrict__ out_amax) {
     const size_t total = (size_t)B * 2 * H * 2 * W * C4;
+    float amax = 0.f;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
         size_t r = i / C4;
@@ -324,8 +349,11 @@ __global__ void upsample2_nearest_add_kernel(const float* __restrict__ up1, cons
         const size_t b = r / (2 * H);
         const float4 a = reinterpret_cast<const float4*>(up1)[i];
         const float4 l = reinterpret_cast<const float4*>(low)[((b * H + (y >> 1)) * W + (x >> 1)) * C4 + c];
-        reinterpret_cast<float4*>(out)[i] = make_float4(a.x + l.x, a.y + l.y, a.z + l.z, a.w + l.w);
+        const float4 o = make_float4(a.x + l.x, a.y + l.y, a.z + l.z, a.w + l.w);
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+        reinterpret_cast<float4*>(out)[i] = o;
     }
+    if (out_amax) cp_amax_commit(out_amax, amax);
 }
 
 inline int check() { return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH; }
@@ -357,46 +385,47 @@ int cp_launch_maxpool2(const float* in, float* out, int B, int H, int W, int C, 
 }
 
 int cp_launch_upsample_add(const float* in, const float* w, const float* add, float* out, int B, int H, int W, int C,
-                           int f, hipStream_t s) {
+                           int f, unsigned* out_amax, hipStream_t s) {
     if (C % 4 || f < 2 || (f & 1)) return CP_ERR_INVALID;
     if ((size_t)B * H * f * W * f * (C / 4) >= ((size_t)1 << 31)) return CP_ERR_INVALID;
     const size_t lds = (size_t)C * 4 * f * f * sizeof(float);
     if (lds > 64 * 1024) return CP_ERR_INVALID;
     hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for((size_t)B * H * f * W * f * (C / 4), 256 * 8)), dim3(TPB), lds,
-                       s, in, w, add, out, B, H, W, C, f);
+                       s, in, w, add, out, B, H, W, C, f, out_amax);
     return check();
 }
 
 int cp_launch_add_relu_sum(const float* a, const float* b, const float* c, const float* d, float* out, size_t n,
-                           hipStream_t s) {
+                           unsigned* out_amax, hipStream_t s) {
     if (n % 4) return CP_ERR_INVALID;
     hipLaunchKernelGGL(add_n_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, s, (const float4*)a, (const float4*)b,
-                       (const float4*)c, (const float4*)d, (float4*)out, n / 4);
+                       (const float4*)c, (const float4*)d, (float4*)out, n / 4, out_amax);
     return check();
 }
 
 int cp_launch_upsample2_nearest_add(const float* up1, const float* low, float* out, int B, int H, int W, int C,
-                                    hipStream_t s) {
+                                    unsigned* out_amax, hipStream_t s) {
     if (C % 4) return CP_ERR_INVALID;
     hipLaunchKernelGGL(upsample2_nearest_add_kernel, dim3(grid_for((size_t)B * 4 * H * W * (C / 4))), dim3(TPB), 0, s, up1,
-                       low, out, B, H, W, C / 4);
+                       low, out, B, H, W, C / 4, out_amax);
     return check();
 }
 
-int cp_launch_gru_gate(const float* x3, const float* h3, const float* hprev, float* hout, size_t M, hipStream_t s) {
-    hipLaunchKernelGGL(gru_gate_kernel, dim3(grid_for(M * 16)), dim3(TPB), 0, s, x3, h3, hprev, hout, M);
+int cp_launch_gru_gate(const float* x3, const float* h3, const float* hprev, float* hout, size_t M, unsigned* out_amax,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(gru_gate_kernel, dim3(grid_for(M * 16)), dim3(TPB), 0, s, x3, h3, hprev, hout, M, out_amax);
     return check();
 }
 
 int cp_launch_groupnorm_relu(float* x, const float* gamma, const float* beta, double* stats_ws, int B, int HW, int C,
-                             int groups, float eps, hipStream_t s) {
+                             int groups, float eps, unsigned* out_amax, hipStream_t s) {
     if (C % 4 || (C / groups) % 4 || groups > 64 || TPB % (C / 4)) return CP_ERR_INVALID;
     if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * groups * B, s) != hipSuccess) return CP_ERR_LAUNCH;
     const int slab = 512;
     hipLaunchKernelGGL(gn_stats_kernel, dim3((HW + slab - 1) / slab, B), dim3(TPB), 0, s, x, stats_ws, HW, C, groups,
                        slab);
     hipLaunchKernelGGL(gn_apply_relu_kernel, dim3(grid_for((size_t)B * HW * (C / 4))), dim3(TPB), 0, s, x, gamma, beta,
-                       stats_ws, B, HW, C, groups, eps);
+                       stats_ws, B, HW, C, groups, eps, out_amax);
     return check();
 }
 
@@ -408,10 +437,10 @@ int cp_launch_pack_weight(const float* w, float* wp, int Cout, int Cin, int taps
 }
 
 int cp_launch_gn_affine(const double* stats, const float* gamma, const float* beta, float* a, float* d, int B, int C,
-                        int groups, double count, float eps, hipStream_t s) {
+                        int groups, double count, float eps, const unsigned* x_amax, unsigned* y_amax, hipStream_t s) {
     if (C % groups) return CP_ERR_INVALID;
     hipLaunchKernelGGL(gn_affine_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, stats, gamma, beta, a, d, B, C, groups,
-                       count, eps);
+                       count, eps, x_amax, y_amax);
     return check();
 }
 

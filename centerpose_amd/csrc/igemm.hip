@@ -400,22 +400,26 @@ namespace {
 __global__ void splitk_epilogue_kernel(const ConvParams p) {
     const int M = p.B * p.Ho * p.Wo, HWo = p.Ho * p.Wo;
     const size_t total = (size_t)M * p.Cout;
+    float afwd, ainv, amax = 0.f;
+    conv_in_scale(p, &afwd, &ainv);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         int m, n;
         if (p.store == CP_STORE_NHWC) { m = (int)(i / p.Cout); n = (int)(i - (size_t)m * p.Cout); }
         else { n = (int)(i / M); m = (int)(i - (size_t)n * M); }
         float acc = 0.f;
         for (int z = 0; z < p.splitk; ++z) acc += p.partial[((size_t)z * M + m) * p.CoutPad + n];
-        float y = acc * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
+        float y = acc * ((p.scale ? p.scale[n] : 1.f) * ainv) + (p.shift ? p.shift[n] : 0.f);
         if (p.res) y += p.res[(size_t)m * p.res_ld + n];
         if (p.act == CP_ACT_RELU) y = fmaxf(y, 0.f);
         else if (p.act == CP_ACT_SIGMOID || (p.act == CP_ACT_SIGMOID_FROM && n >= p.act_from)) y = 1.f / (1.f + expf(-y));
+        amax = fmaxf(amax, fabsf(y));
         if (p.store == CP_STORE_NHWC) p.out[(size_t)m * p.ldo + p.coff + n] = y;
         else {
             const int b = m / HWo, pix = m - b * HWo;
             p.out[((size_t)b * p.ldo + p.coff + n) * HWo + pix] = y;
         }
     }
+    if (p.out_amax) cp_amax_commit(p.out_amax, amax);
 }
 }  // namespace
 

@@ -142,6 +142,9 @@ __global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel
     }
     int d_idx[DCN ? A_SLOTS : 1][4];
     float d_w[DCN ? A_SLOTS : 1][4];
+    // power-of-two pre-scale of the activations (ConvParams::in_amax); DCN folds it into the bilinear weights
+    float afwd, ainv;
+    conv_in_scale(p, &afwd, &ainv);
 
     // weights: [CoutPad][Kpad16] binary16, k contiguous; chunk f -> row n = f / 4, 16-byte column f % 4
     const _Float16* wh = reinterpret_cast<const _Float16*>(p.w16_hi);
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel
                     if (a_ok[j]) {
                         const size_t pix = (size_t)(a_b[j] * p.H + (a_h0[j] + p.pad)) * p.W + (a_w0[j] + p.pad);
                         const float* om = p.offmask + pix * 32;
-                        const float dh = om[2 * u_tap], dw = om[2 * u_tap + 1], mk = om[18 + u_tap];
+                        const float dh = om[2 * u_tap], dw = om[2 * u_tap + 1], mk = om[18 + u_tap] * afwd;
                         const float h_im = (float)(a_h0[j] + u_kh) + dh;
                         const float w_im = (float)(a_w0[j] + u_kw) + dw;
                         if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
@@ -272,7 +275,8 @@ __global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel
 #pragma unroll
         for (int j = 0; j < A_SLOTS; ++j) {
             const int row = (tid >> 3) + j * 32;
-            const Split2 s0 = split2(a_reg[j].x, a_reg[j].y), s1 = split2(a_reg[j].z, a_reg[j].w);
+            const float as = DCN ? 1.f : afwd;
+            const Split2 s0 = split2(a_reg[j].x * as, a_reg[j].y * as), s1 = split2(a_reg[j].z * as, a_reg[j].w * as);
             const int col = ((((k4 >> 1) ^ swz(row)) << 1) | (k4 & 1)) * 4;  // halfs
             *reinterpret_cast<u32x2*>(Ah + row * LDH + col) = u32x2{s0.hi, s1.hi};
             *reinterpret_cast<u32x2*>(Al + row * LDH + col) = u32x2{s0.lo, s1.lo};
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel
         }
     }
     if (p.splitk > 1) igemm_store_partial<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane, blockIdx.y);
-    else igemm_epilogue<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane);
+    else igemm_epilogue<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane, ainv);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -528,6 +532,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
     int tiles_left = n;  // tiles not yet issued; past the end every load goes out of range
 
     // ---- loader pieces: A slot j / B slot j of the tile the K walk points at, then the walk step ----
+    float afwd, ainv;  // power-of-two pre-scale of the activations and its inverse (ConvParams::in_amax)
+    conv_in_scale(p, &afwd, &ainv);
     float4 gn_a4 = make_float4(1.f, 1.f, 1.f, 1.f), gn_d4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int gn_b = GNIN ? (tm * BM) / (p.Ho * p.Wo) : 0;  // the tile's image (the launcher guarantees Ho*Wo % BM == 0)
     auto issue_a = [&](float4(&ga)[A_SLOTS], int j) {
@@ -535,6 +541,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
             const int c = (tiles_left > 0 ? u_cs : 0) + k4 * 4;
             gn_a4 = *reinterpret_cast<const float4*>(p.gn_in_a + (size_t)gn_b * p.Cin + c);
             gn_d4 = *reinterpret_cast<const float4*>(p.gn_in_d + (size_t)gn_b * p.Cin + c);
+            // relu(a*x + d) * 2^e == relu((a*2^e)*x + d*2^e): the pre-scale rides in the affine
+            gn_a4.x *= afwd; gn_a4.y *= afwd; gn_a4.z *= afwd; gn_a4.w *= afwd;
+            gn_d4.x *= afwd; gn_d4.y *= afwd; gn_d4.z *= afwd; gn_d4.w *= afwd;
         }
         __amdgpu_buffer_rsrc_t rs = r_s0;
         int sc = p.src_c[0];
@@ -590,10 +599,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
         if (q == 0) {
             float x = ga[j].x, y = ga[j].y;
             if (GNIN) { x = fmaxf(fmaf(x, gn_a4.x, gn_d4.x), 0.f); y = fmaxf(fmaf(y, gn_a4.y, gn_d4.y), 0.f); }
+            else { x *= afwd; y *= afwd; }
             cs0[j] = split2(x, y);
         } else if (q == 1) {
             float z = ga[j].z, w = ga[j].w;
             if (GNIN) { z = fmaxf(fmaf(z, gn_a4.z, gn_d4.z), 0.f); w = fmaxf(fmaf(w, gn_a4.w, gn_d4.w), 0.f); }
+            else { z *= afwd; w *= afwd; }
             cs1[j] = split2(z, w);
         }
         else if (q == 2) *reinterpret_cast<u32x2*>(Ah + row * LDH + col) = u32x2{cs0[j].hi, cs1[j].hi};
@@ -748,15 +759,30 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
         const bool relu = p.act == CP_ACT_RELU;
+        // hidden activations (bias + ReLU applied) in place, and their |max| over the wave: the second product's
+        // activation operand gets its own power-of-two pre-scale (hfwd), undone on acc2 before the cross-wave sums
+        float hmax = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            float sc[16], sh[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ch = tn * BN + wn * 64 + j * 32 + F::row(r, lane);
-                sc[r] = p.scale ? p.scale[ch] : 1.f;
-                sh[r] = p.shift ? p.shift[ch] : 0.f;
+                const float sc = (p.scale ? p.scale[ch] : 1.f) * ainv, sh = p.shift ? p.shift[ch] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float x = acc[i][j][r] * sc + sh;
+                    if (relu) x = fmaxf(x, 0.f);
+                    acc[i][j][r] = x;
+                    hmax = fmaxf(hmax, fabsf(x));
+                }
             }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hmax = fmaxf(hmax, __shfl_xor(hmax, o, 64));
+        float hfwd, hinv;
+        cp_amax_to_scale(__float_as_uint(hmax), &hfwd, &hinv);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -765,8 +791,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int r = ks * 8 + q * 2;
-                        float x0 = acc[i][j][r] * sc[r] + sh[r], x1 = acc[i][j][r + 1] * sc[r + 1] + sh[r + 1];
-                        if (relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+                        const float x0 = acc[i][j][r] * hfwd, x1 = acc[i][j][r + 1] * hfwd;
                         const Split2 sp = split2(x0, x1);
                         hh[q] = sp.hi;
                         hl[q] = sp.lo;
@@ -782,6 +807,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
         // sum the two hidden-channel halves (wn = 0 / 1) of each pixel range through LDS, in a fixed order
         __syncthreads();  // every wave is done with the tile buffers
         float* red = reinterpret_cast<float*>(lds);  // [wm][i][r][lane]
+        // back to true units: 2^-e of this wave's hidden pre-scale and of the 1x1 weights' per-channel scale
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float wi = (p.fuse_w2_inv ? p.fuse_w2_inv[F::row(r, lane)] : 1.f) * hinv;
+            acc2[0][r] *= wi;
+            acc2[1][r] *= wi;
+        }
         if (wn == 1) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -809,6 +841,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
         // the same float expressions as gru_gate_kernel)
         const int mbase = __builtin_amdgcn_readfirstlane(tm * BM + wm * 32);
         const int ch = tn * 32 + (lane & 31);
+        {   // undo the operand pre-scales: 2^-e_a of the state tensor and 2^-e_w of this lane's three gate rows
+            const int row0 = tn * 96 + (lane & 31);
+            const float s0 = (p.scale ? p.scale[row0] : 1.f) * ainv, s1 = (p.scale ? p.scale[row0 + 32] : 1.f) * ainv,
+                        s2 = (p.scale ? p.scale[row0 + 64] : 1.f) * ainv;
+#pragma unroll
+            for (int r = 0; r < F::NACC; ++r) { acc[0][0][r] *= s0; acc[0][1][r] *= s1; acc[0][2][r] *= s2; }
+        }
+        float amax = 0.f;
         if (mbase + 32 <= M) {
             const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.gru_x3 + (size_t)mbase * 192, 32u * 192u * 4u);
             const __amdgpu_buffer_rsrc_t rh = make_rsrc(p.gru_hprev + (size_t)mbase * 64, 32u * 64u * 4u);
@@ -824,7 +864,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
                 const float rg = 1.f / (1.f + expf(-(xr + acc[0][0][r])));
                 const float zg = 1.f / (1.f + expf(-(xz + acc[0][1][r])));
                 const float ng = tanhf(xn + rg * acc[0][2][r]);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((1.f - zg) * ng + zg * hp), ro, vh, sh, 0);
+                const float hv = (1.f - zg) * ng + zg * hp;
+                amax = fmaxf(amax, fabsf(hv));
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), ro, vh, sh, 0);
             }
         } else {
 #pragma unroll
@@ -836,13 +878,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
                 const float rg = 1.f / (1.f + expf(-(x3[0] + acc[0][0][r])));
                 const float zg = 1.f / (1.f + expf(-(x3[64] + acc[0][1][r])));
                 const float ng = tanhf(x3[128] + rg * acc[0][2][r]);
-                p.out[(size_t)m * 64 + ch] = (1.f - zg) * ng + zg * hp;
+                const float hv = (1.f - zg) * ng + zg * hp;
+                amax = fmaxf(amax, fabsf(hv));
+                p.out[(size_t)m * 64 + ch] = hv;
             }
         }
+        if (p.out_amax) cp_amax_commit(p.out_amax, amax);
         return;
     }
     if (p.splitk > 1) igemm_store_partial<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane, blockIdx.y);
-    else igemm_epilogue<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane);
+    else igemm_epilogue<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane, ainv);
 #if CP_EXP & 256
     if (blockIdx.x == 4000 && threadIdx.x == 0) {
         g_cp_clk[0] = clock64() - clk0;
@@ -873,14 +918,14 @@ int launch16(const ConvParams& p, hipStream_t stream) {
 // fragment (tn, wn, j, ks), lane (c = lane % 32, g = lane / 32), element e holds hidden channel
 // tn*128 + wn*64 + j*32 + (e & 3) + 8 * (2*ks + (e >> 2)) + 4*g of final channel c (zero for c >= C2).
 __global__ void pack_head_w2_kernel(const float* __restrict__ w1, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                    int C2, int Chid) {
+                                    const float* __restrict__ fwd, int C2, int Chid) {
     const int total = Chid * 32;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int e = idx & 7, lane = (idx >> 3) & 63, frag = idx >> 9;
         const int ks = frag & 1, j = (frag >> 1) & 1, wave = frag >> 2;  // wave = tn * 2 + wn
         const int c = lane & 31, g = lane >> 5;
         const int ch = wave * 64 + j * 32 + (e & 3) + 8 * (2 * ks + (e >> 2)) + 4 * g;
-        const float x = c < C2 ? w1[(size_t)c * Chid + ch] : 0.f;
+        const float x = c < C2 ? w1[(size_t)c * Chid + ch] * fwd[c] : 0.f;
         const Split2 sp = split2(x, 0.f);
         reinterpret_cast<uint16_t*>(hi)[idx] = (uint16_t)(sp.hi & 0xffffu);
         reinterpret_cast<uint16_t*>(lo)[idx] = (uint16_t)(sp.lo & 0xffffu);
@@ -905,13 +950,13 @@ __global__ void head_reduce_kernel(const float* __restrict__ slabs, const float*
 
 // pack PyTorch [Cout][Cin][taps] float32 weights into split binary16 [CoutPad][Kpad16] (k = tap*Cin + ci)
 __global__ void pack_weight16_kernel(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                     int Cout, int Cin, int taps, int Kpad16, int coff) {
+                                     int Cout, int Cin, int taps, int Kpad16, int coff, const float* __restrict__ fwd) {
     const size_t total = (size_t)Cout * Cin * taps;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int t = (int)(i % taps);
         const size_t r = i / taps;
         const int ci = (int)(r % Cin), co = (int)(r / Cin);
-        const float x = w[i];
+        const float x = w[i] * (fwd ? fwd[coff + co] : 1.f);
         const Split2 s = split2(x, 0.f);
         const size_t o = (size_t)(coff + co) * Kpad16 + (size_t)t * Cin + ci;
         reinterpret_cast<uint16_t*>(hi)[o] = (uint16_t)(s.hi & 0xffffu);
@@ -919,7 +964,55 @@ __global__ void pack_weight16_kernel(const float* __restrict__ w, _Float16* __re
     }
 }
 
+// one 64-lane block per output channel: (2^e, 2^-e) with max|w[co,:]| * 2^e in [2^14, 2^15)
+__global__ void weight_scale_kernel(const float* __restrict__ w, int per, float* __restrict__ fwd, float* __restrict__ inv) {
+    const int co = blockIdx.x;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < per; i += 64) m = fmaxf(m, fabsf(w[(size_t)co * per + i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (threadIdx.x == 0) {
+        float f = 1.f, iv = 1.f;
+        if (m > 0.f) cp_amax_to_scale(__float_as_uint(m), &f, &iv);
+        fwd[co] = f;
+        inv[co] = iv;
+    }
+}
+
+__global__ void scale16_kernel(const float* __restrict__ scale, const float* __restrict__ inv, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (scale ? scale[i] : 1.f) * inv[i];
+}
+
+__global__ void absmax_kernel(const float4* __restrict__ x, size_t n4, unsigned* __restrict__ slot) {
+    float m = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = x[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    cp_amax_commit(slot, m);
+}
+
 }  // namespace
+
+int cp_launch_weight_scale(const float* w, int Cout, int per, float* fwd, float* inv, hipStream_t s) {
+    hipLaunchKernelGGL(weight_scale_kernel, dim3(Cout), dim3(64), 0, s, w, per, fwd, inv);
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}
+
+int cp_launch_scale16(const float* scale, const float* inv, float* out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(scale16_kernel, dim3((n + 255) / 256), dim3(256), 0, s, scale, inv, out, n);
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}
+
+int cp_launch_absmax(const float* x, size_t n, unsigned* slot, hipStream_t s) {
+    if (n % 4 || ((uintptr_t)x & 15)) return CP_ERR_INVALID;
+    size_t g = (n / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)g), dim3(256), 0, s, (const float4*)x, n / 4, slot);
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}
 
 // N tile of the f16x3 launch: cp_conv_tile_n, except that <= 16-wide outputs whose weights were packed to 32 columns
 // (the GroupNorm'd final 1x1 heads) take the 32-wide tile
@@ -978,12 +1071,12 @@ int cp_conv16_variant(const ConvParams& p) {
 }
 
 int cp_launch_pack_weight16(const float* w, void* hi, void* lo, int Cout, int Cin, int taps, int Kpad16, int coff,
-                            hipStream_t s) {
+                            const float* fwd, hipStream_t s) {
     const size_t n = (size_t)Cout * Cin * taps;
     int g = (int)((n + 255) / 256);
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(pack_weight16_kernel, dim3(g), dim3(256), 0, s, w, (_Float16*)hi, (_Float16*)lo, Cout, Cin, taps,
-                       Kpad16, coff);
+                       Kpad16, coff, fwd);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
@@ -1003,10 +1096,14 @@ int cp_launch_conv16_fused_head(const ConvParams& p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
-int cp_launch_pack_head_w2(const float* w1, void* hi, void* lo, int C2, int Chid, hipStream_t s) {
-    if (Chid % 128 != 0 || C2 < 1 || C2 > 32) return CP_ERR_INVALID;
+int cp_launch_pack_head_w2(const float* w1, void* hi, void* lo, float* w2_inv, int C2, int Chid, hipStream_t s) {
+    if (Chid % 128 != 0 || C2 < 1 || C2 > 32 || !w2_inv) return CP_ERR_INVALID;
+    // w2_inv doubles as [32 inv | 32 fwd]: per-final-channel power-of-two scale of the 1x1 rows (pad rows: 1)
+    float* fwd = w2_inv + 32;
+    if (hipMemsetAsync(w2_inv, 0, 64 * sizeof(float), s) != hipSuccess) return CP_ERR_LAUNCH;
+    hipLaunchKernelGGL(weight_scale_kernel, dim3(C2), dim3(64), 0, s, w1, Chid, fwd, w2_inv);
     hipLaunchKernelGGL(pack_head_w2_kernel, dim3((Chid * 32 + 255) / 256), dim3(256), 0, s, w1, (_Float16*)hi,
-                       (_Float16*)lo, C2, Chid);
+                       (_Float16*)lo, (const float*)fwd, C2, Chid);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 

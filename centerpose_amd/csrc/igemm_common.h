@@ -117,11 +117,24 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
+// Activation pre-scale of an f16x3 launch (ConvParams::in_amax): 2^e_a and its inverse from the largest running |max|
+// of the sources; (1, 1) when the launch carries no slots (exact-f32 kernels, stand-alone calls without tracking).
+__device__ __forceinline__ void conv_in_scale(const ConvParams& p, float* fwd, float* inv) {
+    *fwd = 1.f;
+    *inv = 1.f;
+    if (!p.in_amax[0]) return;
+    unsigned mx = *p.in_amax[0];
+    if (p.nsrc > 1 && p.in_amax[1]) mx = max(mx, *p.in_amax[1]);
+    if (p.nsrc > 2 && p.in_amax[2]) mx = max(mx, *p.in_amax[2]);
+    if (p.nsrc > 3 && p.in_amax[3]) mx = max(mx, *p.in_amax[3]);
+    cp_amax_to_scale(mx, fwd, inv);
+}
+
 // Epilogue of every implicit-GEMM tile: y = acc*scale[n] + shift[n] (+ residual) -> ReLU / sigmoid -> NHWC or NCHW
 // store (folded eval-mode BatchNorm, conv bias, BasicBlock residual: pose_dla_dcn.py:48-62, DeformConv.actf :380-389).
 template <int FRAG, int MT, int NT, int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, typename Frag<FRAG>::acc_t (&acc)[MT][NT], int tm,
-                                               int tn, int wm, int wn, int lane) {
+                                               int tn, int wm, int wn, int lane, float ainv = 1.f) {
     typedef Frag<FRAG> F;
     constexpr int BM = FRAG * MT * WM, BN = FRAG * NT * WN;
     const int M = p.B * p.Ho * p.Wo;
@@ -131,10 +144,12 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, typename Fra
     // per-element branches the epilogue was ~2000 instructions per wave -- more than ten K-steps of the main loop)
     const int act = p.act;
     const bool has_res = p.res != nullptr, has_gn = p.gn_stats != nullptr, nhwc = p.store == CP_STORE_NHWC;
+    float amax = 0.f;  // running max|y| of this lane's outputs (ConvParams::out_amax)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = tn * BN + wn * (NT * FRAG) + j * FRAG + lcol;
-        const float sc = p.scale ? p.scale[n] : 1.f;
+        // ainv = 2^-e_a of the activation pre-scale (1 for the exact-f32 kernels); scale already carries 2^-e_w
+        const float sc = (p.scale ? p.scale[n] : 1.f) * ainv;
         const float sh = p.shift ? p.shift[n] : 0.f;
         const bool n_ok = n < p.Cout;
         const bool sig_lane = act == CP_ACT_SIGMOID || (act == CP_ACT_SIGMOID_FROM && n >= p.act_from);
@@ -174,6 +189,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, typename Fra
 #pragma unroll
                 for (int r = 0; r < F::NACC; ++r) v[r] = sig_lane ? 1.f / (1.f + expf(-v[r])) : v[r];
             }
+#pragma unroll
+            for (int r = 0; r < F::NACC; ++r) amax = fmaxf(amax, fabsf(v[r]));
             if (has_gn) {
                 // GroupNorm statistics of this 32-row x 32-channel fragment: rows live in registers, the 8 channels
                 // of a group in 8 neighbouring lanes (and the other 16 rows in lane ^ 32)
@@ -237,6 +254,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvParams& p, typename Fra
             }
         }
     }
+    if (p.out_amax) cp_amax_commit(p.out_amax, amax);
 }
 
 // split-K: raw accumulators of this K slice -> partial[slice][m][CoutPad]

@@ -32,8 +32,10 @@ struct LowcParams {
     float* out;        // NHWC [B][Ho][Wo][COUT]
     const void* w_hi;  // B fragments [KSTEPS][COUT/16][64 lanes][8 halfs]
     const void* w_lo;
-    const float* scale;  // folded BatchNorm [COUT]
+    const float* scale;  // folded BatchNorm [COUT] x 2^-e_w of the per-channel weight pre-scale
     const float* shift;
+    const unsigned* in_amax;  // running |max| of the input (ConvParams::in_amax), nullptr = no activation pre-scale
+    unsigned* out_amax;       // receives the output's |max|, nullptr = not tracked
     int B, H, W, Ho, Wo, planes, pad;
 };
 
@@ -80,6 +82,8 @@ __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
             }
     }
 
+    float afwd = 1.f, ainv = 1.f;
+    if (p.in_amax) cp_amax_to_scale(*p.in_amax, &afwd, &ainv);
     // ---- stage the input tile: float32 global -> binary16 hi / lo image in LDS, zero outside the picture ----
     if (NCHW_IN) {
         const size_t plane_sz = (size_t)p.H * p.W;
@@ -96,8 +100,8 @@ __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
                 if (p.planes > 3) v3 = q[3 * plane_sz];
             }
             uint32_t h0, l0, h1, l1;
-            split2(v0, v1, &h0, &l0);
-            split2(v2, v3, &h1, &l1);
+            split2(v0 * afwd, v1 * afwd, &h0, &l0);
+            split2(v2 * afwd, v3 * afwd, &h1, &l1);
             *reinterpret_cast<u32x2*>(img_hi + i * 4) = u32x2{h0, h1};
             *reinterpret_cast<u32x2*>(img_lo + i * 4) = u32x2{l0, l1};
         }
@@ -112,8 +116,8 @@ __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
             if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
                 x = *reinterpret_cast<const float4*>(base + ((size_t)iy * p.W + ix) * CIN + v * 4);
             uint32_t h0, l0, h1, l1;
-            split2(x.x, x.y, &h0, &l0);
-            split2(x.z, x.w, &h1, &l1);
+            split2(x.x * afwd, x.y * afwd, &h0, &l0);
+            split2(x.z * afwd, x.w * afwd, &h1, &l1);
             *reinterpret_cast<u32x2*>(img_hi + px * CIN + v * 4) = u32x2{h0, h1};
             *reinterpret_cast<u32x2*>(img_lo + px * CIN + v * 4) = u32x2{l0, l1};
         }
@@ -126,9 +130,10 @@ __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
     float sc[NF], sh[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        sc[f] = p.scale ? p.scale[f * 16 + pl] : 1.f;
+        sc[f] = (p.scale ? p.scale[f * 16 + pl] : 1.f) * ainv;
         sh[f] = p.shift ? p.shift[f * 16 + pl] : 0.f;
     }
+    float amax = 0.f;
     for (int row = wid / XF; row < TH; row += 4 / XF) {
         const int oy = oy0 + row;
         if (oy >= p.Ho) break;
@@ -167,15 +172,20 @@ __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
             if (ox >= p.Wo) continue;
             float* o = p.out + (((size_t)b * p.Ho + oy) * p.Wo + ox) * COUT + pl;
 #pragma unroll
-            for (int f = 0; f < NF; ++f) o[f * 16] = fmaxf(acc[f][r] * sc[f] + sh[f], 0.f);
+            for (int f = 0; f < NF; ++f) {
+                const float y = fmaxf(acc[f][r] * sc[f] + sh[f], 0.f);
+                amax = fmaxf(amax, y);
+                o[f * 16] = y;
+            }
         }
     }
+    if (p.out_amax) cp_amax_commit(p.out_amax, amax);
 }
 
 // PyTorch [COUT][cin][KS][KS] float32 -> hi / lo B fragments in the K layout described at the top of the file
 template <int CIN, int KS>
 __global__ void pack_lowc_weights(const float* __restrict__ w, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
-                                  int cout, int cin) {
+                                  const float* __restrict__ fwd, int cout, int cin) {
     constexpr int KSTEPS = CIN == 4 ? KS : (KS * KS * CIN + 31) / 32;
     const int nf = cout / 16, total = KSTEPS * nf * 64 * 8;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -191,7 +201,7 @@ __global__ void pack_lowc_weights(const float* __restrict__ w, uint16_t* __restr
             if (tap < KS * KS && ci < cin) v = w[(((size_t)co * cin + ci) * KS + tap / KS) * KS + tap % KS];
         }
         uint32_t h, l;
-        split2(v, 0.f, &h, &l);
+        split2(fwd ? v * fwd[co] : v, 0.f, &h, &l);
         hi[idx] = (uint16_t)(h & 0xffffu);
         lo[idx] = (uint16_t)(l & 0xffffu);
     }
@@ -211,17 +221,20 @@ size_t cp_lowc_weight_halfs(int kind) {
     return kind == 0 ? (size_t)7 * 1 * 512 : kind == 1 ? (size_t)5 * 1 * 512 : (size_t)5 * 2 * 512;
 }
 
-int cp_launch_pack_lowc(int kind, const float* w, void* hi, void* lo, int cin, hipStream_t s) {
-    if (kind == 0) hipLaunchKernelGGL((pack_lowc_weights<4, 7>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, 16, cin);
-    else if (kind == 1) hipLaunchKernelGGL((pack_lowc_weights<16, 3>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, 16, cin);
-    else if (kind == 2) hipLaunchKernelGGL((pack_lowc_weights<16, 3>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, 32, cin);
+int cp_launch_pack_lowc(int kind, const float* w, void* hi, void* lo, const float* fwd, int cin, hipStream_t s) {
+    if (kind == 0) hipLaunchKernelGGL((pack_lowc_weights<4, 7>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, fwd, 16, cin);
+    else if (kind == 1) hipLaunchKernelGGL((pack_lowc_weights<16, 3>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, fwd, 16, cin);
+    else if (kind == 2) hipLaunchKernelGGL((pack_lowc_weights<16, 3>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, fwd, 32, cin);
     else return CP_ERR_INVALID;
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
 int cp_launch_lowc(int kind, const float* in, float* out, const void* w_hi, const void* w_lo, const float* scale,
-                   const float* shift, int B, int H, int W, int planes, hipStream_t s) {
+                   const float* shift, const unsigned* in_amax, unsigned* out_amax, int B, int H, int W, int planes,
+                   hipStream_t s) {
     LowcParams p;
+    p.in_amax = in_amax;
+    p.out_amax = out_amax;
     p.in = in;
     p.out = out;
     p.w_hi = w_hi;

@@ -73,6 +73,8 @@ def lib():
     _sig(L.cp_model_profile, c_int, c_void_p, c_int)
     _sig(L.cp_model_profile_read, c_int, c_void_p, ctypes.POINTER(ctypes.c_double), c_int)
     _sig(L.cp_kernel_variant_name, c_char_p, c_int)
+    _sig(L.cp_model_profile_roles, c_int, c_void_p, ctypes.POINTER(ctypes.c_double), c_int)
+    _sig(L.cp_role_name, c_char_p, c_int)
     _sig(L.cp_pnp_workspace_bytes, c_size_t, c_int)
     _sig(L.cp_pnp_solve, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t)
     _lib = L
@@ -85,7 +87,8 @@ def exported_symbols():
             "cp_model_set_param", "cp_model_finalize", "cp_model_destroy", "cp_model_workspace_bytes",
             "cp_model_forward", "cp_model_forward_tap", "cp_conv2d_workspace_bytes", "cp_conv2d_nhwc",
             "cp_decode_workspace_bytes", "cp_decode", "cp_pnp_workspace_bytes", "cp_pnp_solve", "cp_model_profile", "cp_model_profile_read",
-            "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug", "cp_preprocess", "cp_postprocess_workspace_bytes", "cp_postprocess", "cp_render_gaussians"]
+            "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug", "cp_preprocess", "cp_postprocess_workspace_bytes", "cp_postprocess", "cp_render_gaussians",
+            "cp_model_profile_roles", "cp_role_name"]
 
 
 def _check(rc, what):
@@ -324,6 +327,18 @@ class HipModel(object):
             if buf[v * 4] > 0:
                 out[lib().cp_kernel_variant_name(v).decode()] = dict(
                     launches=int(buf[v * 4]), ms=buf[v * 4 + 1], flops=buf[v * 4 + 2], bytes=buf[v * 4 + 3])
+        return out
+
+    def profile_roles(self):
+        """-> {role: dict(launches, ms, flops, bytes)} of the launches drained by the last profile_read()."""
+        nr = 9  # CP_NUM_ROLES
+        buf = (ctypes.c_double * (nr * 4))()
+        _check(lib().cp_model_profile_roles(self._h, buf, nr), "cp_model_profile_roles")
+        out = OrderedDict()
+        for r in range(nr):
+            if buf[r * 4] > 0:
+                out[lib().cp_role_name(r).decode()] = dict(
+                    launches=int(buf[r * 4]), ms=buf[r * 4 + 1], flops=buf[r * 4 + 2], bytes=buf[r * 4 + 3])
         return out
 
     def workspace_bytes(self, B, H, W):

@@ -128,6 +128,21 @@ int cp_model_set_precision(cp_model* m, int precision);
 int cp_model_profile(cp_model* m, int enable);
 int cp_model_profile_read(cp_model* m, double* out, int num_variants);
 const char* cp_kernel_variant_name(int v);
+/* The same launches grouped by what they compute (the figures BASELINE.json's north_star names: DCNv2 traffic, 1x1
+ * convolution MFMA rate, decode time).  Valid after cp_model_profile_read: out[r*4 + 0..3] = {launches, milliseconds,
+ * algorithmic FLOPs, algorithmic bytes} of role r since the previous read. */
+#define CP_ROLE_CONV 0        /* 3x3 / 7x7 convolutions of the base network and the hourglass */
+#define CP_ROLE_CONV1X1 1     /* 1x1 projections, Root nodes, hourglass skips */
+#define CP_ROLE_DCN 2         /* DCNv2 gather + contraction (pose_dla_dcn.py:386-389) */
+#define CP_ROLE_DCN_OFFSET 3  /* conv_offset_mask Cin->27 (dcn_v2.py:105-111) */
+#define CP_ROLE_HEAD 4        /* 3x3 of a prediction head (fused heads: 3x3 + 1x1) */
+#define CP_ROLE_HEAD_FINAL 5  /* final 1x1 of an un-fused head */
+#define CP_ROLE_GRU 6         /* ConvGRU convolutions (convGRU.py:32-39) */
+#define CP_ROLE_LOWC 7        /* stem / level0 / level1 direct kernels (f16x3 mode) */
+#define CP_ROLE_DECODE 8      /* cp_model_detect's decode launch (both kernels) */
+#define CP_NUM_ROLES 9
+int cp_model_profile_roles(cp_model* m, double* out, int num_roles);
+const char* cp_role_name(int role);
 
 /* ------------------------------------------------------------------------------------------
  * Generic NHWC convolution (exposed for unit tests of the implicit-GEMM kernel).

@@ -131,6 +131,127 @@ def test_dcn_both_precisions_vs_oracle(device, precision):
     assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-5
 
 
+@pytest.fixture
+def f16x3():
+    hip.set_default_precision("f16x3")
+    yield
+    hip.set_default_precision("f32")
+
+
+@pytest.mark.parametrize("xmag", [1e-5, 1e-3, 1e3, 1e5])
+@pytest.mark.parametrize("wmag", [1e-4, 1e-2])
+@pytest.mark.parametrize("k,Cout", [(3, 64), (1, 128), (3, 27)])
+def test_f16x3_conv_is_range_safe(device, f16x3, xmag, wmag, k, Cout):
+    """The split-binary16 mode must not depend on operand magnitude (binary16 has 5 exponent bits; float32, the
+    reference's arithmetic -- dcn_v2_cuda.cu:58 -- has 8): activations down to 1e-5 (hi/lo halves would be subnormal)
+    and up to 1e5 (> 65504 would saturate), weights down to 1e-4.  Operands are pre-scaled by exact powers of two
+    (per-tensor |max| for activations, per output channel for weights), so the error stays <= 2e-5 of the range."""
+    g = torch.Generator().manual_seed(int(k * 100 + Cout))
+    x = torch.randn(2, 64, 20, 24, generator=g) * xmag
+    w = torch.randn(Cout, 64, k, k, generator=g) * wmag
+    ref = F.conv2d(x.double(), w.double(), None, 1, k // 2)
+    out = hip.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(device), w.to(device), None, None, None, 1, k // 2, 0)
+    err = float((out.permute(0, 3, 1, 2).cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err
+
+
+def test_f16x3_conv_wide_dynamic_range_inside_one_tensor(device, f16x3):
+    """A few pixels 2^12 times larger than the rest (one per-tensor scale must serve both): error relative to the
+    range <= 2e-5, and the quiet region keeps float32-class relative accuracy (its |max| is 2^-12 of the tensor's)."""
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 64, 32, 32, generator=g)
+    x[:, :, :4, :4] *= 4096.0
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    out = hip.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(device), w.to(device), None, None, None, 1, 1, 0)
+    o = out.permute(0, 3, 1, 2).cpu().double()
+    assert float((o - ref).abs().max() / ref.abs().max()) < 2e-5
+    quiet = (slice(None), slice(None), slice(8, None), slice(8, None))
+    assert float((o[quiet] - ref[quiet]).abs().max() / ref[quiet].abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("xmag", [1e-5, 1e-3, 1e3, 1e5])
+@pytest.mark.parametrize("wmag", [1e-4, 1e-2])
+def test_f16x3_dcn_is_range_safe(device, f16x3, xmag, wmag):
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(2, 64, 24, 20, generator=g) * xmag
+    w = torch.randn(128, 64, 3, 3, generator=g) * wmag
+    b = torch.randn(128, generator=g) * xmag * wmag
+    off = torch.randn(2, 18, 24, 20, generator=g) * 2.5
+    mask = torch.rand(2, 9, 24, 20, generator=g)
+    ref = odcn.dcn_v2_forward_f64(x, w, b, off, mask)
+    out = hip.dcn_v2_forward(*(t.to(device) for t in (x, w, b, off, mask)), 3, 3, 1, 1, 1, 1, 1, 1, 1).cpu()
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
+def _rescale_bn_convs(sd, f=2.0 ** -8):
+    """Every convolution that feeds an eval-mode BatchNorm gets its weight (and bias) multiplied by f and the BatchNorm
+    compensated (running_mean * f, running_var' = (var + eps) * f^2 - eps), so the network computes the same function
+    with conv weights / pre-normalisation activations 256 times smaller -- what trained checkpoints look like next to
+    the unit-variance synthetic ones."""
+    out = {k: v.clone() for k, v in sd.items()}
+    n = 0
+    for k in sd:
+        if not k.endswith(".running_var"):
+            continue
+        bn = k[: -len(".running_var")]
+        # conv feeding this BatchNorm: `<p>.bn1` <- `<p>.conv1`, `<p>.bn` <- `<p>.conv`, `<p>.1` <- `<p>.0`,
+        # `<p>.actf.0` <- `<p>.conv` (DCN: weight + bias)
+        if bn.endswith(".actf.0"):
+            conv = bn[: -len(".actf.0")] + ".conv"
+        elif bn.rsplit(".", 1)[1].startswith("bn"):
+            conv = bn.rsplit(".", 1)[0] + ".conv" + bn.rsplit(".", 1)[1][2:]
+        else:
+            conv = bn.rsplit(".", 1)[0] + "." + str(int(bn.rsplit(".", 1)[1]) - 1)
+        assert conv + ".weight" in sd, (bn, conv)
+        out[conv + ".weight"] = sd[conv + ".weight"] * f
+        if conv + ".bias" in sd:
+            out[conv + ".bias"] = sd[conv + ".bias"] * f
+        out[bn + ".running_mean"] = sd[bn + ".running_mean"] * f
+        out[k] = (sd[k] + 1e-5) * (f * f) - 1e-5
+        assert float(out[k].min()) > 0
+        n += 1
+    assert n > 40
+    return out
+
+
+@pytest.mark.parametrize("arch", ["dla_34", "dlav1_34"])
+def test_backbone_small_weights_f16x3_vs_oracle(device, arch):
+    """Backbone with every BatchNorm'd convolution's weights x 2^-8 (BatchNorm compensated): the f16x3 mode against the
+    float32 oracle run on the SAME rescaled weights, at the heat-map gate, plus the exact-f32 mode as a control."""
+    heads = synth.HEADS_POSE
+    sd = _rescale_bn_convs(synth.make_state_dict(arch, heads))
+    x = synth.frames(2, seed=53, h=128, w=128)
+    zo = ob.dlaseg_forward(sd, x, heads, arch=arch.split("_")[0])
+    zo0 = ob.dlaseg_forward(synth.make_state_dict(arch, heads), x, heads, arch=arch.split("_")[0])
+    assert float((torch.sigmoid(zo["hm"]) - torch.sigmoid(zo0["hm"])).abs().max()) < 1e-3   # same function
+    for prec in ("f16x3", "f32"):
+        z = hip.HipModel(arch, heads, sd, precision=prec)(x.to(device), sigmoid_hm=True)
+        assert float((z["hm"].cpu() - torch.sigmoid(zo["hm"])).abs().max()) < 1e-3, prec
+        assert float((z["hm_hp"].cpu() - torch.sigmoid(zo["hm_hp"])).abs().max()) < 1e-3, prec
+        for k in ("wh", "hps", "reg", "hp_offset", "scale"):
+            assert float((z[k].cpu() - zo[k]).abs().max()) < 1e-3 * max(1.0, float(zo[k].abs().max())), (prec, k)
+
+
+@pytest.mark.parametrize("arch,B,pick", [("dlav1_34", 32, 21), ("dla_34", 64, 45)])
+def test_backbone_at_bench_batch_spot_parity(device, arch, B, pick):
+    """BASELINE configs[1] / configs[2] sizes (B = 32 dlav1_34, B = 64 dla_34, 512x512, f16x3): one image out of the
+    batch against the same image run alone (split-K differs at B = 1: float32 round-off) and against the CPU oracle."""
+    heads = synth.HEADS_POSE
+    sd = synth.make_state_dict(arch, heads)
+    x = synth.frames(B, seed=61)
+    model = hip.HipModel(arch, heads, sd, precision="f16x3")
+    z = {k: v[pick:pick + 1].cpu() for k, v in model(x.to(device), sigmoid_hm=True).items()}
+    z1 = model(x[pick:pick + 1].to(device), sigmoid_hm=True)
+    for k in heads:
+        assert float((z1[k].cpu() - z[k]).abs().max()) < 2e-4 * max(1.0, float(z[k].abs().max())), k
+    zo = ob.dlaseg_forward(sd, x[pick:pick + 1], heads, arch=arch.split("_")[0])
+    assert float((z["hm"] - torch.sigmoid(zo["hm"])).abs().max()) < 1e-3
+    assert float((z["hm_hp"] - torch.sigmoid(zo["hm_hp"])).abs().max()) < 1e-3
+    for k in ("wh", "hps", "reg", "hp_offset", "scale"):
+        assert float((z[k] - zo[k]).abs().max()) < 1e-3 * max(1.0, float(zo[k].abs().max())), k
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("arch,tracking", CONFIGS)
 def test_backbone_vs_reference_golden(device, arch, tracking, prec):

@@ -39,6 +39,16 @@ def test_argument_validation_without_gpu(built):
     assert built.cp_model_create(b"resnet_18", 0, 1, names, classes, 256, ctypes.byref(h)) == -1
     assert b"arch" in built.cp_last_error()
     assert built.cp_model_create(b"dla_34", 0, 1, names, classes, 100, ctypes.byref(h)) == -1
+    # ConvGRU models: a head the reference's routing table (pose_dla_dcn.py:545-563) leaves out of the output dict is
+    # refused up front (it would otherwise come back as an unwritten tensor)
+    names2 = (ctypes.c_char_p * 2)(b"hm", b"hps_uncertainty")
+    classes2 = (ctypes.c_int * 2)(1, 16)
+    assert built.cp_model_create(b"dlav1_34", 0, 2, names2, classes2, 256, ctypes.byref(h)) == -1
+    assert b"hps_uncertainty" in built.cp_last_error()
+    assert built.cp_model_create(b"dlav1_34", 1, 2, names2, classes2, 256, ctypes.byref(h)) == 0
+    built.cp_model_destroy(h)
+    assert built.cp_model_create(b"dla_34", 0, 2, names2, classes2, 256, ctypes.byref(h)) == 0   # no routing without the GRU
+    built.cp_model_destroy(h)
     # sizes are pure host arithmetic
     assert built.cp_decode_workspace_bytes(32, 100) >= 32 * 9 * 100 * 8
     assert built.cp_pnp_workspace_bytes(10) >= 10 * 288 * 8
