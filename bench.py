@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs2", action="store_true", help="skip the BASELINE configs[2] leg of the default run")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--dbg", type=int, default=0, help="cp_set_debug flags (kernel A/B switches, tuning only)")
     return ap.parse_args()
 
 
@@ -264,6 +265,8 @@ def main():
         import torch.distributed as dist
 
         cpd.init_from_env(backend)
+    if args.dbg:
+        hip.lib().cp_set_debug(args.dbg)
     batch = args.batch or {"decode": 32, "full": 64, "track": 16, "track_gru": 16, "hourglass": 8}[args.workload]
     pipe = Pipeline(args.workload, batch, device, seed=317 + 1000 * rank, precision=args.precision)
 

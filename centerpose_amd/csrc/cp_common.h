@@ -39,15 +39,35 @@ __device__ __forceinline__ void cp_amax_to_scale(unsigned amax_bits, float* fwd,
     *fwd = __uint_as_float((unsigned)(268 - e) << 23);
     *inv = __uint_as_float((unsigned)(e - 14) << 23);
 }
-// wave-reduce a lane's local max|v| and fold it into the slot (float bits of non-negative numbers order like unsigned
-// integers).  The slot is read first: once a few waves have reported, almost every later one finds its maximum already
-// covered and issues no atomic.
+// A tensor's |max| lives in CP_AMAX_SUB sub-slots CP_AMAX_STRIDE uints apart (different cache lines): all waves of a
+// small kernel finish at about the same time, all find the slot still at its old value and all issue their atomic --
+// thousands of same-address atomics serialise at the memory side (measured: +10 us per kernel at batch 1).  Spreading
+// the writers over 32 addresses by workgroup (one atomic per workgroup) cuts that to a handful per address; readers
+// take the max.
+#define CP_AMAX_SUB 32
+#define CP_AMAX_STRIDE 2048  // = |max| slots (tensors) per forward pass
+__device__ __forceinline__ unsigned cp_amax_read(const unsigned* slot) {
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < CP_AMAX_SUB; ++k) m = max(m, slot[k * CP_AMAX_STRIDE]);
+    return m;
+}
+// Block-reduce the lanes' local max|v| (wave shuffle, then one LDS word per wave) and fold it into the block's sub-slot
+// (float bits of non-negative numbers order like unsigned integers).  The sub-slot is read first: later blocks usually
+// find their maximum covered and skip the atomic.  Every thread of the block must call it (it contains a barrier).
 __device__ __forceinline__ void cp_amax_commit(unsigned* slot, float local) {
+    __shared__ float cp_amax_red[16];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) local = fmaxf(local, __shfl_xor(local, o, 64));
-    if ((threadIdx.x & 63) == 0) {
-        const unsigned b = __float_as_uint(local);
-        if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+    if ((threadIdx.x & 63) == 0) cp_amax_red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (int)(blockDim.x + 63) >> 6;
+        float m = cp_amax_red[0];
+        for (int i = 1; i < nw; ++i) m = fmaxf(m, cp_amax_red[i]);
+        unsigned* sub = slot + (blockIdx.x & (CP_AMAX_SUB - 1)) * CP_AMAX_STRIDE;
+        const unsigned b = __float_as_uint(m);
+        if (b > __hip_atomic_load(sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(sub, b);
     }
 }
 #endif
@@ -142,6 +162,8 @@ const char* cp_conv_variant_name(int v);
 bool cp_conv16_supported(const ConvParams& p);
 int cp_launch_conv16(const ConvParams& p, hipStream_t stream);
 int cp_conv16_variant(const ConvParams& p);
+// fused DCNv2 gather + contraction (dcn16.hip); bn = N tile (64 / 128), variant = alternative wave count (tuning)
+int cp_launch_dcn16(const ConvParams& p, int bn, int variant, hipStream_t stream);
 // `fwd` (may be nullptr = 1): per-output-channel power-of-two factor applied before the split, indexed [coff + co]
 int cp_launch_pack_weight16(const float* w, void* hi, void* lo, int Cout, int Cin, int taps, int Kpad16, int coff,
                             const float* fwd, hipStream_t s);
@@ -150,7 +172,8 @@ int cp_launch_pack_weight16(const float* w, void* hi, void* lo, int Cout, int Ci
 int cp_launch_weight_scale(const float* w, int Cout, int per, float* fwd, float* inv, hipStream_t s);
 // out[i] = (scale ? scale[i] : 1) * inv[i]
 int cp_launch_scale16(const float* scale, const float* inv, float* out, int n, hipStream_t s);
-// slot = max(slot, float bits of max|x[0..n)|)  (slot zeroed by the caller); n % 4 == 0, 16-byte aligned
+// |max| of x[0..n) folded into the slot's sub-slots (CP_AMAX_SUB x CP_AMAX_STRIDE uints, zeroed by the caller);
+// n % 4 == 0, 16-byte aligned
 int cp_launch_absmax(const float* x, size_t n, unsigned* slot, hipStream_t s);
 // fused head (see ConvParams::fuse_*): is this 3x3 (+ReLU) -> 1x1 pair eligible; launch; 1x1 weight packing
 // (w1: [C2][Chid] float32 -> two arrays of Chid*32 binary16); slice reduction + bias (+ sigmoid) -> NCHW

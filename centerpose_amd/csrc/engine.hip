@@ -129,7 +129,7 @@ int g_default_precision = CP_PREC_F32;
 // split-K policy: launches with fewer output tiles than kSplitTiles (and >= 8 K steps) are cut into K slices until
 // about kSplitTarget workgroups exist
 constexpr int kSplitTiles = 128, kSplitTarget = 384;  // (384 / 512 measured: B=32 equal, hourglass B=1 latency +7 %)
-int g_dbg = 0;  // cp_set_debug (A/B switches for tests and tuning): 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel, 256 unfused ConvGRU step
+int g_dbg = 0;  // cp_set_debug (A/B switches for tests and tuning): 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel, 256 unfused ConvGRU step, 512 no activation |max| tracking / pre-scale, 1024 previous DCN loop, 2048 alternative DCN wave counts
 
 struct DeformW {
     ConvW offset;  // conv_offset_mask (27 -> 32 padded), shift = bias
@@ -568,15 +568,16 @@ struct Fwd {
     const unsigned* gn_in_amax = nullptr;  // bound on max|relu(a*x + d)| for the GNIN loader's pre-scale
     // |max| slots of this forward's tensors (f16x3 range-safe scaling, ConvParams::in_amax): one zeroed block at the
     // start of the arena, a slot per Tensor in creation order
-    static constexpr int kMaxSlots = 4096;
+    static constexpr int kMaxSlots = CP_AMAX_STRIDE;
+    static constexpr size_t kSlotBytes = (size_t)CP_AMAX_SUB * CP_AMAX_STRIDE * sizeof(unsigned);
     Tensor slots_t;
     unsigned* slots = nullptr;
     int nslots = 0;
     void init_slots() {
-        slots_t.blk = std::make_shared<Block>(&m->arena, (size_t)kMaxSlots * sizeof(unsigned));
-        if (m->dry || m->precision != CP_PREC_F16X3) return;
+        slots_t.blk = std::make_shared<Block>(&m->arena, kSlotBytes);
+        if (m->dry || m->precision != CP_PREC_F16X3 || (g_dbg & 512)) return;  // 512: A/B switch, operands used unscaled
         slots = (unsigned*)slots_t.ptr();
-        if (hipMemsetAsync(slots, 0, (size_t)kMaxSlots * sizeof(unsigned), s) != hipSuccess) chk(CP_ERR_LAUNCH);
+        if (hipMemsetAsync(slots, 0, kSlotBytes, s) != hipSuccess) chk(CP_ERR_LAUNCH);
     }
     unsigned* new_slot() {
         if (!slots) return nullptr;
@@ -1525,7 +1526,7 @@ size_t cp_conv2d_workspace_bytes(int Cin, int Cout, int KH, int KW) {
     // f32 packed weights + (split-f16 path) two binary16 copies + per-channel weight scales (2^e, 2^-e, scale * 2^-e)
     // + the input's |max| slot
     return align_up(kpad * cpad * sizeof(float), 256) + 2 * align_up(kpad * cpad * 2, 256) +
-           3 * align_up(cpad * sizeof(float), 256) + 256;
+           3 * align_up(cpad * sizeof(float), 256) + (size_t)CP_AMAX_SUB * CP_AMAX_STRIDE * sizeof(unsigned);
 }
 
 int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const float* scale, const float* shift,
@@ -1584,7 +1585,8 @@ int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const flo
         float* winv = (float*)((char*)wfwd + csz);
         float* sc16 = (float*)((char*)winv + csz);
         unsigned* slot = (unsigned*)((char*)sc16 + csz);
-        if (hipMemsetAsync(wfwd, 0, 3 * csz + 256, s) != hipSuccess) return CP_ERR_LAUNCH;
+        if (hipMemsetAsync(wfwd, 0, 3 * csz + (size_t)CP_AMAX_SUB * CP_AMAX_STRIDE * sizeof(unsigned), s) != hipSuccess)
+            return CP_ERR_LAUNCH;
         rc = cp_launch_weight_scale(w, Cout, Cin * KH * KW, wfwd, winv, s);
         if (rc == CP_OK) rc = cp_launch_pack_weight16(w, (void*)p.w16_hi, (void*)p.w16_lo, Cout, Cin, KH * KW, p.Kpad16, 0, wfwd, s);
         if (rc == CP_OK) rc = cp_launch_scale16(scale, winv, sc16, Cout, s);
@@ -1664,7 +1666,7 @@ size_t cp_dcnv2_workspace_bytes(int B, int C, int H, int W, int Co) {
     const size_t cpad = align_up((size_t)Co, cp_conv_tile_n(Co));
     return align_up(px * C * 4, 256) + align_up(px * 32 * 4, 256) + align_up(px * Co * 4, 256) +
            align_up((size_t)9 * C * cpad * 4, 256) + align_up(cpad * 4, 256) + 2 * align_up((size_t)9 * C * cpad * 2, 256) +
-           3 * align_up(cpad * 4, 256) + 256;
+           3 * align_up(cpad * 4, 256) + (size_t)CP_AMAX_SUB * CP_AMAX_STRIDE * sizeof(unsigned);
 }
 
 }  // extern "C"
@@ -1740,6 +1742,7 @@ extern "C" int cp_dcnv2_forward(cp_stream_t stream, const float* input, const fl
     p.store = CP_STORE_NHWC;
     p.ldo = Co;
     p.offmask = om;
+    p.dbg = g_dbg;
     if (g_default_precision == CP_PREC_F16X3 && C % 32 == 0) {
         char* w16 = (char*)shift + align_up((size_t)cpad * 4, 256);
         const size_t sz = align_up((size_t)9 * C * cpad * 2, 256);
@@ -1752,7 +1755,8 @@ extern "C" int cp_dcnv2_forward(cp_stream_t stream, const float* input, const fl
         float* winv = (float*)((char*)wfwd + csz);
         float* sc16 = (float*)((char*)winv + csz);
         unsigned* slot = (unsigned*)((char*)sc16 + csz);
-        if (hipMemsetAsync(wfwd, 0, 3 * csz + 256, s) != hipSuccess) return CP_ERR_LAUNCH;
+        if (hipMemsetAsync(wfwd, 0, 3 * csz + (size_t)CP_AMAX_SUB * CP_AMAX_STRIDE * sizeof(unsigned), s) != hipSuccess)
+            return CP_ERR_LAUNCH;
         rc = cp_launch_weight_scale(weight, Co, C * 9, wfwd, winv, s);
         if (rc == CP_OK) rc = cp_launch_pack_weight16(weight, (void*)p.w16_hi, (void*)p.w16_lo, Co, C, 9, p.Kpad16, 0, wfwd, s);
         if (rc == CP_OK) rc = cp_launch_scale16(nullptr, winv, sc16, Co, s);

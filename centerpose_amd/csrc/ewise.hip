@@ -293,7 +293,7 @@ __global__ void gn_affine_kernel(const double* __restrict__ stats, const float* 
     }
     if (y_amax) {
         // |relu(a*x + d)| <= |a| * max|x| + |d|; a few ulps of slack for the rounding of the products
-        const float xm = x_amax ? __uint_as_float(*x_amax) : 0.f;
+        const float xm = x_amax ? __uint_as_float(cp_amax_read(x_amax)) : 0.f;
         cp_amax_commit(y_amax, live ? (fabsf(av) * xm + fabsf(dv)) * 1.0001f : 0.f);
     }
 }

@@ -18,51 +18,9 @@
 // igemm16_kernel (previous loop structure; DCN gather layers).  Requirements: every source's channel count % 32 == 0;
 // the 16-channel layers at the top of the network run in lowc.hip, the <= 16-wide GroupNorm'd final 1x1 heads on the
 // exact-f32 kernel.
-#include "igemm_common.h"
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#include "igemm16_common.h"
 
 namespace {
-
-constexpr int BK16 = 32;
-constexpr int LDH = 32;  // halfs per LDS row: 64 bytes, no padding; 16-byte chunks are XOR-swizzled by the row
-// chunk c of row r lives at chunk position c ^ ((r >> 2) & 3): every ds_read_b128 lane group ({0-3,12-15,20-27}, ...)
-// then hits 16 distinct 16-byte slots of the 256-byte bank row, and two consecutive rows written by a ds_write_b64 /
-// b128 lane group cover 32 distinct banks (measured before the swizzle: 33 % of LDS cycles were bank conflicts).
-__device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
-constexpr int NT16 = 256;
-
-// Raw buffer loads (SRD + 32-bit byte offset): an out-of-range offset returns 0, so halo / invalid taps need no
-// exec-mask branch around the load -- and without control flow between the loads the compiler can wait for tile
-// t+1 with a counted s_waitcnt vmcnt(N) while tile t+2 stays in flight.
-__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-constexpr unsigned OOB = 0xffffffffu;
-constexpr unsigned OOB_BASE = 0xf0000000u;  // + any channel offset (< 64 KiB) is still beyond every supported tensor
-
-struct Split2 {
-    uint32_t hi, lo;  // two binary16 values each
-};
-
-__device__ __forceinline__ uint32_t pk(float a, float b) {
-    fp16x2 v = __builtin_amdgcn_cvt_pkrtz(a, b);
-    return *reinterpret_cast<uint32_t*>(&v);
-}
-
-// (a, b) -> packed hi halves and packed lo halves
-__device__ __forceinline__ Split2 split2(float a, float b) {
-    Split2 s;
-    fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    s.hi = *reinterpret_cast<uint32_t*>(&h);
-    const float ra = a - (float)h.x, rb = b - (float)h.y;
-    s.lo = pk(ra, rb);
-    return s;
-}
 
 // PF2: two register sets for the global->LDS staging, i.e. tile t+2 is in flight while tile t is multiplied (a
 // 32-deep K-step is only ~770 MFMA cycles per wave, shorter than an L2 round trip under load).
@@ -1055,6 +1013,9 @@ int cp_launch_conv16(const ConvParams& p, hipStream_t stream) {
     if (p.offmask) {
         if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.nsrc != 1 || p.H != p.Ho || p.W != p.Wo)
             return CP_ERR_INVALID;
+        // dcn16.hip: the software-pipelined gather kernel; cp_set_debug(1024) keeps the previous un-pipelined loop
+        // (igemm16_kernel<DCN>) for A/B runs, 2048 selects the other wave count of the new kernel
+        if (!(p.dbg & 1024)) return cp_launch_dcn16(p, bn, (p.dbg & 2048) ? 1 : 0, stream);
         return bn == 128 ? launch16<2, 2, 2, 2, true, false>(p, stream) : launch16<2, 1, 2, 2, true, false>(p, stream);
     }
     if (bn == 128) return cat ? launch16<2, 2, 2, 2, false, true>(p, stream) : launch16<2, 2, 2, 2, false, false>(p, stream);

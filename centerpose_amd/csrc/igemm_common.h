@@ -123,10 +123,10 @@ __device__ __forceinline__ void conv_in_scale(const ConvParams& p, float* fwd, f
     *fwd = 1.f;
     *inv = 1.f;
     if (!p.in_amax[0]) return;
-    unsigned mx = *p.in_amax[0];
-    if (p.nsrc > 1 && p.in_amax[1]) mx = max(mx, *p.in_amax[1]);
-    if (p.nsrc > 2 && p.in_amax[2]) mx = max(mx, *p.in_amax[2]);
-    if (p.nsrc > 3 && p.in_amax[3]) mx = max(mx, *p.in_amax[3]);
+    unsigned mx = cp_amax_read(p.in_amax[0]);
+    if (p.nsrc > 1 && p.in_amax[1]) mx = max(mx, cp_amax_read(p.in_amax[1]));
+    if (p.nsrc > 2 && p.in_amax[2]) mx = max(mx, cp_amax_read(p.in_amax[2]));
+    if (p.nsrc > 3 && p.in_amax[3]) mx = max(mx, cp_amax_read(p.in_amax[3]));
     cp_amax_to_scale(mx, fwd, inv);
 }
 

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
     }
 
     float afwd = 1.f, ainv = 1.f;
-    if (p.in_amax) cp_amax_to_scale(*p.in_amax, &afwd, &ainv);
+    if (p.in_amax) cp_amax_to_scale(cp_amax_read(p.in_amax), &afwd, &ainv);
     // ---- stage the input tile: float32 global -> binary16 hi / lo image in LDS, zero outside the picture ----
     if (NCHW_IN) {
         const size_t plane_sz = (size_t)p.H * p.W;

@@ -4,12 +4,16 @@ dict ({'results','boxes','output','tot','load','pre','net','dec','post','merge',
 network, decode and PnP stages executed by libcenterpose_hip.so.  ``run_batch`` is the added batched
 entry point (the reference processes one image per call, base_detector.py:134,431).
 
+CenterPoseTrack (``opt.tracking_task``) and the Kalman baseline (``opt.refined_Kalman``) run the reference's
+per-frame loop (:445-464 previous-frame inputs rendered from the tracks, :501-544 Gaussian fusion of the two keypoint
+estimates, :660-665 ``tracker.step``); the previous-frame heat-maps are drawn on the device (cp_render_gaussians).
+
 Not mirrored (out of scope for the inference hot path): the Debugger drawing
-(debug 1-3 only prints), CenterPoseTrack's host-side tracker / Kalman state (tracking_task, refined_Kalman),
-and the GMM sampling of rep_mode 2.
+(debug 1-3 only prints) and the GMM sampling of rep_mode 2.
 """
 import copy
 import json
+import math
 import os
 import time
 
@@ -17,7 +21,9 @@ import numpy as np
 import torch
 
 from ..models.model import create_model, load_model
-from ..utils.image import get_affine_transform, affine_transform, warp_affine_bilinear
+from ..utils.image import (get_affine_transform, affine_transform, warp_affine_bilinear, gaussian_radius,
+                           draw_gaussian_records)
+from ..utils.tracker import Tracker, Tracker_baseline
 from ..utils.pnp.cuboid_pnp_shell import pnp_shell, finish_detection
 from ..utils.pnp.cuboid_pnp_solver import solve_pnp_batch
 
@@ -53,10 +59,6 @@ class BaseDetector(object):
             opt.device = torch.device('cuda')
         else:
             opt.device = torch.device('cpu')
-        if opt.tracking_task or opt.refined_Kalman:
-            raise NotImplementedError("CenterPoseTrack's host tracker is outside this library's hot path "
-                                      "(SURVEY.md section 8(f) N2); the tracking heads themselves are supported by "
-                                      "create_model / object_pose_decode")
         print('Creating model...')
         self.model = create_model(opt.arch, opt.heads, opt.head_conv, opt)
         self.model = load_model(self.model, opt.load_model)
@@ -70,6 +72,10 @@ class BaseDetector(object):
         self.opt = opt
         self.pause = True
         self.pre_images = None
+        if opt.tracking_task:
+            self.tracker = Tracker(opt)
+        if opt.refined_Kalman:
+            self.tracker = Tracker_baseline(opt)
 
     def process(self, images, pre_images=None, pre_hms=None, pre_inds=None, return_time=False):
         raise NotImplementedError
@@ -136,6 +142,132 @@ class BaseDetector(object):
                 meta[k] = input_meta[k]
         return images, meta
 
+    # ------------------------------------------------------------------ CenterPoseTrack: previous-frame inputs
+    def _hp_confidence(self, det):
+        """Peak value of each vertex Gaussian (base_detector.py:277-305): from the Kalman covariance, from the fused
+        std, or the measured heat-map height."""
+        lo, hi = self.opt.conf_border[self.opt.c][0], self.opt.conf_border[self.opt.c][1]
+        decay = np.exp(np.log(0.15) / (lo - hi))
+        if self.opt.kalman == True and 'kf' in det:  # noqa: E712
+            P = det['kf'].P
+            comb = [np.sqrt(P[4 * i, 4 * i] + P[4 * i + 1, 4 * i + 1]) for i in range(8)]
+        elif self.opt.hps_uncertainty:
+            f = det['kps_fusion_std']
+            comb = [np.sqrt(f[2 * i] + f[2 * i + 1]) for i in range(8)]
+        else:
+            return np.array(det['kps_heatmap_height'])
+        return [np.maximum(1 - decay ** (c - hi), 0) for c in comb]
+
+    def _hp_source(self, det, mode):
+        """Which vertex estimate is re-drawn (normalised image coordinates, centre first; :253-268)."""
+        o = self.opt
+        if mode == 'gt':
+            return np.array(det['kps_gt'][1:])
+        if o.render_hmhp_mode in (0, 1):
+            return np.array(det['kps_ori'][1:])
+        if o.kalman == True or o.scale_pool == True:  # noqa: E712
+            return np.array(det['kps_pnp_kf'][1:]) if 'kps_pnp_kf' in det else np.array(det['kps_mean_kf'][1:])
+        return np.array(det['kps_pnp'][1:]) if 'kps_pnp' in det else np.zeros((8, 2))  # PnP failed: nothing to draw
+
+    def _track_records(self, dets, meta, with_hm, with_hm_hp):
+        """The Gaussians ``_get_additional_inputs`` draws (base_detector.py:150-388), as (channel, x, y, radius, k)
+        records for pre_hm and pre_hm_hp, plus the output-grid centre indices."""
+        o = self.opt
+        t_in, t_out = meta['trans_input'], meta['trans_output']
+        iw, ih, ow, oh = meta['inp_width'], meta['inp_height'], meta['out_width'], meta['out_height']
+        W0, H0 = meta['width'], meta['height']
+        hm, hp, inds = [], [], []
+        if o.empty_pre_hm:
+            return hm, hp, inds
+        if o.gt_pre_hm_hmhp == True or (o.gt_pre_hm_hmhp_first == True and meta['id'] == 0):  # noqa: E712
+            mode = 'gt'
+        else:
+            mode = 'pnp' if o.use_pnp else 'kps'
+        for det in dets:
+            if mode != 'gt' and det['score'] < o.pre_thresh:
+                continue
+            box = self._trans_bbox(det['bbox'], t_in, iw, ih)
+            box_out = self._trans_bbox(det['bbox'], t_out, ow, oh)
+            h, w = box[3] - box[1], box[2] - box[0]
+            if not (h > 0 and w > 0):
+                continue
+            radius = max(0, int(gaussian_radius((math.ceil(h), math.ceil(w)))))
+            ct = np.array([(box[0] + box[2]) / 2, (box[1] + box[3]) / 2], dtype=np.float32).astype(np.int32)
+            if with_hm:
+                k = det['score'] if (mode != 'gt' and o.render_hm_mode == 1) else 1
+                if mode == 'gt' or o.render_hm_mode in (0, 1):
+                    hm.append((0, int(ct[0]), int(ct[1]), radius, k))
+            ct_out = np.array([(box_out[0] + box_out[2]) / 2, (box_out[1] + box_out[3]) / 2], dtype=np.int32)
+            inds.append(ct_out[1] * ow + ct_out[0])
+            if not with_hm_hp:
+                continue
+            if mode == 'kps':
+                src = np.array(det['kps']).reshape((-1, 2))
+            else:
+                src = self._hp_source(det, mode)
+                src[:, 0] = src[:, 0] * W0
+                src[:, 1] = src[:, 1] * H0
+            if mode == 'pnp':
+                spread = np.array(det['kps_fusion_std'] if o.hps_uncertainty == True  # noqa: E712
+                                  else det['kps_heatmap_std']).reshape(-1, 2).astype(np.int32)
+                conf = self._hp_confidence(det)
+            # COCO-style visibility in an integer table, exactly as the reference builds it (floats truncate)
+            pts = np.zeros((8, 3), dtype='int64')
+            for idx, q in enumerate(src):
+                outside = q[0] >= W0 or q[0] < 0 or q[1] < 0 or q[1] >= H0
+                pts[idx] = [q[0], q[1], 1 if outside else 2]
+            for j in range(8):
+                pts[j, :2] = affine_transform(pts[j, :2], t_in)
+                if mode != 'gt':
+                    if not (pts[j, 2] > 1 and 0 <= pts[j, 0] < iw and 0 <= pts[j, 1] < ih):
+                        continue
+                x, y = pts[j, :2].astype(np.int32)
+                if mode == 'pnp' and o.render_hmhp_mode in (0, 2):
+                    if spread[j, 0] > 0:  # the heat-map estimate is sometimes missing
+                        hp.append((j, int(x), int(y), radius, conf[j]))
+                elif mode != 'pnp' or o.render_hmhp_mode in (1, 3):
+                    hp.append((j, int(x), int(y), radius, 1))
+        return hm, hp, inds
+
+    def _get_additional_inputs(self, dets, meta, with_hm=True, with_hm_hp=True):
+        """Render the previous frame's tracks as network inputs: pre_hm [1,1,H,W], pre_hm_hp [1,8,H,W], pre_inds."""
+        hm, hp, inds = self._track_records(dets, meta, with_hm, with_hm_hp)
+        ih, iw = meta['inp_height'], meta['inp_width']
+        dev = self.opt.device
+
+        def render(recs, C):
+            if dev.type == 'cuda':
+                from centerpose_amd import hip as _hip
+                return _hip.render_gaussians(np.array(recs, np.float64).reshape(-1, 5), C, ih, iw, dev)[None]
+            return torch.from_numpy(draw_gaussian_records(recs, C, ih, iw)[None]).to(dev)
+
+        input_hm = render(hm, 1) if with_hm else None
+        input_hm_hp = render(hp, 8) if with_hm_hp else None
+        output_inds = torch.from_numpy(np.array(inds, np.int64).reshape(1, -1)).to(dev)
+        return input_hm, input_hm_hp, output_inds
+
+    def _fuse_keypoints(self, det):
+        """Product of the displacement and heat-map Gaussians per coordinate (base_detector.py:503-536)."""
+        mean, std = [], []
+        dm, ds = det['kps_displacement_mean'], det['kps_displacement_std']
+        hmn, hs = det['kps_heatmap_mean'], det['kps_heatmap_std']
+        for i in range(16):
+            missing = hmn[i] < 0 or hs[i] < 0
+            if self.opt.hps_uncertainty == True:  # noqa: E712
+                if missing:
+                    s_, m_ = ds[i], dm[i]
+                else:
+                    s_ = (ds[i] ** -2 + hs[i] ** -2) ** -0.5
+                    m_ = s_ ** 2 * (ds[i] ** -2 * dm[i] + hs[i] ** -2 * hmn[i])
+            elif missing:
+                s_, m_ = 20, dm[i]
+            else:
+                s_ = hs[i] / np.sqrt(2)
+                m_ = s_ ** 2 * (hs[i] ** -2 * dm[i] + hs[i] ** -2 * hmn[i])
+            mean.append(m_)
+            std.append(s_)
+        return mean, std
+
     # ------------------------------------------------------------------ PnP input assembly
     def _pnp_points(self, det):
         """base_detector.py:549-566"""
@@ -176,6 +308,42 @@ class BaseDetector(object):
         dict_out = {"camera_data": [], "objects": []}
         if 'camera_matrix' in meta:
             dict_out['camera_data'] = np.asarray(meta['camera_matrix']).tolist()
+        o = self.opt
+        if o.tracking_task or o.refined_Kalman:  # one object per live track (:681-731)
+            for t in self.tracker.tracks:
+                obj = {'class': o.c, 'ct': t['ct'], 'bbox': np.array(t['bbox']).tolist(), 'confidence': t['score'],
+                       'kps_displacement_mean': t['kps_displacement_mean'].tolist(),
+                       'kps_heatmap_mean': t['kps_heatmap_mean'].tolist(), 'kps_heatmap_std': t['kps_heatmap_std'].tolist(),
+                       'kps_heatmap_height': t['kps_heatmap_height'].tolist(),
+                       'obj_scale': (t['obj_scale'] / t['obj_scale'][1]).tolist(), 'tracking_id': t['tracking_id']}
+                if o.use_pnp:
+                    if 'location' in t:
+                        obj['location'] = t['location']
+                        obj['quaternion_xyzw'] = t['quaternion_xyzw'].tolist()
+                    if 'kps_pnp' in t:
+                        obj['kps_pnp'] = t['kps_pnp'].tolist()
+                        obj['kps_3d_cam'] = t['kps_3d_cam'].tolist()
+                if o.obj_scale_uncertainty:
+                    obj['obj_scale_uncertainty'] = t['obj_scale_uncertainty'].tolist()
+                if o.kalman:
+                    obj['kps_mean_kf'] = t['kps_mean_kf'].tolist()
+                    obj['kps_std_kf'] = t['kps_std_kf']
+                    if o.use_pnp and 'kps_pnp_kf' in t:
+                        obj['kps_pnp_kf'] = t['kps_pnp_kf'].tolist()
+                        obj['kps_3d_cam_kf'] = t['kps_3d_cam_kf'].tolist()
+                if o.scale_pool == True:  # noqa: E712
+                    obj['obj_scale_kf'] = (t['obj_scale_kf'] / t['obj_scale_kf'][1]).tolist()
+                    obj['obj_scale_uncertainty_kf'] = t['obj_scale_uncertainty_kf'].tolist()
+                if o.hps_uncertainty:
+                    obj['kps_displacement_std'] = t['kps_displacement_std'].tolist()
+                    obj['kps_fusion_mean'] = t['kps_fusion_mean'].tolist()
+                    obj['kps_fusion_std'] = t['kps_fusion_std'].tolist()
+                if o.tracking:
+                    obj['tracking'] = t['tracking'].tolist()
+                if o.tracking_hp:
+                    obj['tracking_hp'] = t['tracking_hp'].tolist()
+                dict_out['objects'].append(obj)
+            return dict_out
         for box in boxes:
             b = box[4]
             obj = {'class': self.opt.c, 'ct': b['ct'], 'bbox': np.array(b['bbox']).tolist(), 'confidence': b['score'],
@@ -222,10 +390,24 @@ class BaseDetector(object):
                 images = torch.from_numpy(np.expand_dims(image, axis=0))
                 meta = meta_inp
             images = images.to(self.opt.device)
+            pre_hms, pre_hm_hp, pre_inds = None, None, None
+            if self.opt.refined_Kalman:
+                self.tracker.init_track(meta)
+            if self.opt.tracking_task:
+                if self.pre_images is None:  # first frame of a video: the frame is its own predecessor
+                    print('Initialize tracking!')
+                    self.pre_images = images
+                    self.tracker.init_track(meta)
+                elif self.opt.gt_pre_hm_hmhp or (self.opt.gt_pre_hm_hmhp_first and meta['id'] == 0):
+                    self.tracker.init_track(meta)
+                if self.opt.pre_hm or self.opt.pre_hm_hp:
+                    pre_hms, pre_hm_hp, pre_inds = self._get_additional_inputs(
+                        self.tracker.tracks, meta, with_hm=self.opt.pre_hm, with_hm_hp=self.opt.pre_hm_hp)
             self._sync()
             pre_process_time = time.time()
             pre_time += pre_process_time - scale_start_time
-            output, dets, forward_time = self.process(images, self.pre_images, None, None, None, return_time=True)
+            output, dets, forward_time = self.process(images, self.pre_images, pre_hms, pre_hm_hp, pre_inds,
+                                                      return_time=True)
             self._sync()
             net_time += forward_time - pre_process_time
             decode_time = time.time()
@@ -239,11 +421,22 @@ class BaseDetector(object):
         merge_outputs_time = time.time()
         merge_time += merge_outputs_time - post_process_time
 
+        if self.opt.tracking_task or self.opt.refined_Kalman:
+            for det in results:
+                m_, s_ = self._fuse_keypoints(det)
+                det['kps_fusion_mean'] = np.array(m_)
+                det['kps_fusion_std'] = np.array(s_)
+
         boxes = []
         if self.opt.use_pnp == True:  # noqa: E712
             boxes = self._pnp_all(results, meta)
         pnp_process_time = time.time()
         pnp_time += pnp_process_time - merge_outputs_time
+        if self.opt.tracking_task:
+            results, boxes = self.tracker.step(results, boxes)
+            self.pre_images = images
+        elif self.opt.refined_Kalman:
+            results, boxes = self.tracker.step(results, boxes)
         end_time = time.time()
         track_time += end_time - pnp_process_time
         tot_time += end_time - start_time
@@ -321,4 +514,5 @@ class BaseDetector(object):
                 json.dump(dict_out, fp)
 
     def reset_tracking(self):
+        self.tracker.reset()
         self.pre_images = None

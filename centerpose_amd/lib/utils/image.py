@@ -90,3 +90,34 @@ def warp_affine_bilinear(img, trans, out_w, out_h):
     out = (tap(y0, x0) * (1 - fx) * (1 - fy) + tap(y0, x0 + 1) * fx * (1 - fy) +
            tap(y0 + 1, x0) * (1 - fx) * fy + tap(y0 + 1, x0 + 1) * fx * fy)
     return out
+
+
+def gaussian_radius(det_size, min_overlap=0.7):
+    """CornerNet radius rule (utils/image.py:103-123): the smallest of the three quadratic roots."""
+    h, w = det_size
+    o = min_overlap
+    roots = []
+    for a, b, c in ((1, h + w, w * h * (1 - o) / (1 + o)), (4, 2 * (h + w), (1 - o) * w * h),
+                    (4 * o, -2 * o * (h + w), (o - 1) * w * h)):
+        roots.append((b + np.sqrt(b ** 2 - 4 * a * c)) / 2)
+    return min(roots)
+
+
+def draw_gaussian_records(records, C, H, W):
+    """Host renderer with the semantics of cp_render_gaussians / draw_umich_gaussian (utils/image.py:126-150):
+    records (channel, x, y, radius, k) -> float32 [C,H,W], merged with max(), clipped to the map."""
+    out = np.zeros((C, H, W), np.float32)
+    for ch, x, y, radius, k in records:
+        ch, x, y, radius = int(ch), int(x), int(y), int(radius)
+        d = 2 * radius + 1
+        yy, xx = np.ogrid[-radius:radius + 1, -radius:radius + 1]
+        sigma = d / 6
+        g = np.exp(-(xx * xx + yy * yy) / (2 * sigma * sigma))
+        g[g < np.finfo(g.dtype).eps * g.max()] = 0
+        left, right = min(x, radius), min(W - x, radius + 1)
+        top, bottom = min(y, radius), min(H - y, radius + 1)
+        dst = out[ch, y - top:y + bottom, x - left:x + right]
+        src = g[radius - top:radius + bottom, radius - left:radius + right]
+        if min(src.shape) > 0 and min(dst.shape) > 0:
+            np.maximum(dst, src * k, out=dst)
+    return out

@@ -122,10 +122,20 @@ class Tracker(object):
                 self.tracks.append(self._start(item))
 
     # ---- one frame --------------------------------------------------------------------------------------------
+    P_STRIDE = 4            # diagonal entries of P read as vertex v's (x, y) variance: P[s*v], P[s*v + 1]
+    PNP_OPENCV_RETURN = True   # the filtered PnP follows opt.show_axes (Tracker) or the default frame (baseline)
+
+    def _det_centres(self, dets):
+        """Detection centres moved back to the previous frame by the predicted ``tracking`` offset [130]."""
+        return [np.asarray(d['ct']) + np.asarray(d['tracking']) for d in dets]
+
+    def _track_centres(self):
+        return [t['ct'] for t in self.tracks]
+
     def _associate(self, dets):
         n, m = len(dets), len(self.tracks)
-        det_ct = np.array([np.asarray(d['ct']) + np.asarray(d['tracking']) for d in dets], np.float32).reshape(n, 2)
-        trk_ct = np.array([t['ct'] for t in self.tracks], np.float32).reshape(m, 2)
+        det_ct = np.array(self._det_centres(dets), np.float32).reshape(n, 2)
+        trk_ct = np.array(self._track_centres(), np.float32).reshape(m, 2)
         trk_area = np.array([_area(t['bbox']) for t in self.tracks], np.float32)
         det_area = np.array([_area(d['bbox']) for d in dets], np.float32)
         trk_cls = np.array([t['cls'] for t in self.tracks], np.int32)
@@ -201,7 +211,8 @@ class Tracker(object):
                     kf = trk['kf']
                     trk['kps_mean_kf'] = np.array([kf.x[4 * v:4 * v + 2] for v in range(8)])
                     kps = trk['kps_mean_kf']
-                    var = np.diag(kf.P).reshape(8, 4)[:, :2]
+                    dg, st = np.diag(kf.P), self.P_STRIDE
+                    var = np.array([[dg[st * v], dg[st * v + 1]] for v in range(8)])
                     trk['kps_std_kf'] = list(np.sqrt(var).reshape(-1))
                     # confidence decays exponentially with the combined std, 0.15 at conf_border[0] [254-262]
                     comb = np.sqrt(var.sum(1))
@@ -217,10 +228,64 @@ class Tracker(object):
                 if opt.use_pnp == True:  # noqa: E712
                     from .pnp.cuboid_pnp_shell import pnp_shell
 
-                    res = pnp_shell(opt, self.meta, trk, kps, scale, OPENCV_RETURN=opt.show_axes)
+                    res = pnp_shell(opt, self.meta, trk, kps, scale,
+                                    OPENCV_RETURN=opt.show_axes if self.PNP_OPENCV_RETURN else False)
                     if res is not None:
                         if np.sum(conf) / 8 > 0.25:
                             boxes.append(res)
                         trk['kps_pnp_kf'], trk['kps_3d_cam_kf'], trk['kps_ori_kf'] = res[0], res[1], res[3]
         self.tracks = out
         return out, boxes
+
+
+class Tracker_baseline(Tracker):
+    """``opt.refined_Kalman``: CenterPose + a position-only Kalman filter (utils/tracker_baseline.py:14-310).  Differences
+    from ``Tracker`` (reference lines of tracker_baseline.py in brackets): only (x, y) of each vertex is observed,
+    H is 16 x 32 [56-63]; the initial covariance block of a vertex is the 2 x 2 broadcast of its two variances [70];
+    the scale pool is a plain average with a placeholder uncertainty [94-101, 267-269]; association uses the raw
+    detection centres against track centres advanced by the mean filtered velocity [121, 134-140]; the read-out
+    takes P[2v], P[2v+1] [251-254]; the filtered PnP always returns the default (OpenGL) frame [276]."""
+    P_STRIDE = 2
+    PNP_OPENCV_RETURN = False
+
+    def init_kf(self, det):
+        kf = KalmanFilter(dim_x=32, dim_z=16)
+        kf.H = np.zeros((16, 32))
+        std = np.asarray(det['kps_fusion_std'], float)
+        for v in range(8):
+            kf.H[2 * v, 4 * v] = 1
+            kf.H[2 * v + 1, 4 * v + 1] = 1
+            kf.F[4 * v, 4 * v + 2] = 1
+            kf.F[4 * v + 1, 4 * v + 3] = 1
+            kf.R[2 * v, 2 * v] *= std[2 * v] ** 2
+            kf.R[2 * v + 1, 2 * v + 1] *= std[2 * v + 1] ** 2
+            # a 2-vector assigned to a 2 x 2 block broadcasts over its rows: [[vx, vy], [vx, vy]]
+            kf.P[4 * v:4 * v + 2, 4 * v:4 * v + 2] = [kf.R[2 * v, 2 * v], kf.R[2 * v + 1, 2 * v + 1]]
+        mean = np.asarray(det['kps_fusion_mean'], float)
+        for v in range(8):
+            kf.x[4 * v:4 * v + 2] = mean[2 * v:2 * v + 2].reshape(-1, 1)
+        return kf
+
+    def update_kf(self, det):
+        z = np.asarray(det['kps_fusion_mean'], float).reshape(16).copy()
+        R = np.diag(np.asarray(det['kps_fusion_std'], float).reshape(16) ** 2)
+        det['kf'].update(z, R=R)
+
+    @staticmethod
+    def update_scale_pool(det):
+        mean = np.zeros(3)
+        for sample, _ in det['scale_pool']:
+            mean += np.array(sample)
+        return mean / len(det['scale_pool']), np.array([0, 0, 0])  # the reference stores a placeholder uncertainty
+
+    def _det_centres(self, dets):
+        return [d['ct'] for d in dets]
+
+    def _track_centres(self):
+        out = []
+        for t in self.tracks:
+            v = np.array([0, 0]).astype('float64')
+            for i in range(8):
+                v += np.array(t['kf'].x[4 * i + 2:4 * i + 4]).flatten()
+            out.append(t['ct'] + v / 8)
+        return out
