@@ -94,7 +94,14 @@ class Pipeline(object):
         xs = [synth.frames(min(8, batch - i), seed=seed + i).to(device) for i in range(0, batch, 8)]
         self.x = torch.cat(xs, 0).contiguous()
         self.cam = torch.tensor([663.0287679036459, 663.0287679036459, 300.2775065104167, 395.00066121419275],
-                                dtype=torch.float64, device=device)  # demo.py:143-144
+                                dtype=torch.float64, device=device).repeat(batch, 1).contiguous()  # demo.py:143-144
+        # 512x512 frames, fix_res: c = (256, 256), s = 512 (base_detector.py:110-114) -> inverse affine grid -> image
+        from centerpose_amd.lib.utils.image import get_affine_transform
+        import numpy as np
+        m = np.zeros((batch, 8))
+        m[:, :6] = get_affine_transform(np.array([256.0, 256.0], np.float32), 512.0, 0, (128, 128), inv=1).reshape(-1)
+        m[:, 6] = 512.0 / 128
+        self.meta = torch.from_numpy(m).to(device)
 
     def step(self, x=None, graph=False):
         if x is None:
@@ -113,18 +120,11 @@ class Pipeline(object):
                                  K=100, rep_mode=1, fit_gaussian=True, balance=2.0)
             # the tracker of every video needs all detections: one RCCL all-gather of the fixed-size records
             return cpd.allgather_detections(det)
-        if self.workload != "full":
-            return det
-        # PnP input assembly for rep_mode 1 (base_detector.py:558-566): per vertex (displacement, heat-map),
-        # output-grid -> input-image scale (x4); every detection above vis_thresh 0.3 (opts.py:68)
-        B, K = det.shape[0], det.shape[1]
-        keep = det[..., 4] > 0.3
-        d = det[keep]
-        disp = d[:, 46:62].reshape(-1, 8, 1, 2)
-        hmk = d[:, 78:94].reshape(-1, 8, 1, 2)
-        pts = torch.cat([disp, hmk], 2).reshape(-1, 16, 2)
-        pts = torch.where(pts == -10000, pts, pts * 4.0)
-        poses = hip.pnp_solve(pts, d[:, 22:25], self.cam.expand(pts.shape[0], 4))
+        # configs[2]: post-process + soft-NMS (cp_postprocess), PnP input assembly for rep_mode 1 and the batched solve
+        # (cp_pnp_from_post) -- library launches only, no torch indexing and no host synchronisation inside the step
+        n = det.shape[0]
+        post, cnt = hip.postprocess(det, self.meta[:n], 0.3, nms=True)
+        poses = hip.pnp_from_post(post, cnt, self.cam[:n], rep_mode=1)
         return det, poses
 
 

@@ -156,12 +156,15 @@ int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream);
 // K steps (of 16 for the f32 kernels, 32 for f16x3) and output tiles of the launch cp_launch_conv[16] would make
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 27
+#define CP_NUM_CONV_VARIANTS 30
 #define CP_VARIANT_GRU 26
 // split-f16 ("f16x3") implicit GEMM (igemm16.hip)
 bool cp_conv16_supported(const ConvParams& p);
 int cp_launch_conv16(const ConvParams& p, hipStream_t stream);
 int cp_conv16_variant(const ConvParams& p);
+// halo-resident 3x3 / stride-1 convolution (halo16.hip): eligibility and launch (bn = N tile 32 / 64 / 128)
+bool cp_halo16_supported(const ConvParams& p);
+int cp_launch_halo16(const ConvParams& p, int bn, hipStream_t stream);
 // fused DCNv2 gather + contraction (dcn16.hip); bn = N tile (64 / 128), variant = alternative wave count (tuning)
 int cp_launch_dcn16(const ConvParams& p, int bn, int variant, hipStream_t stream);
 // `fwd` (may be nullptr = 1): per-output-channel power-of-two factor applied before the split, indexed [coff + co]
@@ -256,10 +259,13 @@ size_t cp_pnp_ws_bytes(int N);
 int cp_launch_pnp(hipStream_t s, const float* pts, const float* scale, const double* cam, int N, int npts, double* out,
                   void* ws);
 
-int cp_launch_preprocess(const unsigned char* img, int H, int W, const float* minv6, const float* mean3,
+int cp_launch_preprocess(const unsigned char* img, int H, int W, const double* trans6, const float* mean3,
                          const float* std3, float* out, int OH, int OW, hipStream_t s);
+int cp_launch_resize_u8(const unsigned char* img, int H, int W, int C, unsigned char* out, int OH, int OW, hipStream_t s);
 
 // device post-process + soft-NMS (post.hip); record layout CP_POST_* in include/centerpose_hip.h
 int cp_launch_postprocess(const float* det, int B, int K, const double* meta, double vis_thresh, int nms,
                           float div_scale, double* out, int* count, double* ws, hipStream_t s);
+int cp_launch_pnp_assemble(const double* post, const int* count, int B, int K, int npts, const double* cam_img, float* pts,
+                           float* scale, double* cam, hipStream_t s);
 int cp_launch_render_gaussians(const double* recs, int N, float* out, int C, int H, int W, hipStream_t s);

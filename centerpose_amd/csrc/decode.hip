@@ -4,9 +4,10 @@
 // utils.py:43-47; replaces ~60 ATen kernels, 5-9 full-map transposes and a B x 8 x K Python loop with
 // D2H syncs (decode.py:191-252) by two launches.
 //
-//   peaks_kernel   one workgroup (1024 lanes = 16 wavefronts) per (image, map): optional in-place
-//                  sigmoid, NMS, then an exact radix select of the K largest (value desc, index asc)
-//                  on register-resident keys, and a 128-wide bitonic sort of the winners in LDS.
+//   peaks_kernel   one workgroup (1024 lanes = 16 wavefronts) per (image, map): the map is read once (coalesced
+//                  16-byte loads, optional in-place sigmoid) into LDS, NMS from LDS, then an exact radix select of
+//                  the K largest (value desc, index asc) on register-resident keys -- over the positive keys only
+//                  when they fill the top K -- and a 128-wide bitonic sort of the winners in LDS.
 //   assoc_kernel   one workgroup per (image, joint): candidate table in LDS, one lane per detection
 //                  scans the K candidates (float ops in the reference's order, no FMA contraction so
 //                  argmin / threshold decisions match the CPU bit for bit).
@@ -56,111 +57,195 @@ __device__ int block_excl_scan(int v, int* sh /*[17]*/, int* total) {
     return r;
 }
 
+// block-wide sums of two ints per lane (1024 lanes)
+__device__ void block_sum2(int a, int b, int* sh /*[34]*/, int* ta, int* tb) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[w] = a; sh[16 + w] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int x = 0, y = 0;
+        for (int i = 0; i < PK_THREADS / 64; ++i) { x += sh[i]; y += sh[16 + i]; }
+        sh[32] = x;
+        sh[33] = y;
+    }
+    __syncthreads();
+    *ta = sh[32];
+    *tb = sh[33];
+    __syncthreads();
+}
+
 // maps: NCHW.  Block (m, b): m == 0 -> hm[b, 0], m >= 1 -> hm_hp[b, m-1].
+//
+// A lane owns PK_G groups of four consecutive pixels, group g of lane t = pixels 4 (1024 g + t) .. + 3: the map is read
+// once with coalesced 16-byte loads (the first version gave each lane 16 consecutive pixels = a 64-byte lane stride and
+// read the 8 NMS neighbours of every pixel from global memory) and staged in LDS, from which the 3x3 maximum of a group
+// takes 3 x (one 16-byte + two 4-byte) reads.  After NMS nearly every key is the suppressed value +0: histogramming
+// those through LDS atomics meant ~15000 serialised updates of ONE bin per pass, which was most of the kernel's time.
+// Keys are therefore classed first -- positive / zero / negative -- and the radix select only runs over the positive
+// ones when they already fill the top K (always, for sigmoid heat-maps); the zeros are taken by index when they do not;
+// only maps that need negative values walk the general path.
+constexpr int PK_G = 4;
+constexpr uint32_t ZKEY = 0x80000000u;  // f2ord(+0.0f)
+
 __global__ __launch_bounds__(PK_THREADS) void peaks_kernel(float* __restrict__ hm, float* __restrict__ hm_hp,
                                                            int J, int H, int W, int K, int apply_sigmoid,
                                                            float* __restrict__ pk_score, int* __restrict__ pk_ind) {
     const int mi = blockIdx.x, b = blockIdx.y, nm = gridDim.x;
-    const int HW = H * W;
+    const int HW = H * W, n4 = HW >> 2;
     float* map = (mi == 0) ? hm + (size_t)b * HW : hm_hp + ((size_t)b * J + (mi - 1)) * HW;
+    __shared__ __attribute__((aligned(16))) float smap[PK_THREADS * PK_NPT];  // 64 KB: the whole map
     __shared__ int hist[256];
-    __shared__ int scan_sh[17];
+    __shared__ int scan_sh[34];
     __shared__ int sel[2];  // digit, need
     __shared__ unsigned long long list[128];
     __shared__ int cnt;
     const int tid = threadIdx.x;
-    const int p0 = tid * PK_NPT;
 
-    if (apply_sigmoid) {
-        for (int i = 0; i < PK_NPT; ++i) {
-            const int p = p0 + i;
-            if (p < HW) map[p] = 1.f / (1.f + expf(-map[p]));
-        }
-        __syncthreads();
-    }
-    // ---- NMS: key = ordered bits of (v * (hmax == v)) ----
-    uint32_t key[PK_NPT];
+    float4 v[PK_G];
 #pragma unroll
-    for (int i = 0; i < PK_NPT; ++i) {
-        const int p = p0 + i;
-        uint32_t k = 0u;  // below every real key
-        if (p < HW) {
-            const int y = p / W, x = p - y * W;
-            const float v = map[p];
-            float mx = v;
+    for (int g = 0; g < PK_G; ++g) {
+        const int i4 = g * PK_THREADS + tid;
+        v[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i4 < n4) {
+            v[g] = reinterpret_cast<const float4*>(map)[i4];
+            if (apply_sigmoid) {
+                v[g].x = 1.f / (1.f + expf(-v[g].x));
+                v[g].y = 1.f / (1.f + expf(-v[g].y));
+                v[g].z = 1.f / (1.f + expf(-v[g].z));
+                v[g].w = 1.f / (1.f + expf(-v[g].w));
+                reinterpret_cast<float4*>(map)[i4] = v[g];
+            }
+            reinterpret_cast<float4*>(smap)[i4] = v[g];
+        }
+    }
+    __syncthreads();
+    // ---- NMS: key = ordered bits of (v * (hmax == v)) ----
+    uint32_t key[PK_G * 4];
+    int n_pos = 0, n_zero = 0;
+    const float NINF = -__builtin_huge_valf();
+#pragma unroll
+    for (int g = 0; g < PK_G; ++g) {
+        const int i4 = g * PK_THREADS + tid;
+        if (i4 < n4) {
+            const int p = i4 << 2;
+            const int y = p / W, x0 = p - y * W;  // W % 4 == 0: the four pixels share a row
+            float m0 = NINF, m1 = NINF, m2 = NINF, m3 = NINF;
+#pragma unroll
             for (int dy = -1; dy <= 1; ++dy) {
                 const int yy = y + dy;
                 if (yy < 0 || yy >= H) continue;
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int xx = x + dx;
-                    if (xx < 0 || xx >= W) continue;
-                    mx = fmaxf(mx, map[yy * W + xx]);
-                }
+                const int rb = yy * W + x0;
+                const float4 c = *reinterpret_cast<const float4*>(smap + rb);
+                const float l = x0 > 0 ? smap[rb - 1] : NINF, r = x0 + 4 < W ? smap[rb + 4] : NINF;
+                m0 = fmaxf(m0, fmaxf(l, fmaxf(c.x, c.y)));
+                m1 = fmaxf(m1, fmaxf(c.x, fmaxf(c.y, c.z)));
+                m2 = fmaxf(m2, fmaxf(c.y, fmaxf(c.z, c.w)));
+                m3 = fmaxf(m3, fmaxf(c.z, fmaxf(c.w, r)));
             }
-            const float kept = (mx == v) ? v : v * 0.0f;  // heat * keep (decode.py:23)
-            k = f2ord(kept + 0.0f);                      // -0 -> +0 so equal values tie
-            if (k == 0u) k = 1u;
+            const float vv[4] = {v[g].x, v[g].y, v[g].z, v[g].w}, mm[4] = {m0, m1, m2, m3};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float kept = (mm[e] == vv[e]) ? vv[e] : vv[e] * 0.0f;  // heat * keep (decode.py:23)
+                uint32_t k = f2ord(kept + 0.0f);                            // -0 -> +0 so equal values tie
+                if (k == 0u) k = 1u;
+                key[g * 4 + e] = k;
+                n_pos += k > ZKEY ? 1 : 0;
+                n_zero += k == ZKEY ? 1 : 0;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) key[g * 4 + e] = 0u;  // below every real key
         }
-        key[i] = k;
     }
-    // ---- radix select: K-th largest key ----
-    uint32_t prefix = 0u, maskb = 0u;
+    int tot_pos, tot_zero;
+    block_sum2(n_pos, n_zero, scan_sh, &tot_pos, &tot_zero);
+
+    // ---- K-th largest key: radix select over the class that contains it ----
+    uint32_t prefix = 0u;
     int need = K;
-    for (int pass = 3; pass >= 0; --pass) {
-        const int shift = pass * 8;
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
+    if (tot_pos < K && tot_pos + tot_zero >= K) {
+        prefix = ZKEY;  // every positive key, then zeros by ascending index
+        need = K - tot_pos;
+    } else {
+        const uint32_t floor_excl = tot_pos >= K ? ZKEY : 0u;  // histogram only keys above this
+        uint32_t maskb = 0u;
+        for (int pass = 3; pass >= 0; --pass) {
+            const int shift = pass * 8;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
 #pragma unroll
-        for (int i = 0; i < PK_NPT; ++i)
-            if (key[i] != 0u && (key[i] & maskb) == prefix) atomicAdd(&hist[(key[i] >> shift) & 255u], 1);
-        __syncthreads();
-        if (tid < 64) {
-            // lane l owns bins 4l..4l+3; suffix sums over lanes (high digits first)
-            const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-            const int s = h0 + h1 + h2 + h3;
-            int suf = s;  // inclusive suffix sum: lanes >= tid
+            for (int i = 0; i < PK_G * 4; ++i)
+                if (key[i] > floor_excl && (key[i] & maskb) == prefix) atomicAdd(&hist[(key[i] >> shift) & 255u], 1);
+            __syncthreads();
+            if (tid < 64) {
+                // lane l owns bins 4l..4l+3; suffix sums over lanes (high digits first)
+                const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                const int s = h0 + h1 + h2 + h3;
+                int suf = s;  // inclusive suffix sum: lanes >= tid
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int y = __shfl_down(suf, o, 64);
-                if (tid + o < 64) suf += y;
-            }
-            const int above = suf - s;  // keys in higher lanes' bins
-            if (above < need && need <= suf) {
-                int c = above, d = 4 * tid + 3;
-                const int hh[4] = {h0, h1, h2, h3};
-                for (int q = 3; q >= 0; --q) {
-                    if (c + hh[q] >= need) { d = 4 * tid + q; break; }
-                    c += hh[q];
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int y = __shfl_down(suf, o, 64);
+                    if (tid + o < 64) suf += y;
                 }
-                sel[0] = d;
-                sel[1] = need - c;
+                const int above = suf - s;  // keys in higher lanes' bins
+                if (above < need && need <= suf) {
+                    int c = above, d = 4 * tid + 3;
+                    const int hh[4] = {h0, h1, h2, h3};
+                    for (int q = 3; q >= 0; --q) {
+                        if (c + hh[q] >= need) { d = 4 * tid + q; break; }
+                        c += hh[q];
+                    }
+                    sel[0] = d;
+                    sel[1] = need - c;
+                }
             }
+            __syncthreads();
+            prefix |= ((uint32_t)sel[0]) << shift;
+            maskb |= 0xffu << shift;
+            need = sel[1];
+            __syncthreads();
         }
-        __syncthreads();
-        prefix |= ((uint32_t)sel[0]) << shift;
-        maskb |= 0xffu << shift;
-        need = sel[1];
-        __syncthreads();
     }
-    // prefix = K-th largest key; need = how many keys == prefix to take (lowest indices first)
-    int my_eq = 0;
+    // prefix = K-th largest key; need = how many keys == prefix to take (lowest pixel indices first)
+    int my_eq = 0, dummy = 0;
 #pragma unroll
-    for (int i = 0; i < PK_NPT; ++i) my_eq += (key[i] == prefix) ? 1 : 0;
+    for (int i = 0; i < PK_G * 4; ++i) my_eq += (key[i] == prefix) ? 1 : 0;
     int total_eq;
-    int rank = block_excl_scan(my_eq, scan_sh, &total_eq);
+    block_sum2(my_eq, 0, scan_sh, &total_eq, &dummy);
     if (tid == 0) cnt = 0;
     if (tid < 128) list[tid] = 0ull;
     __syncthreads();
+    const bool all_eq = total_eq <= need;  // no tie at the threshold: every equal key is taken, no ranking needed
+    int taken_before = 0;                  // equal keys in lower-indexed groups (pixel order: group, lane, element)
 #pragma unroll
-    for (int i = 0; i < PK_NPT; ++i) {
-        bool take = key[i] > prefix;
-        if (key[i] == prefix) {
-            take = rank < need;
-            ++rank;
+    for (int g = 0; g < PK_G; ++g) {
+        int rank = 0;
+        if (!all_eq) {
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c += key[g * 4 + e] == prefix ? 1 : 0;
+            int tot_g;
+            rank = taken_before + block_excl_scan(c, scan_sh, &tot_g);
+            taken_before += tot_g;
         }
-        if (take && key[i] != 0u) {
-            const int slot = atomicAdd(&cnt, 1);
-            if (slot < 128) list[slot] = ((unsigned long long)key[i] << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(p0 + i));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t k = key[g * 4 + e];
+            bool take = k > prefix;
+            if (k == prefix) {
+                take = all_eq || rank < need;
+                ++rank;
+            }
+            if (take && k != 0u) {
+                const int slot = atomicAdd(&cnt, 1);
+                const uint32_t p = (uint32_t)(((g * PK_THREADS + tid) << 2) + e);
+                if (slot < 128) list[slot] = ((unsigned long long)k << 32) | (unsigned long long)(0xffffffffu - p);
+            }
         }
     }
     __syncthreads();
@@ -408,7 +493,7 @@ int cp_launch_decode(hipStream_t s, int B, int J, int H, int W, float* hm, const
                      const float* hps_unc, const float* scale, const float* scale_unc, const float* reg, float* hm_hp,
                      const float* hp_offset, const float* tracking, const float* tracking_hp, int K, int rep_mode,
                      int fit_gaussian, float balance, int legacy_bool_mask, int apply_sigmoid, float* det, void* ws) {
-    if (H * W > PK_THREADS * PK_NPT || H * W < K || K < 1 || K > 128 || J < 1) return CP_ERR_INVALID;
+    if (H * W > PK_THREADS * PK_NPT || H * W < K || K < 1 || K > 128 || J < 1 || W % 4 != 0) return CP_ERR_INVALID;
     float* pk_score = (float*)ws;
     int* pk_ind = (int*)((char*)ws + (size_t)B * (J + 1) * K * 4);
     hipLaunchKernelGGL(peaks_kernel, dim3(J + 1, B), dim3(PK_THREADS), 0, s, hm, hm_hp, J, H, W, K, apply_sigmoid,

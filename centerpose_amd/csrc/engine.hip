@@ -1601,12 +1601,18 @@ int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const flo
     return cp_launch_conv(p, s);
 }
 
-int cp_preprocess(cp_stream_t stream, const unsigned char* image_hwc_bgr, int H, int W, const float* inv_trans6,
+int cp_preprocess(cp_stream_t stream, const unsigned char* image_hwc_bgr, int H, int W, const double* trans6,
                   const float* mean3, const float* std3, float* out_chw, int out_h, int out_w) {
-    if (!image_hwc_bgr || !inv_trans6 || !mean3 || !std3 || !out_chw || H < 1 || W < 1 || out_h < 1 || out_w < 1)
+    if (!image_hwc_bgr || !trans6 || !mean3 || !std3 || !out_chw || H < 1 || W < 1 || out_h < 1 || out_w < 1)
         return fail(CP_ERR_INVALID, "bad argument");
-    return cp_launch_preprocess(image_hwc_bgr, H, W, inv_trans6, mean3, std3, out_chw, out_h, out_w,
-                                (hipStream_t)stream);
+    return cp_launch_preprocess(image_hwc_bgr, H, W, trans6, mean3, std3, out_chw, out_h, out_w, (hipStream_t)stream);
+}
+
+int cp_resize_u8(cp_stream_t stream, const unsigned char* image_hwc, int H, int W, int C, unsigned char* out_hwc, int out_h,
+                 int out_w) {
+    if (!image_hwc || !out_hwc || H < 1 || W < 1 || C < 1 || C > 4 || out_h < 1 || out_w < 1)
+        return fail(CP_ERR_INVALID, "bad argument");
+    return cp_launch_resize_u8(image_hwc, H, W, C, out_hwc, out_h, out_w, (hipStream_t)stream);
 }
 
 int cp_render_gaussians(cp_stream_t stream, const double* recs, int N, float* out, int C, int H, int W, int clear) {
@@ -1639,6 +1645,34 @@ int cp_pnp_solve(cp_stream_t stream, const float* pts, const float* scale, const
     if (npts != 8 && npts != 16) return fail(CP_ERR_INVALID, "npts must be 8 or 16");
     if (workspace_bytes < cp_pnp_ws_bytes(N)) return fail(CP_ERR_INVALID, "workspace too small");
     return cp_launch_pnp((hipStream_t)stream, pts, scale, cam, N, npts, out, workspace);
+}
+
+// workspace: [pts B*K*16*2 f32][scale B*K*3 f32][cam B*K*4 f64][solver workspace]
+size_t cp_pnp_from_post_workspace_bytes(int B, int K) {
+    if (B < 1 || K < 1) return 0;
+    const size_t n = (size_t)B * K;
+    return align_up(n * 32 * 4, 256) + align_up(n * 3 * 4, 256) + align_up(n * 4 * 8, 256) + cp_pnp_ws_bytes((int)n);
+}
+
+int cp_pnp_from_post(cp_stream_t stream, const double* post, const int* count, int B, int K, int rep_mode,
+                     const double* cam, double* out, void* workspace, size_t workspace_bytes) {
+    if (!post || !count || !cam || !out || !workspace || B < 1 || K < 1) return fail(CP_ERR_INVALID, "bad argument");
+    if (rep_mode < 0 || rep_mode > 4 || rep_mode == 2)
+        return fail(CP_ERR_INVALID, "rep_mode 0, 1, 3 or 4 (2 samples a GMM with numpy's RNG: host only)");
+    if (workspace_bytes < cp_pnp_from_post_workspace_bytes(B, K)) return fail(CP_ERR_INVALID, "workspace too small");
+    const size_t n = (size_t)B * K;
+    const int npts = rep_mode == 1 ? 16 : 8;
+    char* w = (char*)workspace;
+    float* pts = (float*)w;
+    w += align_up(n * 32 * 4, 256);
+    float* scale = (float*)w;
+    w += align_up(n * 3 * 4, 256);
+    double* camn = (double*)w;
+    w += align_up(n * 4 * 8, 256);
+    int rc = cp_launch_pnp_assemble(post, count, B, K, npts, cam, pts, scale, camn, (hipStream_t)stream);
+    if (rc != CP_OK) return fail(rc, "pnp assemble launch failed");
+    rc = cp_launch_pnp((hipStream_t)stream, pts, scale, camn, (int)n, npts, out, w);
+    return rc == CP_OK ? CP_OK : fail(rc, "pnp launch failed");
 }
 
 size_t cp_decode_workspace_bytes(int B, int K) { return cp_decode_ws_bytes(B, 8, K); }

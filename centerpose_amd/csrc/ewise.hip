@@ -298,13 +298,15 @@ __global__ void gn_affine_kernel(const double* __restrict__ stats, const float* 
     }
 }
 
-// BaseDetector.pre_process on device (base_detector.py:127-134): warpAffine(INTER_LINEAR, constant 0 border) of an
-// 8-bit HWC BGR frame to the network input size, then (x / 255 - mean) / std, written NCHW float32.  `minv` maps
-// output pixel (x, y) to source coordinates (the inverse of trans_input).  Float bilinear weights (cv2 uses 5-bit
-// fixed-point weights, so values can differ from cv2 by a few 1/255 steps).
+// BaseDetector.pre_process on device (base_detector.py:127-134): cv2.warpAffine(INTER_LINEAR, constant 0 border) of an
+// 8-bit HWC BGR frame to the network input size, then (x / 255 - mean) / std, written NCHW float32.
+// The warp follows OpenCV's fixed-point arithmetic (imgwarp.cpp WarpAffineInvoker + remapBilinear, restated in
+// oracle/cv_emul.py): source coordinates with 10 fractional bits (round-half-even of m * x * 1024, + 16), reduced to 5,
+// integer tap weights (32 - fx)(32 - fy) * 32 that sum to 2^15, result (sum + 2^14) >> 15 as an 8-bit value -- so the
+// network sees exactly the grey levels the reference's pre-process produces, not a float blend of them.
 struct PreParams {
-    float m[6];
-    float mean[3], inv_std[3];
+    double m[6];  // INVERSE map (destination -> source), float64 as cv::invertAffineTransform leaves it
+    double mean[3], std[3];
 };
 
 __global__ void preprocess_kernel(const unsigned char* __restrict__ img, int H, int W, float* __restrict__ out, int OH,
@@ -312,25 +314,65 @@ __global__ void preprocess_kernel(const unsigned char* __restrict__ img, int H, 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= OH * OW) return;
     const int y = i / OW, x = i - y * OW;
-    const float sx = pp.m[0] * x + pp.m[1] * y + pp.m[2];
-    const float sy = pp.m[3] * x + pp.m[4] * y + pp.m[5];
-    const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
-    const float fx = sx - x0, fy = sy - y0;
-    float acc[3] = {0.f, 0.f, 0.f};
+    // rint() = lrint / cvRound: round half to even
+    const long long adelta = (long long)rint(pp.m[0] * (double)x * 1024.0), bdelta = (long long)rint(pp.m[3] * (double)x * 1024.0);
+    const long long X0 = (long long)rint((pp.m[1] * (double)y + pp.m[2]) * 1024.0) + 16;
+    const long long Y0 = (long long)rint((pp.m[4] * (double)y + pp.m[5]) * 1024.0) + 16;
+    const long long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+    const long long sx = X >> 5, sy = Y >> 5;
+    const int fx = (int)(X & 31), fy = (int)(Y & 31);
+    int acc[3] = {0, 0, 0};
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-            const int xx = x0 + dx, yy = y0 + dy;
+            const long long xx = sx + dx, yy = sy + dy;
             if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-            const float wgt = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy);
-            const unsigned char* px = img + ((size_t)yy * W + xx) * 3;
+            const int wgt = (dx ? fx : 32 - fx) * (dy ? fy : 32 - fy) * 32;
+            const unsigned char* px = img + ((size_t)yy * W + (size_t)xx) * 3;
             acc[0] += wgt * px[0];
             acc[1] += wgt * px[1];
             acc[2] += wgt * px[2];
         }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out[(size_t)c * OH * OW + i] = (acc[c] / 255.f - pp.mean[c]) * pp.inv_std[c];
+    for (int c = 0; c < 3; ++c) {
+        const int v8 = (acc[c] + (1 << 14)) >> 15;
+        // numpy: (uint8 / 255. - mean) / std in float64, then .astype(float32)
+        out[(size_t)c * OH * OW + i] = (float)(((double)v8 / 255.0 - pp.mean[c]) / pp.std[c]);
+    }
+}
+
+// cv2.resize(img, (OW, OH)) (INTER_LINEAR) of an 8-bit HWC frame, OpenCV's fixed-point form (resize.cpp: coefficients
+// with 11 fractional bits, horizontal pass in int32, vertical ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+// the `scale != 1` branch of pre_process (base_detector.py:128), multi-scale testing.
+__device__ __forceinline__ void resize_coef(int d, int dst, int src, int* s0, int* s1, int* a0, int* a1) {
+    const double scale = (double)src / (double)dst;
+    double f = ((double)d + 0.5) * scale - 0.5;
+    int s = (int)floor(f);
+    float ff = (float)(f - (double)s);
+    if (s < 0) { ff = 0.f; s = 0; }
+    if (s >= src - 1) { ff = 0.f; s = src - 1; }
+    *s0 = s;
+    *s1 = min(s + 1, src - 1);
+    *a0 = (int)rintf((1.f - ff) * 2048.f);
+    *a1 = (int)rintf(ff * 2048.f);
+}
+
+__global__ void resize_u8_kernel(const unsigned char* __restrict__ img, int H, int W, int C, unsigned char* __restrict__ out,
+                                 int OH, int OW) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= OH * OW) return;
+    const int y = i / OW, x = i - y * OW;
+    int x0, x1, ax0, ax1, y0, y1, ay0, ay1;
+    resize_coef(x, OW, W, &x0, &x1, &ax0, &ax1);
+    resize_coef(y, OH, H, &y0, &y1, &ay0, &ay1);
+    for (int c = 0; c < C; ++c) {
+        const int S0 = img[((size_t)y0 * W + x0) * C + c] * ax0 + img[((size_t)y0 * W + x1) * C + c] * ax1;
+        const int S1 = img[((size_t)y1 * W + x0) * C + c] * ax0 + img[((size_t)y1 * W + x1) * C + c] * ax1;
+        int v = (((ay0 * (S0 >> 4)) >> 16) + ((ay1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        out[(size_t)i * C + c] = (unsigned char)v;
+    }
 }
 
 // kp_module merge of the stacked hourglass (large_hourglass.py:186-188): out = up1 + Upsample(scale_factor=2)(low3),
@@ -449,14 +491,25 @@ int cp_launch_gn_finalize(const double* stats, float* mr, int n, double count, f
     return check();
 }
 
-int cp_launch_preprocess(const unsigned char* img, int H, int W, const float* minv6, const float* mean3,
+int cp_launch_preprocess(const unsigned char* img, int H, int W, const double* trans6, const float* mean3,
                          const float* std3, float* out, int OH, int OW, hipStream_t s) {
     PreParams pp;
-    for (int i = 0; i < 6; ++i) pp.m[i] = minv6[i];
+    // cv::invertAffineTransform (float64): warpAffine without WARP_INVERSE_MAP inverts the forward matrix first
+    const double* M = trans6;
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1.0 / D : 0.0;
+    const double A11 = M[4] * D, A22 = M[0] * D, A12 = -M[1] * D, A21 = -M[3] * D;
+    pp.m[0] = A11; pp.m[1] = A12; pp.m[2] = -A11 * M[2] - A12 * M[5];
+    pp.m[3] = A21; pp.m[4] = A22; pp.m[5] = -A21 * M[2] - A22 * M[5];
     for (int i = 0; i < 3; ++i) {
-        pp.mean[i] = mean3[i];
-        pp.inv_std[i] = 1.f / std3[i];
+        pp.mean[i] = (double)mean3[i];
+        pp.std[i] = (double)std3[i];
     }
     hipLaunchKernelGGL(preprocess_kernel, dim3((OH * OW + 255) / 256), dim3(256), 0, s, img, H, W, out, OH, OW, pp);
+    return check();
+}
+
+int cp_launch_resize_u8(const unsigned char* img, int H, int W, int C, unsigned char* out, int OH, int OW, hipStream_t s) {
+    hipLaunchKernelGGL(resize_u8_kernel, dim3((OH * OW + 255) / 256), dim3(256), 0, s, img, H, W, C, out, OH, OW);
     return check();
 }

@@ -1,0 +1,276 @@
+// Halo-resident 3x3 / stride-1 / pad-1 convolution in the split-f16 ("f16x3") arithmetic of igemm16.hip.
+//
+// The implicit-GEMM kernel of igemm16.hip re-loads, re-converts (float32 -> binary16 hi / lo) and re-stores the A tile
+// for every one of the 9 taps: per 128-pixel tile and 64 input channels that is 9 x 32 KB of global loads, ~500 VALU
+// per lane of conversion and 9 x 32 KB of LDS writes, all in the shadow of (and competing for issue slots with) the
+// MFMAs -- the reason that kernel sits at ~35 % of the f16 matrix peak (41 % issuing, 38 % issue-stalled).
+// Here a block owns an 8 x 16 patch of output pixels of one image and stages the (8+2) x (16+2) input halo of a
+// 64-channel chunk ONCE into LDS, already split into hi / lo binary16 planes in pixel-major order.  Every tap's A
+// fragment is then read straight out of that image (the 8 consecutive k of a lane are 8 consecutive halfs of one
+// pixel), so per chunk the loop body is only: weight tile -> LDS (16 KB per tap), fragment reads, MFMAs.  A-side global
+// traffic / conversion work / LDS writes drop by 9 / 1.41 (halo overhead) = 6.4x.  The same idea as lowc.hip, for the
+// 64..512-channel layers: prediction-head 3x3s, ConvGRU input side, BasicBlock convolutions, DCN offset convolutions.
+//
+// K order is (64-channel chunk, tap, 32-channel half) instead of (tap, channel): same products, different summation
+// order than igemm16p_kernel (results agree to float32 round-off, both inside the parity budget).
+// Requirements (else the launcher falls back to igemm16p_kernel): 3x3, stride 1, pad 1, one source, Cin % 64 == 0,
+// H % 8 == 0, W % 16 == 0, NHWC output, no split-K.
+#include "igemm16_common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16, PW = TW + 2, PH = TH + 2, NPIX = PH * PW;  // 180 patch pixels
+constexpr int CK = 64;                                                    // channels per staged chunk
+constexpr int PROW = CK;                                                  // halfs per patch pixel and plane (128 B)
+
+// chunk c (8 halfs) of patch pixel q sits at position c ^ (q & 7): lanes of a fragment read consecutive pixels, so a
+// ds_read_b128 group of 8 lanes covers all 8 sixteen-byte slots of the 128-byte row (conflict-free), and the staging
+// writes of 8 lanes (one pixel, 8 chunks) do too
+__device__ __forceinline__ int pswz(int q) { return q & 7; }
+
+template <int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
+    typedef Frag<32> F;
+    typedef F::acc_t acc_t;
+    static_assert(WM * WN == 4 && 32 * MT * WM == TH * TW, "4 waves over a 128-pixel patch");
+    constexpr int BN = 32 * NT * WN;
+    constexpr int B_CHUNKS = BN * BK16 * 2 / 16;  // 16-byte chunks per weight array (hi or lo) per 32-deep K tile
+    constexpr int B_SLOTS = (B_CHUNKS + 255) / 256;
+    constexpr bool B_PART = B_CHUNKS % 256 != 0;
+    constexpr int B_SZ = BN * LDH;
+    __shared__ __attribute__((aligned(16))) _Float16 patch_hi[NPIX * PROW];
+    __shared__ __attribute__((aligned(16))) _Float16 patch_lo[NPIX * PROW];
+    __shared__ __attribute__((aligned(16))) _Float16 bt[2][2 * B_SZ];  // [buffer][hi | lo]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int tile = tile_of_block(tiles_m, tiles_n);
+    const int tn = tile % tiles_n;
+    int tm = tile / tiles_n;
+    const int txs = p.W / TW, tys = p.H / TH;
+    const int tx0 = (tm % txs) * TW;
+    tm /= txs;
+    const int ty0 = (tm % tys) * TH, b = tm / tys;
+    float afwd, ainv;
+    conv_in_scale(p, &afwd, &ainv);
+
+    const unsigned img_bytes = (unsigned)p.B * p.H * p.W * (unsigned)p.Cin * 4u;
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(p.src[0], img_bytes);
+    const unsigned w_bytes = (unsigned)((size_t)p.CoutPad * p.Kpad16 * 2);
+    const __amdgpu_buffer_rsrc_t r_wh = make_rsrc(p.w16_hi, w_bytes), r_wl = make_rsrc(p.w16_lo, w_bytes);
+
+    // ---- staging geometry: slot s of this thread = patch pixel (tid / 16) + 16 s, float4 column tid % 16 ----
+    constexpr int ST = (NPIX + 15) / 16;  // 12 passes of 16 pixels x 16 float4
+    const int c4 = tid & 15;
+    // ---- weight tile loads: chunk f -> row n = f / 4, 16-byte column f % 4 of the 32-deep K tile ----
+    unsigned b_off[B_SLOTS];
+#pragma unroll
+    for (int j = 0; j < B_SLOTS; ++j) {
+        const int f = tid + j * 256;
+        b_off[j] = (!B_PART || f < B_CHUNKS) ? (unsigned)(((size_t)(tn * BN + f / 4) * p.Kpad16 + (f % 4) * 8) * 2) : OOB;
+    }
+    u32x4 gbh[B_SLOTS], gbl[B_SLOTS];
+    auto issue_b = [&](int kbyte) {  // kbyte: byte offset of the K tile inside a weight row (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < B_SLOTS; ++j) {
+            gbh[j] = __builtin_amdgcn_raw_buffer_load_b128(r_wh, (int)b_off[j], kbyte, 0);
+            gbl[j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)b_off[j], kbyte, 0);
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < B_SLOTS; ++j) {
+            const int f = tid + j * 256;
+            if (!B_PART || f < B_CHUNKS) {
+                const int nn = f / 4, c = f % 4;
+                *reinterpret_cast<u32x4*>(bt[buf] + nn * LDH + (c ^ swz(nn)) * 8) = gbh[j];
+                *reinterpret_cast<u32x4*>(bt[buf] + B_SZ + nn * LDH + (c ^ swz(nn)) * 8) = gbl[j];
+            }
+        }
+    };
+
+    acc_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < F::NACC; ++r) acc[i][j][r] = 0.f;
+
+    // ---- fragment geometry: row m of the tile = pixel (m / 16, m % 16); lane reads rows lcol + 32 i + 32 MT wm ----
+    const int lrow = lane >> 5, lcol = lane & 31;
+    int q0[MT];  // patch pixel of the fragment row at tap (0, 0)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = wm * (MT * 32) + i * 32 + lcol;
+        q0[i] = (m >> 4) * PW + (m & 15);
+    }
+    const int b_frag = (wn * (NT * 32) + lcol) * LDH;
+
+    const int nchunks = p.Cin / CK;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        // first weight tile of the chunk in flight while the patch is staged
+        issue_b(((0 * p.Cin) + ch * CK) * 2);
+        if (ch > 0) __syncthreads();  // every wave is done reading the previous chunk's patch
+        // ---- stage the halo patch of this 64-channel chunk: float32 global -> hi / lo binary16 planes ----
+#pragma unroll 4
+        for (int s = 0; s < ST; ++s) {
+            const int q = (tid >> 4) + 16 * s;
+            if (q < NPIX) {
+                const int py = q / PW, px = q - py * PW;
+                const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+                const bool in = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const unsigned off = in ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + ch * CK + c4 * 4) * 4u : OOB;
+                const float4 v = buf_ld4(r_x, off);
+                const Split2 s0 = split2(v.x * afwd, v.y * afwd), s1 = split2(v.z * afwd, v.w * afwd);
+                const int col = ((((c4 >> 1) ^ pswz(q)) << 1) | (c4 & 1)) * 4;  // halfs
+                *reinterpret_cast<u32x2*>(patch_hi + q * PROW + col) = u32x2{s0.hi, s1.hi};
+                *reinterpret_cast<u32x2*>(patch_lo + q * PROW + col) = u32x2{s0.lo, s1.lo};
+            }
+        }
+        store_b(0);
+        __syncthreads();
+        // ---- 18 K tiles: (tap, 32-channel half) ----
+#pragma unroll 1
+        for (int kt = 0; kt < 18; ++kt) {
+            const int cur = kt & 1;
+            const int tap = kt >> 1, half = kt & 1;
+            if (kt + 1 < 18) {
+                const int tap1 = (kt + 1) >> 1, half1 = (kt + 1) & 1;
+                issue_b((tap1 * p.Cin + ch * CK + half1 * 32) * 2);
+            }
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const int dq = kh * PW + kw;
+            const _Float16* Bh = bt[cur] + b_frag;
+            const _Float16* Bl = Bh + B_SZ;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                h8 ah[MT], al[MT], bh[NT], bl[NT];
+                const int c8 = half * 4 + ks * 2 + lrow;  // 16-byte chunk of the 64-channel pixel row
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int q = q0[i] + dq;
+                    const int o = q * PROW + ((c8 ^ pswz(q)) * 8);
+                    ah[i] = *reinterpret_cast<const h8*>(patch_hi + o);
+                    al[i] = *reinterpret_cast<const h8*>(patch_lo + o);
+                }
+                const int co = ((ks * 2 + lrow) ^ swz(lcol)) * 8;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    bh[j] = *reinterpret_cast<const h8*>(Bh + j * 32 * LDH + co);
+                    bl[j] = *reinterpret_cast<const h8*>(Bl + j * 32 * LDH + co);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < 18) store_b(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: y = acc * scale[n] * 2^-e_a + shift[n] (+ residual) -> activation -> NHWC store (full tiles only);
+    //      GroupNorm statistics and |max| tracking as igemm_epilogue ----
+    const int act = p.act;
+    const bool has_res = p.res != nullptr, has_gn = p.gn_stats != nullptr;
+    float amax = 0.f;
+    const int h4 = lane >> 5;  // fragment rows (r & 3) + 8 (r >> 2) + 4 h4
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = tn * BN + wn * (NT * 32) + j * 32 + lcol;
+        const float sc = (p.scale ? p.scale[n] : 1.f) * ainv;
+        const float sh = p.shift ? p.shift[n] : 0.f;
+        const bool n_ok = n < p.Cout;
+        const bool sig_lane = act == CP_ACT_SIGMOID || (act == CP_ACT_SIGMOID_FROM && n >= p.act_from);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            // fragment = tile rows m0 .. m0 + 31 = patch rows y, y + 1 (16 pixels each)
+            const int m0 = wm * (MT * 32) + i * 32;
+            const int pix0 = __builtin_amdgcn_readfirstlane((b * p.H + ty0 + (m0 >> 4)) * p.W + tx0);
+            float v[F::NACC];
+#pragma unroll
+            for (int r = 0; r < F::NACC; ++r) v[r] = acc[i][j][r] * sc + sh;
+            if (has_res) {
+                const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res + (size_t)pix0 * p.res_ld, (unsigned)((p.W + TW) * p.res_ld) * 4u);
+                const unsigned vr = n_ok ? (unsigned)(4 * h4 * p.res_ld + n) * 4u : 0x80000000u;
+#pragma unroll
+                for (int r = 0; r < F::NACC; ++r) {
+                    const int so = (((r >> 3) * p.W) + 8 * ((r >> 2) & 1) + (r & 3)) * p.res_ld * 4;
+                    v[r] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, (int)vr, so, 0));
+                }
+            }
+            if (act == CP_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < F::NACC; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (act == CP_ACT_SIGMOID || act == CP_ACT_SIGMOID_FROM) {
+#pragma unroll
+                for (int r = 0; r < F::NACC; ++r) v[r] = sig_lane ? 1.f / (1.f + expf(-v[r])) : v[r];
+            }
+#pragma unroll
+            for (int r = 0; r < F::NACC; ++r) amax = fmaxf(amax, fabsf(v[r]));
+            if (has_gn) {
+                float s1 = 0.f, s2 = 0.f;
+                if (n_ok) {
+#pragma unroll
+                    for (int r = 0; r < F::NACC; ++r) { s1 += v[r]; s2 += v[r] * v[r]; }
+                }
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if ((lane & 7) == 0 && lane < 32 && n_ok) {
+                    double* st = p.gn_stats + ((size_t)b * p.gn_groups + n / p.gn_cpg) * 2;
+                    atomicAdd(st, (double)s1);
+                    atomicAdd(st + 1, (double)s2);
+                }
+            }
+            float* frag_out = p.out + (size_t)pix0 * p.ldo + p.coff;
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(frag_out, (unsigned)((p.W + TW) * p.ldo) * 4u);
+            const unsigned vo = n_ok ? (unsigned)(4 * h4 * p.ldo + n) * 4u : 0x80000000u;
+#pragma unroll
+            for (int r = 0; r < F::NACC; ++r) {
+                const int so = (((r >> 3) * p.W) + 8 * ((r >> 2) & 1) + (r & 3)) * p.ldo * 4;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, (int)vo, so, 0);
+            }
+        }
+    }
+    if (p.out_amax) cp_amax_commit(p.out_amax, amax);
+}
+
+template <int MT, int NT, int WM, int WN>
+int launch_halo(const ConvParams& p, hipStream_t stream) {
+    constexpr int BN = 32 * NT * WN;
+    const int tiles_m = p.B * (p.H / TH) * (p.W / TW), tiles_n = p.CoutPad / BN;
+    hipLaunchKernelGGL((halo16_kernel<MT, NT, WM, WN>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m, tiles_n);
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}
+
+}  // namespace
+
+bool cp_halo16_supported(const ConvParams& p) {
+    return p.w16_hi && p.w16_lo && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.nsrc == 1 && !p.offmask &&
+           !p.gn_in_a && !p.gn_in_mr && p.splitk <= 1 && p.Cin % CK == 0 && p.H % TH == 0 && p.W % TW == 0 && p.H == p.Ho &&
+           p.W == p.Wo && p.store == CP_STORE_NHWC && p.Kpad16 == 9 * p.Cin &&
+           (size_t)p.B * p.H * p.W * p.Cin * 4 < (size_t)0xf0000000u && (size_t)p.B * p.H * p.W * p.ldo * 4 < (size_t)0xf0000000u;
+}
+
+// bn: N tile the weights were padded for (32 / 64 / 128)
+int cp_launch_halo16(const ConvParams& p, int bn, hipStream_t stream) {
+    if (!cp_halo16_supported(p) || p.CoutPad % bn != 0) return CP_ERR_INVALID;
+    if (bn == 128) return launch_halo<2, 2, 2, 2>(p, stream);
+    if (bn == 64) return launch_halo<2, 1, 2, 2>(p, stream);
+    if (bn == 32) return launch_halo<1, 1, 4, 1>(p, stream);
+    return CP_ERR_INVALID;
+}

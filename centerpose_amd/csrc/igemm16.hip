@@ -979,6 +979,11 @@ static int conv16_tile_n(const ConvParams& p) {
     return (bn < 32 && p.CoutPad >= 32 && p.CoutPad % 32 == 0) ? 32 : bn;
 }
 
+static bool halo16_wanted(const ConvParams& p, int bn) {
+    if ((p.dbg & 4096) || p.gn_in_a || !cp_halo16_supported(p)) return false;
+    return bn == 32 || (p.dbg & 8192);
+}
+
 bool cp_conv16_supported(const ConvParams& p) {
     if (!p.w16_hi || !p.w16_lo || p.Cin % BK16 != 0 || p.KH * p.KW > 32) return false;
     for (int s = 0; s < p.nsrc; ++s)
@@ -1018,6 +1023,12 @@ int cp_launch_conv16(const ConvParams& p, hipStream_t stream) {
         if (!(p.dbg & 1024)) return cp_launch_dcn16(p, bn, (p.dbg & 2048) ? 1 : 0, stream);
         return bn == 128 ? launch16<2, 2, 2, 2, true, false>(p, stream) : launch16<2, 1, 2, 2, true, false>(p, stream);
     }
+    // 3x3 / stride 1 layers with full 8x16 patches can run on the halo-resident kernel (halo16.hip).  Measured on the
+    // dlav1_34 B=32 step (profiles/r02_halo_ab.txt): N tile 32 (conv_offset_mask) 62 -> 103 TFLOP/s, N 64 223 -> 212,
+    // N 128 288 -> 290: with 64+ output channels the loop is bound by MFMA issue + fragment reads at the sustained
+    // clock, not by the A-side loads / conversion the halo removes, so only the 32-wide tile uses it by default.
+    // cp_set_debug: 4096 = never, 8192 = every eligible layer (A/B runs).
+    if (halo16_wanted(p, bn)) return cp_launch_halo16(p, bn, stream);
     if (bn == 128) return cat ? launch16<2, 2, 2, 2, false, true>(p, stream) : launch16<2, 2, 2, 2, false, false>(p, stream);
     if (bn == 64) return cat ? launch16<2, 1, 2, 2, false, true>(p, stream) : launch16<2, 1, 2, 2, false, false>(p, stream);
     return cat ? launch16<1, 1, 4, 1, false, true>(p, stream) : launch16<1, 1, 4, 1, false, false>(p, stream);
@@ -1028,6 +1039,7 @@ int cp_conv16_variant(const ConvParams& p) {
     const int bn = conv16_tile_n(p);
     if (p.offmask) return bn == 128 ? 18 : 17;
     const int t = bn == 32 ? 0 : bn == 64 ? 1 : 2;
+    if (halo16_wanted(p, bn)) return 27 + t;
     return (p.nsrc > 1 ? 19 : 14) + t;
 }
 

@@ -181,6 +181,41 @@ int cp_launch_render_gaussians(const double* recs, int N, float* out, int C, int
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
+// PnP input assembly for every post-processed slot (base_detector.py:547-566): slot (b, k) is a detection iff
+// k < count[b]; its 8 (rep_mode 0/3/4: `kps`) or 16 (rep_mode 1: displacement / heat-map pairs interleaved per vertex)
+// image points, relative size and the image's intrinsics are laid out for cp_pnp_solve.  Absent slots get all points
+// invalid, so the solver returns status -1 for them without work.
+__global__ void pnp_assemble_kernel(const double* __restrict__ post, const int* __restrict__ count, int B, int K, int npts,
+                                    const double* __restrict__ cam_img, float* __restrict__ pts, float* __restrict__ scale,
+                                    double* __restrict__ cam) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * K) return;
+    const int b = i / K, k = i - b * K;
+    const double* r = post + (size_t)i * CP_POST_STRIDE;
+    float* P = pts + (size_t)i * npts * 2;
+    const bool live = k < count[b];
+    for (int v = 0; v < 8; ++v) {
+        if (npts == 16) {
+            P[4 * v + 0] = live ? (float)r[64 + 2 * v] : -10000.f;  // kps_displacement_mean
+            P[4 * v + 1] = live ? (float)r[65 + 2 * v] : -10000.f;
+            P[4 * v + 2] = live ? (float)r[80 + 2 * v] : -10000.f;  // kps_heatmap_mean
+            P[4 * v + 3] = live ? (float)r[81 + 2 * v] : -10000.f;
+        } else {
+            P[2 * v + 0] = live ? (float)r[30 + 2 * v] : -10000.f;  // kps
+            P[2 * v + 1] = live ? (float)r[31 + 2 * v] : -10000.f;
+        }
+    }
+    for (int d = 0; d < 3; ++d) scale[(size_t)i * 3 + d] = live ? (float)r[2 + d] : 1.f;
+    for (int d = 0; d < 4; ++d) cam[(size_t)i * 4 + d] = cam_img[(size_t)b * 4 + d];
+}
+
+int cp_launch_pnp_assemble(const double* post, const int* count, int B, int K, int npts, const double* cam_img, float* pts,
+                           float* scale, double* cam, hipStream_t s) {
+    hipLaunchKernelGGL(pnp_assemble_kernel, dim3((B * K + 127) / 128), dim3(128), 0, s, post, count, B, K, npts, cam_img,
+                       pts, scale, cam);
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}
+
 int cp_launch_postprocess(const float* det, int B, int K, const double* meta, double vis_thresh, int nms,
                           float div_scale, double* out, int* count, double* ws, hipStream_t s) {
     if (K < 1 || K > MAXK) return CP_ERR_INVALID;

@@ -67,8 +67,9 @@ def lib():
     _sig(L.cp_postprocess_workspace_bytes, c_size_t, c_int, c_int)
     _sig(L.cp_postprocess, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.c_double, c_int, ctypes.c_float,
          c_void_p, c_void_p, c_void_p, c_size_t)
-    _sig(L.cp_preprocess, c_int, c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_float),
+    _sig(L.cp_preprocess, c_int, c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_double),
          ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_void_p, c_int, c_int)
+    _sig(L.cp_resize_u8, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int)
     _sig(L.cp_model_set_precision, c_int, c_void_p, c_int)
     _sig(L.cp_model_profile, c_int, c_void_p, c_int)
     _sig(L.cp_model_profile_read, c_int, c_void_p, ctypes.POINTER(ctypes.c_double), c_int)
@@ -76,6 +77,8 @@ def lib():
     _sig(L.cp_model_profile_roles, c_int, c_void_p, ctypes.POINTER(ctypes.c_double), c_int)
     _sig(L.cp_role_name, c_char_p, c_int)
     _sig(L.cp_pnp_workspace_bytes, c_size_t, c_int)
+    _sig(L.cp_pnp_from_post_workspace_bytes, c_size_t, c_int, c_int)
+    _sig(L.cp_pnp_from_post, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t)
     _sig(L.cp_pnp_solve, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t)
     _lib = L
     return L
@@ -88,7 +91,7 @@ def exported_symbols():
             "cp_model_forward", "cp_model_forward_tap", "cp_conv2d_workspace_bytes", "cp_conv2d_nhwc",
             "cp_decode_workspace_bytes", "cp_decode", "cp_pnp_workspace_bytes", "cp_pnp_solve", "cp_model_profile", "cp_model_profile_read",
             "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug", "cp_preprocess", "cp_postprocess_workspace_bytes", "cp_postprocess", "cp_render_gaussians",
-            "cp_model_profile_roles", "cp_role_name"]
+            "cp_model_profile_roles", "cp_role_name", "cp_pnp_from_post_workspace_bytes", "cp_pnp_from_post", "cp_resize_u8"]
 
 
 def _check(rc, what):
@@ -199,13 +202,25 @@ def preprocess(image_u8_hwc, trans_input, mean, std, out_h, out_w):
     if not (image_u8_hwc.is_cuda and image_u8_hwc.dtype == torch.uint8 and image_u8_hwc.is_contiguous()):
         raise RuntimeError("preprocess: image must be a contiguous uint8 device tensor [H,W,3]")
     H, W = int(image_u8_hwc.shape[0]), int(image_u8_hwc.shape[1])
-    minv = np.linalg.inv(np.vstack([np.asarray(trans_input, np.float64), [0, 0, 1]]))[:2].astype(np.float32).reshape(-1)
+    fwd = np.asarray(trans_input, np.float64).reshape(-1)
     f3 = ctypes.c_float * 3
     out = torch.empty(1, 3, out_h, out_w, device=image_u8_hwc.device, dtype=torch.float32)
-    rc = L.cp_preprocess(_stream(), _ptr(image_u8_hwc), H, W, (ctypes.c_float * 6)(*minv.tolist()),
+    rc = L.cp_preprocess(_stream(), _ptr(image_u8_hwc), H, W, (ctypes.c_double * 6)(*fwd.tolist()),
                          f3(*[float(v) for v in np.asarray(mean).reshape(-1)]),
                          f3(*[float(v) for v in np.asarray(std).reshape(-1)]), _ptr(out), out_h, out_w)
     _check(rc, "cp_preprocess")
+    return out
+
+
+def resize_u8(image_u8_hwc, out_h, out_w):
+    """cv2.resize(img, (out_w, out_h)) (INTER_LINEAR, OpenCV's fixed-point form) of a uint8 [H,W,C] device frame."""
+    L = lib()
+    if not (image_u8_hwc.is_cuda and image_u8_hwc.dtype == torch.uint8 and image_u8_hwc.is_contiguous()
+            and image_u8_hwc.dim() == 3):
+        raise RuntimeError("resize_u8: image must be a contiguous uint8 device tensor [H,W,C]")
+    H, W, C = (int(v) for v in image_u8_hwc.shape)
+    out = torch.empty(out_h, out_w, C, device=image_u8_hwc.device, dtype=torch.uint8)
+    _check(L.cp_resize_u8(_stream(), _ptr(image_u8_hwc), H, W, C, _ptr(out), out_h, out_w), "cp_resize_u8")
     return out
 
 
@@ -274,6 +289,29 @@ def pnp_solve(pts, scale, cam):
     return out
 
 
+_pnp_ws_cache = {}
+
+
+def pnp_from_post(post, count, cam, rep_mode=1):
+    """PnP of every post-processed slot on the device (cp_pnp_from_post): post [B,K,120] float64 + count [B] int32 from
+    ``postprocess``, cam [B,4] float64 (fx, fy, cx, cy).  Returns [B,K,40] float64; rows k >= count[b] carry status -1.
+    No host synchronisation."""
+    L = lib()
+    B, K = int(post.shape[0]), int(post.shape[1])
+    if not (post.is_cuda and post.dtype == torch.float64 and post.is_contiguous() and count.is_cuda and cam.is_cuda):
+        raise RuntimeError("pnp_from_post: contiguous device tensors expected (no CPU path)")
+    cam = cam.contiguous().double().reshape(B, 4)
+    out = torch.empty(B, K, PNP_STRIDE, dtype=torch.float64, device=post.device)
+    n = L.cp_pnp_from_post_workspace_bytes(B, K)
+    key = (B, K, post.device)
+    ws = _pnp_ws_cache.get(key)
+    if ws is None:
+        ws = _pnp_ws_cache[key] = torch.empty(n, dtype=torch.uint8, device=post.device)
+    _check(L.cp_pnp_from_post(_stream(), _ptr(post), _ptr(count), B, K, int(rep_mode), _ptr(cam), _ptr(out), _ptr(ws), n),
+           "cp_pnp_from_post")
+    return out
+
+
 class HipModel(object):
     """Device-resident DLA-34 / DLA-34+ConvGRU network built from a reference-format state dict."""
 
@@ -319,7 +357,7 @@ class HipModel(object):
 
     def profile_read(self):
         """-> {kernel name: dict(launches, ms, flops, bytes)} accumulated since the last read."""
-        nv = 27  # CP_NUM_KERNEL_VARIANTS (include/centerpose_hip.h)
+        nv = 30  # CP_NUM_KERNEL_VARIANTS (include/centerpose_hip.h)
         buf = (ctypes.c_double * (nv * 4))()
         _check(lib().cp_model_profile_read(self._h, buf, nv), "cp_model_profile_read")
         out = OrderedDict()

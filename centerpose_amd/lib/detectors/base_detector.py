@@ -124,13 +124,16 @@ class BaseDetector(object):
         out_height = inp_height // self.opt.down_ratio
         out_width = inp_width // self.opt.down_ratio
         trans_output = get_affine_transform(c, s, 0, [out_width, out_height])
-        resized_image = _resize(image, new_width, new_height)
-        if self.opt.device.type == 'cuda' and resized_image.dtype == np.uint8 and resized_image.ndim == 3:
-            # warp + normalise on the device (cp_preprocess); the 8-bit frame is the only host->device copy
+        if self.opt.device.type == 'cuda' and image.dtype == np.uint8 and image.ndim == 3:
+            # resize (scale != 1) + warp + normalise on the device, in OpenCV's fixed-point arithmetic (cp_resize_u8,
+            # cp_preprocess); the 8-bit frame is the only host->device copy
             from centerpose_amd import hip as _hip
-            frame = torch.from_numpy(np.ascontiguousarray(resized_image)).to(self.opt.device)
+            frame = torch.from_numpy(np.ascontiguousarray(image)).to(self.opt.device)
+            if (new_width, new_height) != (width, height):
+                frame = _hip.resize_u8(frame, new_height, new_width)
             images = _hip.preprocess(frame, trans_input, self.mean, self.std, inp_height, inp_width)
         else:
+            resized_image = _resize(image, new_width, new_height)
             inp_image = warp_affine_bilinear(resized_image, trans_input, inp_width, inp_height)
             inp_image = ((inp_image / 255. - self.mean) / self.std).astype(np.float32)
             images = torch.from_numpy(inp_image.transpose(2, 0, 1).reshape(1, 3, inp_height, inp_width))
@@ -289,9 +292,7 @@ class BaseDetector(object):
         scales = [np.asarray(d['obj_scale'], np.float64) / d['obj_scale'][1] for d in results]
         raw = solve_pnp_batch(pts, scales, meta['camera_matrix'], device=self.opt.device)
         for det, r in zip(results, raw):
-            if int(r[0]) == -2:
-                raise NotImplementedError("4-5 valid points: EPnP branch is not built")
-            if int(r[0]) != 1:
+            if int(r[0]) != 1:  # no pose (too few points, behind the camera, degenerate): dropped (cuboid_pnp_shell.py:24)
                 continue
             proj = r[8:24].reshape(8, 2).copy()
             if self.opt.show_axes:  # OPENCV_RETURN (base_detector.py:652)
@@ -477,14 +478,20 @@ class BaseDetector(object):
                 all_results.append(results)
         t2 = time.time()
         if self.opt.use_pnp == True:  # noqa: E712
-            flat = [(b, d) for b, rs in enumerate(all_results) for d in rs]
+            flat = [(b, k, d) for b, rs in enumerate(all_results) for k, d in enumerate(rs)]
             boxes_per = [[] for _ in metas]
             if flat:
-                pts = [self._pnp_points(d) for _, d in flat]
-                scales = [np.asarray(d['obj_scale'], np.float64) / d['obj_scale'][1] for _, d in flat]
-                cams = np.stack([np.asarray(metas[b]['camera_matrix'], np.float64) for b, _ in flat])
-                raw = solve_pnp_batch(pts, scales, cams, device=self.opt.device)
-                for (b, det), r in zip(flat, raw):
+                if on_device and getattr(self, 'pnp_dev', None) is not None:
+                    # solved on the device straight from the post-processed records (cp_pnp_from_post): no per-detection
+                    # host assembly, one copy of the [B,K,40] result
+                    allraw = self.pnp_dev.cpu().numpy()
+                    raw = [allraw[b, k] for b, k, _ in flat]
+                else:
+                    pts = [self._pnp_points(d) for _, _, d in flat]
+                    scales = [np.asarray(d['obj_scale'], np.float64) / d['obj_scale'][1] for _, _, d in flat]
+                    cams = np.stack([np.asarray(metas[b]['camera_matrix'], np.float64) for b, _, _ in flat])
+                    raw = solve_pnp_batch(pts, scales, cams, device=self.opt.device)
+                for (b, _, det), r in zip(flat, raw):
                     if int(r[0]) != 1:
                         continue
                     proj = r[8:24].reshape(8, 2).copy()

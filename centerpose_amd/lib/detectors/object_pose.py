@@ -134,6 +134,14 @@ class ObjectPoseDetector(BaseDetector):
             arr[b, 6] = meta['s'] / max(w, h)
         use_nms = bool(self.opt.nms or len(self.opt.test_scales) > 1)
         rec, cnt = _hip.postprocess(self.raw_dets, arr, self.opt.vis_thresh, use_nms)
+        self.post_dev = (rec, cnt)  # stays on the device for cp_pnp_from_post (run_batch)
+        self.pnp_dev = None
+        if self.opt.use_pnp == True and self.opt.rep_mode != 2 and all('camera_matrix' in m for m in metas):  # noqa: E712
+            cams = np.array([[np.asarray(m['camera_matrix'], np.float64)[0, 0], np.asarray(m['camera_matrix'], np.float64)[1, 1],
+                              np.asarray(m['camera_matrix'], np.float64)[0, 2], np.asarray(m['camera_matrix'], np.float64)[1, 2]]
+                             for m in metas])
+            # enqueued behind the post-process: the single device->host copy below then carries both results
+            self.pnp_dev = _hip.pnp_from_post(rec, cnt, torch.from_numpy(cams).to(rec.device), self.opt.rep_mode)
         rec = rec.cpu().numpy()
         cnt = cnt.cpu().numpy()
         f32_fields = ('obj_scale', 'obj_scale_uncertainty', 'kps_displacement_std', 'tracking', 'tracking_hp',

@@ -52,8 +52,6 @@ class CuboidPNPSolver(object):
         size = np.asarray(self._cuboid3d.size3d, np.float64)
         r = solve_pnp_batch([cuboid2d_points], [size], self._camera_intrinsic_matrix)[0]
         status = int(r[0])
-        if status == -2:
-            raise NotImplementedError("4-5 valid points: the reference switches to SOLVEPNP_EPNP, which is not built")
         projected = cuboid2d_points
         err = None
         if status >= 1:

@@ -124,7 +124,7 @@ int cp_model_set_precision(cp_model* m, int precision);
  * pair.  cp_model_profile_read drains them: out[v*4 + 0..3] = {launches, total milliseconds, total
  * algorithmic FLOPs (2*M*Cout*KH*KW*Cin), total algorithmic bytes (input + output + weights
  * [+ offsets/mask] [+ residual], float32)} per kernel variant v in [0, CP_NUM_KERNEL_VARIANTS). */
-#define CP_NUM_KERNEL_VARIANTS 27
+#define CP_NUM_KERNEL_VARIANTS 30
 int cp_model_profile(cp_model* m, int enable);
 int cp_model_profile_read(cp_model* m, double* out, int num_variants);
 const char* cp_kernel_variant_name(int v);
@@ -187,14 +187,20 @@ int cp_decode(cp_stream_t stream, int B, int H, int W, float* hm, const float* h
               void* workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------
- * Pre-process — replaces the warp + normalise part of `BaseDetector.pre_process`
- *   (detectors/base_detector.py:127-134: cv2.warpAffine(..., INTER_LINEAR) then (x/255 - mean)/std, HWC->CHW).
- * image_hwc_bgr: DEVICE uint8 [H,W,3] (BGR as cv2.imread gives); inv_trans6: HOST float[6], the row-major 2x3
- * matrix mapping OUTPUT pixel (x,y) to source coordinates (inverse of `trans_input`); mean3/std3: HOST float[3]
- * (opts.py:436-437); out_chw: DEVICE float32 [3,out_h,out_w].  Float bilinear weights (cv2 uses 5-bit fixed point).
+ * Pre-process — replaces `BaseDetector.pre_process`'s image work
+ *   (detectors/base_detector.py:127-134: cv2.resize when scale != 1, cv2.warpAffine(..., INTER_LINEAR), then
+ *    (x/255 - mean)/std, HWC->CHW).
+ * image_hwc_bgr: DEVICE uint8 [H,W,3] (BGR as cv2.imread gives); trans6: HOST double[6], the row-major 2x3 FORWARD
+ * matrix `trans_input` (source -> network input), inverted inside exactly as cv::invertAffineTransform does;
+ * mean3/std3: HOST float[3] (opts.py:436-437); out_chw: DEVICE float32 [3,out_h,out_w].
+ * Both kernels follow OpenCV's fixed-point arithmetic (5-bit bilinear weights for the warp, 11-bit coefficients for the
+ * resize; oracle/cv_emul.py restates it), so the network input is built from the same rounded 8-bit values as the
+ * reference's.  cp_resize_u8: in / out DEVICE uint8 [H,W,C] -> [out_h,out_w,C].
  * ------------------------------------------------------------------------------------------ */
-int cp_preprocess(cp_stream_t stream, const unsigned char* image_hwc_bgr, int H, int W, const float* inv_trans6,
+int cp_preprocess(cp_stream_t stream, const unsigned char* image_hwc_bgr, int H, int W, const double* trans6,
                   const float* mean3, const float* std3, float* out_chw, int out_h, int out_w);
+int cp_resize_u8(cp_stream_t stream, const unsigned char* image_hwc, int H, int W, int C, unsigned char* out_hwc,
+                 int out_h, int out_w);
 
 /* ------------------------------------------------------------------------------------------
  * Post-process + soft-NMS — replaces `ObjectPoseDetector.post_process` + `merge_outputs`
@@ -229,7 +235,7 @@ int cp_render_gaussians(cp_stream_t stream, const double* recs, int N, float* ou
 
 /* ------------------------------------------------------------------------------------------
  * Batched cuboid PnP — replaces the per-detection loop `pnp_shell` -> `CuboidPNPSolver.solve_pnp`
- *   -> `cv2.solvePnPGeneric(SOLVEPNP_ITERATIVE)` + `cv2.projectPoints`
+ *   -> `cv2.solvePnPGeneric(SOLVEPNP_ITERATIVE | SOLVEPNP_EPNP)` + `cv2.projectPoints`
  *   (utils/pnp/cuboid_pnp_shell.py:11-24, utils/pnp/cuboid_pnp_solver.py:141-239,
  *   detectors/base_detector.py:547-654).
  *   pts   [N, npts, 2] float32 image points, npts = 8 (rep_mode 0/3/4: `kps`) or 16 (rep_mode 1:
@@ -238,9 +244,11 @@ int cp_render_gaussians(cp_stream_t stream, const double* recs, int N, float* ou
  *   scale [N, 3] float32 relative cuboid size (divided by its y component inside, shell :12)
  *   cam   [N, 4] float64 (fx, fy, cx, cy) of each detection's image
  *   out   [N, 40] float64:
- *     [0] status: 1 solved, 2 solved but t_z < 0 (reference drops it, solver :207-220),
- *                 -1 < 4 valid points, -2 4-5 valid points (reference switches to EPnP: not
- *                 implemented), -3 planar model (homography branch: not implemented), 0 failure
+ *     [0] status: 1 solved, 2 solved but t_z < 0 (reference drops it, solver :207-220), -1 < 4 valid points,
+ *                 0 failure (degenerate correspondences, e.g. 4-5 coplanar points handed to EPnP)
+ *                 Branches as the reference selects them (solver :157-171): >= 6 valid non-planar points
+ *                 SOLVEPNP_ITERATIVE (DLT + LM), coplanar model points its homography initialisation + LM,
+ *                 4-5 valid points SOLVEPNP_EPNP (no refinement; approximate for exactly 4 points, as published)
  *     [1:4] rvec  [4:7] tvec (OpenCV frame)  [7] RMS reprojection error
  *     [8:24] the 8 cuboid vertices projected with (rvec, tvec), pixels
  *     [24:28] quaternion xyzw (OpenCV frame)   [28:31] location, [31:35] quaternion xyzw in the
@@ -250,6 +258,19 @@ int cp_render_gaussians(cp_stream_t stream, const double* recs, int N, float* ou
 size_t cp_pnp_workspace_bytes(int N);
 int cp_pnp_solve(cp_stream_t stream, const float* pts, const float* scale, const double* cam, int N, int npts,
                  double* out, void* workspace, size_t workspace_bytes);
+
+/* PnP of every post-processed detection of a batch without leaving the device -- replaces the per-detection loop of
+ *   `BaseDetector.run` (detectors/base_detector.py:547-566 point assembly by rep_mode, :652 `pnp_shell`) between
+ *   `merge_outputs` and the packaging of `cuboid_pnp_shell.py:26-91`.
+ *   post / count: outputs of cp_postprocess ([B,K,CP_POST_STRIDE] float64, [B] int32).
+ *   rep_mode: 0 / 3 / 4 -> 8 points from `kps`; 1 -> 16 points, (kps_displacement_mean, kps_heatmap_mean) per vertex.
+ *   cam: DEVICE float64 [B,4] (fx, fy, cx, cy) per image.
+ *   out: DEVICE float64 [B,K,CP_PNP_STRIDE]; row (b,k) as cp_pnp_solve for k < count[b], status -1 beyond.
+ * No host synchronisation and no host-visible count: the whole chain backbone -> decode -> post-process -> PnP is a
+ * fixed launch sequence. */
+size_t cp_pnp_from_post_workspace_bytes(int B, int K);
+int cp_pnp_from_post(cp_stream_t stream, const double* post, const int* count, int B, int K, int rep_mode,
+                     const double* cam, double* out, void* workspace, size_t workspace_bytes);
 
 #ifdef __cplusplus
 }

@@ -251,6 +251,8 @@ def solve_pnp_epnp(obj, img, Kmat):
     for i in range(3):
         cws[i + 1] = cws[0] + np.sqrt(max(dc[2 - i], 0.0) / n) * uc[:, 2 - i]
     CC = (cws[1:] - cws[0]).T
+    if abs(np.linalg.det(CC)) < 1e-300:  # coplanar / collinear points: no barycentric coordinates (cv::epnp returns garbage)
+        return False, np.zeros(3), np.zeros(3)
     al = np.linalg.solve(CC, (obj - cws[0]).T).T
     alphas = np.hstack([1 - al.sum(1, keepdims=True), al])
     M = np.zeros((2 * n, 12))

@@ -231,9 +231,66 @@ def reference_detector(argv=TRACK_ARGV):
     return det, rimage.get_affine_transform
 
 
+def shell_cases():
+    """Injected poses for the packaging / visibility logic of pnp_shell (cuboid_pnp_shell.py:26-91): a centred object,
+    objects sliding out of the frame to the right / bottom until 3 resp. 6 projected points leave the unit square, a
+    centroid outside, per category family (thresholds 3, 6, none)."""
+    from oracle import pnp as opnp
+
+    cases = []
+    scale = np.array([0.8, 1.0, 1.3])
+    V = opnp.cuboid_vertices(scale / scale[1])
+    q = np.array([0.2, -0.4, 0.1, 0.9])
+    R = opnp.quat_xyzw_to_matrix(q / np.linalg.norm(q))
+    rvec = opnp.matrix_to_rodrigues(R)
+    for cat in ("cup", "chair", "shoe"):
+        for tx, ty in ((0.0, 0.0), (0.9, 0.0), (1.15, 0.0), (1.35, 0.0), (1.8, 0.2), (0.0, 0.75), (0.0, 1.2), (-1.4, -1.6)):
+            t = np.array([tx, ty, 3.0])
+            proj = opnp.project_points(V, rvec, t, K_DEMO)
+            cases.append({"c": cat, "location": t.tolist(), "quaternion": opnp.axis_angle_quat_xyzw(rvec).tolist(),
+                          "projected": proj.tolist(), "scale": scale.tolist(),
+                          "kps": (proj + 1.5).reshape(-1).tolist()})
+    return cases
+
+
+def run_shell_cases(pnp_shell_fn, solver_cls):
+    """pnp_shell with the solver's answer injected (so only the reference's own packaging logic runs)."""
+    out = []
+    for cs in shell_cases():
+        opt = types.SimpleNamespace(c=cs["c"])
+        meta = {"camera_matrix": K_DEMO, "width": 600, "height": 800}
+        bbox = {"kps": list(cs["kps"]), "obj_scale": np.array(cs["scale"])}
+        orig = solver_cls.solve_pnp
+        solver_cls.solve_pnp = lambda self, pts, OPENCV_RETURN=False, **k: (
+            list(cs["location"]), np.array(cs["quaternion"]), np.array(cs["projected"]), 0.5)
+        try:
+            ret = pnp_shell_fn(opt, meta, bbox, np.zeros((16, 2)), cs["scale"], OPENCV_RETURN=True)
+        finally:
+            solver_cls.solve_pnp = orig
+        if ret is None:
+            out.append(None)
+        else:
+            out.append({"kps_pnp": _f(ret[0]), "kps_3d_cam": _f(ret[1]), "obj_scale": _f(ret[2]), "kps_ori": _f(ret[3]),
+                        "bbox_keys": sorted(ret[4].keys())})
+    return out
+
+
+def shell_golden():
+    _install_reference_shims()
+    from lib.utils.pnp import cuboid_pnp_shell as rshell
+    from lib.utils.pnp.cuboid_pnp_solver import CuboidPNPSolver as RSolver
+
+    out = run_shell_cases(rshell.pnp_shell, RSolver)
+    with open(os.path.join(GOLD, "pnp_shell_ref.json"), "w") as f:
+        json.dump(out, f)
+    print("pnp_shell_ref.json: kept / dropped", sum(o is not None for o in out), sum(o is None for o in out))
+
+
 def main():
     import contextlib
     import io
+
+    shell_golden()
 
     det, gat = reference_detector()
     with contextlib.redirect_stdout(io.StringIO()):

@@ -124,21 +124,31 @@ def test_load_model_handles_reference_checkpoint_quirks(device, tmp_path):
     assert z["hm"].shape == (1, 1, 16, 16) and torch.isfinite(z["hps"]).all()
 
 
-def test_device_preprocess_matches_host_restatement(device):
-    """cp_preprocess vs the float numpy warp + normalise (base_detector.py:127-134) on a 480x640 frame."""
-    from centerpose_amd.lib.utils.image import get_affine_transform, warp_affine_bilinear
+def test_device_preprocess_matches_opencv_fixed_point_emulation(device):
+    """cp_preprocess / cp_resize_u8 against oracle/cv_emul.py (integer emulation of cv2.warpAffine / cv2.resize with
+    INTER_LINEAR on 8-bit images -- PARITY UNPINNED, cv2 is absent -- followed by the reference's
+    (x / 255 - mean) / std, base_detector.py:127-134): the rounded grey levels are identical, so the float32 inputs agree
+    to the last bit of the float64 -> float32 cast."""
+    from centerpose_amd.lib.utils.image import get_affine_transform
+    from oracle import cv_emul as cv
 
     rng = np.random.RandomState(3)
-    img = rng.randint(0, 256, (480, 640, 3)).astype(np.uint8)
-    c = np.array([320.0, 240.0], np.float32)
-    trans = get_affine_transform(c, 640.0, 0, [512, 512])
     mean = np.array([0.408, 0.447, 0.470], np.float32)
     std = np.array([0.289, 0.274, 0.278], np.float32)
-    ref = ((warp_affine_bilinear(img, trans, 512, 512) / 255.0 - mean.reshape(1, 1, 3)) / std.reshape(1, 1, 3))
-    ref = ref.astype(np.float32).transpose(2, 0, 1)
-    out = hip.preprocess(torch.from_numpy(img).to(device), trans, mean, std, 512, 512).cpu().numpy()[0]
-    np.testing.assert_allclose(out, ref, atol=2e-4)
+    for (h, w), s in (((480, 640), 640.0), ((600, 800), 800.0), ((97, 131), 131.0)):
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        c = np.array([w / 2.0, h / 2.0], np.float32)
+        trans = get_affine_transform(c, s, 0, [512, 512])
+        warped = cv.warp_affine_u8(img, trans, (512, 512))
+        ref = ((warped / 255.0 - mean.reshape(1, 1, 3)) / std.reshape(1, 1, 3)).astype(np.float32).transpose(2, 0, 1)
+        out = hip.preprocess(torch.from_numpy(img).to(device), trans, mean, std, 512, 512).cpu().numpy()[0]
+        np.testing.assert_array_equal(out, ref)
     assert out[:, 0, 0].tolist() == pytest.approx(((0 - mean) / std).tolist(), abs=1e-6)  # padding rows are "black"
+    # resize (multi-scale testing, scale != 1): up, down, odd sizes
+    img = rng.randint(0, 256, (120, 160, 3)).astype(np.uint8)
+    for oh, ow in ((180, 240), (60, 80), (97, 203), (120, 160)):
+        got = hip.resize_u8(torch.from_numpy(img).to(device), oh, ow).cpu().numpy()
+        np.testing.assert_array_equal(got, cv.resize_linear_u8(img, (ow, oh)))
 
 
 def test_device_postprocess_soft_nms_matches_reference_golden(device):
