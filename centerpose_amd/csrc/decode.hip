@@ -18,7 +18,6 @@
 namespace {
 
 constexpr int PK_THREADS = 1024;
-constexpr int PK_NPT = 16;  // pixels per lane -> maps up to 16384 pixels (128 x 128)
 constexpr float NEGV = -10000.0f;
 
 __device__ __forceinline__ uint32_t f2ord(float f) {
@@ -89,16 +88,18 @@ __device__ void block_sum2(int a, int b, int* sh /*[34]*/, int* ta, int* tb) {
 // Keys are therefore classed first -- positive / zero / negative -- and the radix select only runs over the positive
 // ones when they already fill the top K (always, for sigmoid heat-maps); the zeros are taken by index when they do not;
 // only maps that need negative values walk the general path.
-constexpr int PK_G = 4;
 constexpr uint32_t ZKEY = 0x80000000u;  // f2ord(+0.0f)
 
+// PK_G = 4: maps up to 16384 pixels (128 x 128, 64 KB of LDS); PK_G = 8: up to 32768 (e.g. --keep_res 480 x 640 frames ->
+// 120 x 160, or --input_res 1024 x 512 -> 256 x 128; 128 KB of the CU's 160 KB LDS)
+template <int PK_G>
 __global__ __launch_bounds__(PK_THREADS) void peaks_kernel(float* __restrict__ hm, float* __restrict__ hm_hp,
                                                            int J, int H, int W, int K, int apply_sigmoid,
                                                            float* __restrict__ pk_score, int* __restrict__ pk_ind) {
     const int mi = blockIdx.x, b = blockIdx.y, nm = gridDim.x;
     const int HW = H * W, n4 = HW >> 2;
     float* map = (mi == 0) ? hm + (size_t)b * HW : hm_hp + ((size_t)b * J + (mi - 1)) * HW;
-    __shared__ __attribute__((aligned(16))) float smap[PK_THREADS * PK_NPT];  // 64 KB: the whole map
+    __shared__ __attribute__((aligned(16))) float smap[PK_THREADS * PK_G * 4];  // the whole map
     __shared__ int hist[256];
     __shared__ int scan_sh[34];
     __shared__ int sel[2];  // digit, need
@@ -493,11 +494,15 @@ int cp_launch_decode(hipStream_t s, int B, int J, int H, int W, float* hm, const
                      const float* hps_unc, const float* scale, const float* scale_unc, const float* reg, float* hm_hp,
                      const float* hp_offset, const float* tracking, const float* tracking_hp, int K, int rep_mode,
                      int fit_gaussian, float balance, int legacy_bool_mask, int apply_sigmoid, float* det, void* ws) {
-    if (H * W > PK_THREADS * PK_NPT || H * W < K || K < 1 || K > 128 || J < 1 || W % 4 != 0) return CP_ERR_INVALID;
+    if (H * W > PK_THREADS * 32 || H * W < K || K < 1 || K > 128 || J < 1 || W % 4 != 0) return CP_ERR_INVALID;
     float* pk_score = (float*)ws;
     int* pk_ind = (int*)((char*)ws + (size_t)B * (J + 1) * K * 4);
-    hipLaunchKernelGGL(peaks_kernel, dim3(J + 1, B), dim3(PK_THREADS), 0, s, hm, hm_hp, J, H, W, K, apply_sigmoid,
-                       pk_score, pk_ind);
+    if (H * W <= PK_THREADS * 16)
+        hipLaunchKernelGGL(peaks_kernel<4>, dim3(J + 1, B), dim3(PK_THREADS), 0, s, hm, hm_hp, J, H, W, K, apply_sigmoid,
+                           pk_score, pk_ind);
+    else
+        hipLaunchKernelGGL(peaks_kernel<8>, dim3(J + 1, B), dim3(PK_THREADS), 0, s, hm, hm_hp, J, H, W, K, apply_sigmoid,
+                           pk_score, pk_ind);
     AssocParams p;
     p.hps = hps; p.wh = wh; p.hps_unc = hps_unc; p.scale = scale; p.scale_unc = scale_unc; p.reg = reg;
     p.hm_hp = hm_hp; p.hp_offset = hp_offset; p.tracking = tracking; p.tracking_hp = tracking_hp;

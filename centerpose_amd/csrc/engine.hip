@@ -457,21 +457,22 @@ struct Packer {
     }
     void run() {
         conv_bn("base.base_layer", "base.base_layer.0", "base.base_layer.1", 16, 3, 7, 4);
-        if (m->tracking) {
-            conv_bn("base.pre_img_layer", "base.pre_img_layer.0", "base.pre_img_layer.1", 16, 3, 7, 4);
-            conv_bn("base.pre_hm_layer", "base.pre_hm_layer.0", "base.pre_hm_layer.1", 16, 1, 7, 4);
-            conv_bn("base.pre_hm_hp_layer", "base.pre_hm_hp_layer.0", "base.pre_hm_hp_layer.1", 16, 8, 7, 8);
-        }
+        // previous-frame stems: each exists iff its own flag was set when the checkpoint was made
+        // (pose_dla_dcn.py:253-271), i.e. iff its weights were supplied
+        const bool has_pre_img = m->params.count("base.pre_img_layer.0.weight") != 0;
+        const bool has_pre_hm = m->params.count("base.pre_hm_layer.0.weight") != 0;
+        const bool has_pre_hm_hp = m->params.count("base.pre_hm_hp_layer.0.weight") != 0;
+        if (has_pre_img) conv_bn("base.pre_img_layer", "base.pre_img_layer.0", "base.pre_img_layer.1", 16, 3, 7, 4);
+        if (has_pre_hm) conv_bn("base.pre_hm_layer", "base.pre_hm_layer.0", "base.pre_hm_layer.1", 16, 1, 7, 4);
+        if (has_pre_hm_hp) conv_bn("base.pre_hm_hp_layer", "base.pre_hm_hp_layer.0", "base.pre_hm_hp_layer.1", 16, 8, 7, 8);
         conv_bn("base.level0", "base.level0.0", "base.level0.1", 16, 16, 3);
         conv_bn("base.level1", "base.level1.0", "base.level1.1", 32, 16, 3);
         // f16x3 fragments of the same layers (after conv_bn: they take the folded BatchNorm from the ConvW)
         lowc("base.base_layer", "base.base_layer.0", 0, 16, 3, 7);
         lowc("base.level0", "base.level0.0", 1, 16, 16, 3);
         lowc("base.level1", "base.level1.0", 2, 32, 16, 3);
-        if (m->tracking) {
-            lowc("base.pre_img_layer", "base.pre_img_layer.0", 0, 16, 3, 7);
-            lowc("base.pre_hm_layer", "base.pre_hm_layer.0", 0, 16, 1, 7);
-        }
+        if (has_pre_img) lowc("base.pre_img_layer", "base.pre_img_layer.0", 0, 16, 3, 7);
+        if (has_pre_hm) lowc("base.pre_hm_layer", "base.pre_hm_layer.0", 0, 16, 1, 7);
         tree("base.level2", 1, 32, 64, false);
         tree("base.level3", 2, 64, 128, true);
         tree("base.level4", 2, 128, 256, true);
@@ -1023,7 +1024,18 @@ struct Fwd {
             Tensor in = to_nhwc(images, 3, 4, H, W);
             x0 = conv(cw("base.base_layer"), {&in}, 1, 3, CP_ACT_RELU);
         }
-        if (m->tracking && (pre_img || pre_hm || pre_hm_hp)) {
+        // a dry run (workspace query) is sized for every stem the model has
+        if (m->dry) {
+            if (!m->convs.count("base.pre_img_layer")) pre_img = nullptr;
+            if (!m->convs.count("base.pre_hm_layer")) pre_hm = nullptr;
+            if (!m->convs.count("base.pre_hm_hp_layer")) pre_hm_hp = nullptr;
+        }
+        if ((pre_img && !m->convs.count("base.pre_img_layer")) || (pre_hm && !m->convs.count("base.pre_hm_layer")) ||
+            (pre_hm_hp && !m->convs.count("base.pre_hm_hp_layer"))) {
+            chk(fail(CP_ERR_INVALID, "a previous-frame input was given to a model built without that pre_* layer"));
+            return;
+        }
+        if (pre_img || pre_hm || pre_hm_hp) {
             Tensor a, b, c;
             if (pre_img) {
                 a = lowc("base.pre_img_layer", 0, pre_img, H, W, 3,
@@ -1469,7 +1481,7 @@ int cp_model_detect(cp_model* m, cp_stream_t stream, int B, int H, int W, const 
             (void)hipEventRecord(r.e1, s);
             m->prof.push_back(r);
         }
-        if (rc != CP_OK) return fail(rc, "detect: decode failed (need K <= 128 <= H*W/16 <= 16384)");
+        if (rc != CP_OK) return fail(rc, "detect: decode failed (need K <= 128 <= H*W/16 <= 32768)");
         return rc;
     };
     if (!use_graph || m->profile) return enqueue();
@@ -1689,7 +1701,7 @@ int cp_decode(cp_stream_t stream, int B, int H, int W, float* hm, const float* h
     int rc = cp_launch_decode((hipStream_t)stream, B, 8, H, W, hm, hps, wh, hps_uncertainty, scale, scale_uncertainty,
                               reg, hm_hp, hp_offset, tracking, tracking_hp, K, rep_mode, fit_gaussian, balance,
                               legacy_bool_mask, apply_sigmoid, det, workspace);
-    if (rc != CP_OK) return fail(rc, "decode: unsupported shape (need K <= 128 <= H*W <= 16384) or launch failure");
+    if (rc != CP_OK) return fail(rc, "decode: unsupported shape (need K <= 128 <= H*W <= 32768, W % 4 == 0) or launch failure");
     return CP_OK;
 }
 

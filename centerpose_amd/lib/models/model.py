@@ -29,8 +29,8 @@ class HipPoseNet(object):
         self.heads = OrderedDict(heads)
         self.head_conv = head_conv
         self.opt = opt
-        self.tracking = bool(opt is not None and (getattr(opt, 'pre_img', False) or getattr(opt, 'pre_hm', False)
-                                                 or getattr(opt, 'pre_hm_hp', False)))
+        # each previous-frame stem is created from its own flag (pose_dla_dcn.py:253-271)
+        self.tracking = tuple(bool(opt is not None and getattr(opt, f, False)) for f in ('pre_img', 'pre_hm', 'pre_hm_hp'))
         self.tracking_task = bool(opt is not None and getattr(opt, 'tracking_task', False))
         self._spec = _synth.param_spec(self.arch, self.heads, self.tracking, head_conv)
         # construction-time values follow the reference's initialisers where they are deterministic

@@ -165,8 +165,11 @@ def param_spec(arch="dla_34", heads=None, tracking=False, head_conv=256):
     _tree(s, "base.level3", 2, ch[2], ch[3], True)
     _tree(s, "base.level4", 2, ch[3], ch[4], True)
     _tree(s, "base.level5", 1, ch[4], ch[5], True)
-    if tracking:
-        for nm, cin in (("pre_img_layer", 3), ("pre_hm_layer", 1), ("pre_hm_hp_layer", 8)):
+    # the three previous-frame stems exist independently (pose_dla_dcn.py:253-271: opt.pre_img / pre_hm / pre_hm_hp);
+    # `tracking` may be a bool (all or none) or a (pre_img, pre_hm, pre_hm_hp) triple
+    pre = tuple(bool(v) for v in tracking) if isinstance(tracking, (tuple, list)) else (bool(tracking),) * 3
+    for on, (nm, cin) in zip(pre, (("pre_img_layer", 3), ("pre_hm_layer", 1), ("pre_hm_hp_layer", 8))):
+        if on:
             s["base.%s.0.weight" % nm] = (16, cin, 7, 7)
             _bn(s, "base.%s.1" % nm, 16)
     _ida(s, "dla_up.ida_0", 256, [256, 512], [1, 2])

@@ -158,7 +158,7 @@ int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const flo
  * Heat-map decode — replaces `object_pose_decode(..., Inference=True)` (models/decode.py:72-375,
  *   models/utils.py:43-47; called from detectors/object_pose.py:154-161) including the 13
  *   device->host copies and the per-point Python loop (decode.py:191-252).
- * Inputs are the head tensors, NCHW float32 on the device, H x W = output grid (<= 16384 pixels),
+ * Inputs are the head tensors, NCHW float32 on the device, H x W = output grid (<= 32768 pixels, W % 4 == 0),
  * one category, 8 joints: hm [B,1,H,W], hps [B,16,H,W], wh [B,2,H,W], hm_hp [B,8,H,W] are
  * required (the detector's Inference configuration); hps_uncertainty [B,16], scale [B,3],
  * scale_uncertainty [B,3], reg [B,2], hp_offset [B,2], tracking [B,2], tracking_hp [B,16] may be

@@ -401,6 +401,22 @@ def test_fused_head_matches_unfused_path(device):
         assert float((z[k] - zu[k]).abs().max()) < 2e-5 * max(1.0, float(zu[k].abs().max())), k
 
 
+def test_previous_frame_stems_are_independent(device):
+    """Each pre_* stem exists iff its own flag was set (pose_dla_dcn.py:253-271): a checkpoint with only pre_img_layer
+    loads, uses pre_img, and refuses a pre_hm it has no layer for (instead of ignoring it)."""
+    heads = synth.HEADS_TRACK
+    sd = synth.make_state_dict("dla_34", heads, True)
+    sd = {k: v for k, v in sd.items() if "pre_hm_layer" not in k and "pre_hm_hp_layer" not in k}
+    x, kw = mg.backbone_inputs(True)
+    model = hip.HipModel("dla_34", heads, sd, tracking_task=True, precision="f16x3")
+    z = model(x.to(device), pre_img=kw["pre_img"].to(device), sigmoid_hm=True)
+    zo = ob.dlaseg_forward(sd, x, heads, arch="dla", tracking_task=True, pre_img=kw["pre_img"])
+    assert float((z["hm"].cpu() - torch.sigmoid(zo["hm"])).abs().max()) < 1e-3
+    assert float((z["tracking"].cpu() - zo["tracking"]).abs().max()) < 1e-3 * max(1.0, float(zo["tracking"].abs().max()))
+    with pytest.raises(RuntimeError, match="pre_"):
+        model(x.to(device), pre_img=kw["pre_img"].to(device), pre_hm=kw["pre_hm"].to(device))
+
+
 def test_model_missing_parameter_fails_loudly(device):
     sd = synth.make_state_dict("dla_34")
     del sd["base.level3.tree1.root.conv.weight"]
