@@ -12,8 +12,9 @@
 //   * software pipeline: the raw corner vectors of tile t+1 are issued BEFORE the MFMAs of tile t and blended /
 //     converted / stored after them (one register set of A_SLOTS x 4 float4), so the L2 round trip of the gather
 //     hides under the matrix work instead of preceding it;
-//   * the (dh, dw, mask) triple of the NEXT tap is prefetched into registers while the current tap is multiplied, so
-//     the bilinear set-up at a tap boundary never waits on memory;
+//   * the bilinear set-up of all 9 taps of the tile's 128 pixels is computed once per block into an LDS table (not once
+//     per lane and tap: 8 lanes share a pixel row), so a tap boundary costs two LDS reads and a few selects per row;
+//   * the 4-corner blend runs on packed float32 FMAs (two channels per instruction);
 //   * 8 waves per block for the 128-wide N tile (two pixel rows per thread instead of four: half the gather state per
 //     thread, no spills next to the 64 accumulators' worth of output).
 // Measured effect of the pipelining: +4 % (N 64) / +12 % (N 128) -- the gather is not latency- but issue-bound: a K tile
@@ -41,6 +42,14 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void dcn16_kernel(const ConvPara
     constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;
     constexpr int BUF = 2 * A_SZ + 2 * B_SZ;
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * BUF];
+    // Bilinear set-up of every (pixel row, tap) of the tile, computed ONCE by the block (1152 entries over its threads)
+    // instead of once per lane: the 8 lanes that share a pixel row used to repeat the floor / compare / index
+    // arithmetic (with its quarter-rate integer multiplies) per tap -- PMC of the previous version: 302 VALU
+    // instructions per wave and K tile against 12 MFMAs, i.e. the kernel was VALU-bound (42 % VALU busy, TA 58 %, MFMA
+    // 13 %).  Entry: byte offset of corner (h_lo, w_lo) with the 4 corner-validity bits in its low bits (the offset is
+    // a multiple of Cin * 4 >= 128), and the 4 corner weights (mask and activation pre-scale folded in).
+    __shared__ int tab_base[BM * 9];
+    __shared__ __attribute__((aligned(16))) float tab_w[BM * 9][4];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -54,22 +63,46 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void dcn16_kernel(const ConvPara
 
     // ---- per-thread pixel rows: row (tid / 8) + RPP * j, float4 column k4 = tid % 8 of the 32-channel K tile ----
     const int k4 = tid & 7;
-    int a_y[A_SLOTS], a_x[A_SLOTS], a_bh[A_SLOTS];  // output pixel (y, x) and image row base b * H
-    unsigned om_off[A_SLOTS];                       // byte offset of the pixel's 32-float offset/mask record
-#pragma unroll
-    for (int j = 0; j < A_SLOTS; ++j) {
-        const int m = tm * BM + (tid >> 3) + j * RPP;
-        const bool ok = m < M;
-        int b, ho, wo;
-        pdec.split(ok ? m : 0, &b, &ho, &wo);
-        a_y[j] = ho;
-        a_x[j] = wo;
-        a_bh[j] = b * p.H;
-        om_off[j] = ok ? (unsigned)m * 128u : OOB;  // H == Ho, W == Wo: the record index is the output pixel index
-    }
     const unsigned img_px = (unsigned)p.B * p.H * p.W;
     const __amdgpu_buffer_rsrc_t r_x = make_rsrc(p.src[0], img_px * (unsigned)p.Cin * 4u);
     const __amdgpu_buffer_rsrc_t r_om = make_rsrc(p.offmask, img_px * 128u);
+    {   // ---- set-up table (dcn_v2_im2col_cuda.cu:25-54, 150-187) ----
+        const int cb = p.Cin * 4;
+        for (int e = tid; e < BM * 9; e += NTH) {
+            const int r = e % BM, tap = e / BM;  // consecutive lanes = consecutive pixels
+            const int m = tm * BM + r;
+            int base = 0;
+            float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+            if (m < M) {
+                int b, y, x;
+                pdec.split(m, &b, &y, &x);
+                const unsigned o = (unsigned)m * 128u;  // H == Ho, W == Wo: the record index is the output pixel index
+                const float dh = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_om, (int)o + (2 * tap) * 4, 0, 0));
+                const float dw = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_om, (int)o + (2 * tap + 1) * 4, 0, 0));
+                const float mk = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_om, (int)o + (18 + tap) * 4, 0, 0)) * afwd;
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const float h_im = (float)(y - 1 + kh) + dh;
+                const float w_im = (float)(x - 1 + kw) + dw;
+                if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
+                    const int h_lo = (int)floorf(h_im), w_lo = (int)floorf(w_im);
+                    const int h_hi = h_lo + 1, w_hi = w_lo + 1;
+                    const float lh = h_im - (float)h_lo, lw = w_im - (float)w_lo;
+                    const float hh = 1.f - lh, hw = 1.f - lw;
+                    int vm = 0;
+                    if (h_lo >= 0 && w_lo >= 0) vm |= 1;
+                    if (h_lo >= 0 && w_hi <= p.W - 1) vm |= 2;
+                    if (h_hi <= p.H - 1 && w_lo >= 0) vm |= 4;
+                    if (h_hi <= p.H - 1 && w_hi <= p.W - 1) vm |= 8;
+                    base = (((b * p.H + h_lo) * p.W + w_lo) * cb) | vm;  // may be "before" the tensor when h_lo / w_lo = -1:
+                                                                          // only valid corners are ever dereferenced
+                    w1 = hh * hw * mk; w2 = hh * lw * mk; w3 = lh * hw * mk; w4 = lh * lw * mk;
+                }
+            }
+            tab_base[e] = base;
+            *reinterpret_cast<float4*>(tab_w[e]) = make_float4(w1, w2, w3, w4);
+        }
+        __syncthreads();
+    }
     const unsigned w_bytes = (unsigned)((size_t)p.CoutPad * p.Kpad16 * 2);
     const __amdgpu_buffer_rsrc_t r_wh = make_rsrc(p.w16_hi, w_bytes), r_wl = make_rsrc(p.w16_lo, w_bytes);
 
@@ -95,44 +128,23 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void dcn16_kernel(const ConvPara
     }
     int b_soff = 0;
 
-    // ---- offset / mask triple of one tap for every pixel row of this thread (out-of-range rows read zeros) ----
-    float om_dh[A_SLOTS], om_dw[A_SLOTS], om_mk[A_SLOTS];
-    auto fetch_om = [&](int tap) {
-#pragma unroll
-        for (int j = 0; j < A_SLOTS; ++j) {
-            const unsigned o = tap < 9 ? om_off[j] : OOB;
-            om_dh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_om, (int)o, (2 * tap) * 4, 0));
-            om_dw[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_om, (int)o, (2 * tap + 1) * 4, 0));
-            om_mk[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_om, (int)o, (18 + tap) * 4, 0));
-        }
-    };
-    // corner byte offsets / weights of the tap being gathered (dcn_v2_im2col_cuda.cu:25-54, 150-187; the mask and the
-    // activation pre-scale ride in the weights)
+    // corner byte offsets / weights of the tap being gathered, expanded from the table
     int d_idx[A_SLOTS][4];
     float d_w[A_SLOTS][4];
     auto setup_tap = [&]() {
-        const int cb = p.Cin * 4;
+        const int cb = p.Cin * 4, rowb = p.W * cb;
 #pragma unroll
         for (int j = 0; j < A_SLOTS; ++j) {
-            int i0 = (int)OOB_BASE, i1 = (int)OOB_BASE, i2 = (int)OOB_BASE, i3 = (int)OOB_BASE;
-            float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
-            const float mk = om_mk[j] * afwd;
-            const float h_im = (float)(a_y[j] - 1 + u_kh) + om_dh[j];
-            const float w_im = (float)(a_x[j] - 1 + u_kw) + om_dw[j];
-            if (om_off[j] != OOB && h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
-                const int h_lo = (int)floorf(h_im), w_lo = (int)floorf(w_im);
-                const int h_hi = h_lo + 1, w_hi = w_lo + 1;
-                const float lh = h_im - (float)h_lo, lw = w_im - (float)w_lo;
-                const float hh = 1.f - lh, hw = 1.f - lw;
-                const int bb = a_bh[j];
-                if (h_lo >= 0 && w_lo >= 0) i0 = ((bb + h_lo) * p.W + w_lo) * cb;
-                if (h_lo >= 0 && w_hi <= p.W - 1) i1 = ((bb + h_lo) * p.W + w_hi) * cb;
-                if (h_hi <= p.H - 1 && w_lo >= 0) i2 = ((bb + h_hi) * p.W + w_lo) * cb;
-                if (h_hi <= p.H - 1 && w_hi <= p.W - 1) i3 = ((bb + h_hi) * p.W + w_hi) * cb;
-                w1 = hh * hw * mk; w2 = hh * lw * mk; w3 = lh * hw * mk; w4 = lh * lw * mk;
-            }
-            d_idx[j][0] = i0; d_idx[j][1] = i1; d_idx[j][2] = i2; d_idx[j][3] = i3;
-            d_w[j][0] = w1; d_w[j][1] = w2; d_w[j][2] = w3; d_w[j][3] = w4;
+            const int e = u_tap * BM + (tid >> 3) + j * RPP;
+            const int bv = tab_base[e];
+            const float4 w = *reinterpret_cast<const float4*>(tab_w[e]);
+            const int base = (bv & ~15) + k4 * 16;  // + this lane's float4 column; the K walk's channel offset is wave-uniform
+                                                     // and rides in the loads' scalar offset
+            d_idx[j][0] = (bv & 1) ? base : (int)OOB_BASE;
+            d_idx[j][1] = (bv & 2) ? base + cb : (int)OOB_BASE;
+            d_idx[j][2] = (bv & 4) ? base + rowb : (int)OOB_BASE;
+            d_idx[j][3] = (bv & 8) ? base + rowb + cb : (int)OOB_BASE;
+            d_w[j][0] = w.x; d_w[j][1] = w.y; d_w[j][2] = w.z; d_w[j][3] = w.w;
         }
     };
 
@@ -144,15 +156,17 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void dcn16_kernel(const ConvPara
     auto issue = [&]() {
         const bool live = tiles_left > 0;
         if (need_setup && live) {
-            setup_tap();          // consumes the prefetched triple of u_tap ...
-            fetch_om(u_tap + 1);  // ... and starts the loads of the next tap's (in flight for Cin / 32 tiles)
+            setup_tap();
             need_setup = false;
         }
-        const unsigned coff = (unsigned)(u_c0 + k4 * 4) * 4u;
+        const int csoff = live ? u_c0 * 4 : 0;  // bytes (range checking ignores the scalar offset: an OOB index stays OOB)
 #pragma unroll
         for (int j = 0; j < A_SLOTS; ++j)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) raw[j][c] = buf_ld4(r_x, live ? (unsigned)d_idx[j][c] + coff : OOB);
+            for (int c = 0; c < 4; ++c) {
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r_x, live ? d_idx[j][c] : (int)OOB, csoff, 0);
+                raw[j][c] = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
+            }
 #pragma unroll
         for (int j = 0; j < B_SLOTS; ++j) {
             const unsigned vo = live ? b_off[j] : OOB;
@@ -178,13 +192,20 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void dcn16_kernel(const ConvPara
         _Float16* Bl = Bh + B_SZ;
 #pragma unroll
         for (int j = 0; j < A_SLOTS; ++j) {
-            const float w1 = d_w[j][0], w2 = d_w[j][1], w3 = d_w[j][2], w4 = d_w[j][3];
+            // fma(w4, v4, fma(w3, v3, fma(w2, v2, w1 * v1))) per component, two components per v_pk_fma_f32
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 w1 = {d_w[j][0], d_w[j][0]}, w2 = {d_w[j][1], d_w[j][1]}, w3 = {d_w[j][2], d_w[j][2]},
+                        w4 = {d_w[j][3], d_w[j][3]};
             const float4 v1 = raw[j][0], v2 = raw[j][1], v3 = raw[j][2], v4 = raw[j][3];
+            f32x2 lo2 = w1 * f32x2{v1.x, v1.y}, hi2 = w1 * f32x2{v1.z, v1.w};
+            lo2 = __builtin_elementwise_fma(w2, f32x2{v2.x, v2.y}, lo2);
+            hi2 = __builtin_elementwise_fma(w2, f32x2{v2.z, v2.w}, hi2);
+            lo2 = __builtin_elementwise_fma(w3, f32x2{v3.x, v3.y}, lo2);
+            hi2 = __builtin_elementwise_fma(w3, f32x2{v3.z, v3.w}, hi2);
+            lo2 = __builtin_elementwise_fma(w4, f32x2{v4.x, v4.y}, lo2);
+            hi2 = __builtin_elementwise_fma(w4, f32x2{v4.z, v4.w}, hi2);
             float4 v;
-            v.x = fmaf(w4, v4.x, fmaf(w3, v3.x, fmaf(w2, v2.x, w1 * v1.x)));
-            v.y = fmaf(w4, v4.y, fmaf(w3, v3.y, fmaf(w2, v2.y, w1 * v1.y)));
-            v.z = fmaf(w4, v4.z, fmaf(w3, v3.z, fmaf(w2, v2.z, w1 * v1.z)));
-            v.w = fmaf(w4, v4.w, fmaf(w3, v3.w, fmaf(w2, v2.w, w1 * v1.w)));
+            v.x = lo2.x; v.y = lo2.y; v.z = hi2.x; v.w = hi2.y;
             const int row = (tid >> 3) + j * RPP;
             const Split2 s0 = split2(v.x, v.y), s1 = split2(v.z, v.w);
             const int col = ((((k4 >> 1) ^ swz(row)) << 1) | (k4 & 1)) * 4;  // halfs
@@ -249,8 +270,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void dcn16_kernel(const ConvPara
         }
     };
 
-    // ---- prologue: the first tap's triple, tile 0 into buffer 0 ----
-    fetch_om(u_tap);
+    // ---- prologue: tile 0 into buffer 0 ----
     issue();
     blend_store(0);
     __syncthreads();
@@ -288,6 +308,6 @@ int cp_launch_dcn16(const ConvParams& p, int bn, int variant, hipStream_t stream
     // measured on the dlav1_34 B=32 step (profiles/r02_dcn_ab.txt): N 64: 4 waves of 64x32, two blocks per CU (110 TFLOP/s)
     // vs 8 waves at 128 VGPRs (108); N 128: 8 waves of 64x32, one block per CU (152) vs 4 waves of 64x64 at 256 VGPRs (136)
     if (bn == 64) return variant ? launch_dcn16<1, 1, 4, 2, 4>(p, stream) : launch_dcn16<2, 1, 2, 2, 2>(p, stream);
-    if (bn == 128) return variant ? launch_dcn16<2, 2, 2, 2, 2>(p, stream) : launch_dcn16<2, 1, 2, 4, 2>(p, stream);
+    if (bn == 128) return variant ? launch_dcn16<2, 2, 2, 2, 1>(p, stream) : launch_dcn16<2, 1, 2, 4, 2>(p, stream);
     return CP_ERR_INVALID;
 }

@@ -28,7 +28,12 @@ constexpr int PROW = CK;                                                  // hal
 // writes of 8 lanes (one pixel, 8 chunks) do too
 __device__ __forceinline__ int pswz(int q) { return q & 7; }
 
-template <int MT, int NT, int WM, int WN>
+// BDIRECT (the 32-wide N tile: conv_offset_mask, 6 MFMAs per wave and K tile): the weight fragments are loaded from
+// global memory straight into the MFMA operand registers -- the packed weights are k-contiguous per output channel,
+// so a lane's fragment (row n = lane % 32, 8 consecutive k) IS one 16-byte load -- one K tile ahead.  With the patch
+// static and no weight tile in LDS the K loop has no barrier at all; with only 192 MFMA cycles between barriers the
+// staged version was barrier-latency-bound.
+template <int MT, int NT, int WM, int WN, bool BDIRECT = false>
 __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
     constexpr int B_SZ = BN * LDH;
     __shared__ __attribute__((aligned(16))) _Float16 patch_hi[NPIX * PROW];
     __shared__ __attribute__((aligned(16))) _Float16 patch_lo[NPIX * PROW];
-    __shared__ __attribute__((aligned(16))) _Float16 bt[2][2 * B_SZ];  // [buffer][hi | lo]
+    __shared__ __attribute__((aligned(16))) _Float16 bt[BDIRECT ? 1 : 2][BDIRECT ? 8 : 2 * B_SZ];  // [buffer][hi | lo]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -107,10 +112,27 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
     }
     const int b_frag = (wn * (NT * 32) + lcol) * LDH;
 
+    // BDIRECT: this lane's fragment rows of the packed weights (n = wn tile + j * 32 + lcol), 16-byte k chunk lrow (+ 2 ks)
+    unsigned bd_off[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+        bd_off[j] = (unsigned)(((size_t)(tn * BN + wn * (NT * 32) + j * 32 + lcol) * p.Kpad16 + lrow * 8) * 2);
+    u32x4 dbh[2][2][NT], dbl[2][2][NT];  // [register set][k-step][fragment]
+    auto issue_bd = [&](int set, int kbyte) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                dbh[set][ks][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wh, (int)bd_off[j] + ks * 32, kbyte, 0);
+                dbl[set][ks][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)bd_off[j] + ks * 32, kbyte, 0);
+            }
+    };
+
     const int nchunks = p.Cin / CK;
     for (int ch = 0; ch < nchunks; ++ch) {
         // first weight tile of the chunk in flight while the patch is staged
-        issue_b(((0 * p.Cin) + ch * CK) * 2);
+        if (BDIRECT) issue_bd(0, ((0 * p.Cin) + ch * CK) * 2);
+        else issue_b(((0 * p.Cin) + ch * CK) * 2);
         if (ch > 0) __syncthreads();  // every wave is done reading the previous chunk's patch
         // ---- stage the halo patch of this 64-channel chunk: float32 global -> hi / lo binary16 planes ----
 #pragma unroll 4
@@ -128,16 +150,17 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
                 *reinterpret_cast<u32x2*>(patch_lo + q * PROW + col) = u32x2{s0.lo, s1.lo};
             }
         }
-        store_b(0);
+        if (!BDIRECT) store_b(0);
         __syncthreads();
         // ---- 18 K tiles: (tap, 32-channel half) ----
-#pragma unroll 1
+#pragma unroll 2
         for (int kt = 0; kt < 18; ++kt) {
             const int cur = kt & 1;
             const int tap = kt >> 1, half = kt & 1;
             if (kt + 1 < 18) {
                 const int tap1 = (kt + 1) >> 1, half1 = (kt + 1) & 1;
-                issue_b((tap1 * p.Cin + ch * CK + half1 * 32) * 2);
+                if (BDIRECT) issue_bd(cur ^ 1, (tap1 * p.Cin + ch * CK + half1 * 32) * 2);
+                else issue_b((tap1 * p.Cin + ch * CK + half1 * 32) * 2);
             }
             const int kh = tap / 3, kw = tap - kh * 3;
             const int dq = kh * PW + kw;
@@ -157,8 +180,13 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
                 const int co = ((ks * 2 + lrow) ^ swz(lcol)) * 8;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    bh[j] = *reinterpret_cast<const h8*>(Bh + j * 32 * LDH + co);
-                    bl[j] = *reinterpret_cast<const h8*>(Bl + j * 32 * LDH + co);
+                    if (BDIRECT) {
+                        bh[j] = *reinterpret_cast<const h8*>(&dbh[cur][ks][j]);
+                        bl[j] = *reinterpret_cast<const h8*>(&dbl[cur][ks][j]);
+                    } else {
+                        bh[j] = *reinterpret_cast<const h8*>(Bh + j * 32 * LDH + co);
+                        bl[j] = *reinterpret_cast<const h8*>(Bl + j * 32 * LDH + co);
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -176,8 +204,10 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             }
-            if (kt + 1 < 18) store_b(cur ^ 1);
-            __syncthreads();
+            if (!BDIRECT) {
+                if (kt + 1 < 18) store_b(cur ^ 1);
+                __syncthreads();
+            }
         }
     }
 
@@ -249,11 +279,12 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
     if (p.out_amax) cp_amax_commit(p.out_amax, amax);
 }
 
-template <int MT, int NT, int WM, int WN>
+template <int MT, int NT, int WM, int WN, bool BDIRECT = false>
 int launch_halo(const ConvParams& p, hipStream_t stream) {
     constexpr int BN = 32 * NT * WN;
     const int tiles_m = p.B * (p.H / TH) * (p.W / TW), tiles_n = p.CoutPad / BN;
-    hipLaunchKernelGGL((halo16_kernel<MT, NT, WM, WN>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m, tiles_n);
+    hipLaunchKernelGGL((halo16_kernel<MT, NT, WM, WN, BDIRECT>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m,
+                       tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
@@ -271,6 +302,6 @@ int cp_launch_halo16(const ConvParams& p, int bn, hipStream_t stream) {
     if (!cp_halo16_supported(p) || p.CoutPad % bn != 0) return CP_ERR_INVALID;
     if (bn == 128) return launch_halo<2, 2, 2, 2>(p, stream);
     if (bn == 64) return launch_halo<2, 1, 2, 2>(p, stream);
-    if (bn == 32) return launch_halo<1, 1, 4, 1>(p, stream);
+    if (bn == 32) return (p.dbg & 16384) ? launch_halo<1, 1, 4, 1>(p, stream) : launch_halo<1, 1, 4, 1, true>(p, stream);
     return CP_ERR_INVALID;
 }

@@ -4,7 +4,10 @@ Put ``centerpose_amd/`` on ``sys.path`` (instead of the reference's ``src/``) an
 ``demo.py`` imports — ``lib.opts.opts``, ``lib.detectors.detector_factory.detector_factory``,
 ``lib.models.model.create_model/load_model``, ``lib.models.decode.object_pose_decode``,
 ``lib.utils.pnp.cuboid_pnp_shell.pnp_shell`` — resolve here, with the compute routed to
-libcenterpose_hip.so.  Only what the hot path needs is mirrored (no training, datasets, tracker).
+libcenterpose_hip.so.  Only what the inference hot path needs is mirrored: detectors (incl. the CenterPoseTrack
+per-frame loop with ``lib.utils.tracker.Tracker`` / ``Tracker_baseline``), opts, model factory, decode, PnP packaging;
+no training, datasets, losses, evaluation or drawing.  The reference's own ``src/demo.py`` runs unmodified against it
+(tests/test_demo_dropin.py).
 """
 import os as _os
 import sys as _sys
