@@ -28,11 +28,12 @@ constexpr int PROW = CK;                                                  // hal
 // writes of 8 lanes (one pixel, 8 chunks) do too
 __device__ __forceinline__ int pswz(int q) { return q & 7; }
 
-// BDIRECT (the 32-wide N tile: conv_offset_mask, 6 MFMAs per wave and K tile): the weight fragments are loaded from
-// global memory straight into the MFMA operand registers -- the packed weights are k-contiguous per output channel,
-// so a lane's fragment (row n = lane % 32, 8 consecutive k) IS one 16-byte load -- one K tile ahead.  With the patch
-// static and no weight tile in LDS the K loop has no barrier at all; with only 192 MFMA cycles between barriers the
-// staged version was barrier-latency-bound.
+// BDIRECT (experiment, off by default): the weight fragments of the 32-wide N tile loaded from global memory straight
+// into the MFMA operand registers (a lane's fragment -- row n = lane % 32, 8 consecutive k -- is one 16-byte load of the
+// k-contiguous packed weights), one K tile ahead, so that the K loop has no barrier at all.  Measured on the B=32 step
+// (profiles/r02_halo_ab.txt): 80 TFLOP/s against 106 for the LDS-staged tile -- neighbouring lanes read different
+// weight rows (1152 B apart), every lane its own cache line, and the texture addresser needs 4x the cycles of a
+// coalesced load; 8 such loads per wave and K tile cost more than the barrier they remove.
 template <int MT, int NT, int WM, int WN, bool BDIRECT = false>
 __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     typedef Frag<32> F;
@@ -302,6 +303,7 @@ int cp_launch_halo16(const ConvParams& p, int bn, hipStream_t stream) {
     if (!cp_halo16_supported(p) || p.CoutPad % bn != 0) return CP_ERR_INVALID;
     if (bn == 128) return launch_halo<2, 2, 2, 2>(p, stream);
     if (bn == 64) return launch_halo<2, 1, 2, 2>(p, stream);
-    if (bn == 32) return (p.dbg & 16384) ? launch_halo<1, 1, 4, 1>(p, stream) : launch_halo<1, 1, 4, 1, true>(p, stream);
+    // (cp_set_debug 16384: the BDIRECT experiment -- measured SLOWER, 80 vs 106 TFLOP/s: see the template's comment)
+    if (bn == 32) return (p.dbg & 16384) ? launch_halo<1, 1, 4, 1, true>(p, stream) : launch_halo<1, 1, 4, 1>(p, stream);
     return CP_ERR_INVALID;
 }
