@@ -26,6 +26,14 @@ def variant(kname):
         gru = len(extra) > 1 and extra[1]
         pre = "igemm16_gru" if gru else "igemm16_head" if mp.group(6) == "true" else "igemm16_cat" if mp.group(5) == "true" else "igemm16"
         return "%s_f16x3_m%dn%d" % (pre, 32 * mt * wm, 32 * nt * wn)
+    md = re.search(r"dcn16_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", kname)
+    if md:  # <MT, NT, WM, WN, OCC>
+        mt, nt, wm, wn = (int(md.group(i)) for i in range(1, 5))
+        return "dcn_igemm16_f16x3_m%dn%d" % (32 * mt * wm, 32 * nt * wn)
+    mh = re.search(r"halo16_kernel<(\d+), (\d+), (\d+), (\d+)", kname)
+    if mh:
+        mt, nt, wm, wn = (int(mh.group(i)) for i in range(1, 5))
+        return "halo16_f16x3_m%dn%d" % (32 * mt * wm, 32 * nt * wn)
     ml = re.search(r"lowc_kernel<(\d+), (\d+), (\d+), ", kname)
     if ml:
         return {("4", "1"): "lowc_stem7x7_f16x3", ("16", "1"): "lowc_3x3_c16_f16x3",
