@@ -374,7 +374,10 @@ def main():
                        "arch": pipe.arch, "global_batch": world * batch, "input": "512x512",
                        "parallelism": "batch-shard x%d (%s)" % (
                            world, "all-gather of detection records" if pipe.track else "no collective"),
-                       "gflop_per_image": gf},
+                       "gflop_per_image": gf,
+                       **({"gflop_note": "603.7 = BASELINE.md's 739.2 GFLOP/img for the reference module minus the 135.3 of the "
+                                         "first stack's seven heads, which do not feed model(x)[-1] (object_pose.py:135) and "
+                                         "are not computed"} if pipe.arch == "hourglass" else {})},
             "p50_frame_ms_batch1": lat,
             "whole_step_tflops": round(value * gf / 1e3 / world, 2),
             "roofline": roof, "configs2": cfg2, "cpu_baseline": cpu,
