@@ -156,7 +156,7 @@ int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream);
 // K steps (of 16 for the f32 kernels, 32 for f16x3) and output tiles of the launch cp_launch_conv[16] would make
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 30
+#define CP_NUM_CONV_VARIANTS 31
 #define CP_VARIANT_GRU 26
 // split-f16 ("f16x3") implicit GEMM (igemm16.hip)
 bool cp_conv16_supported(const ConvParams& p);
@@ -167,6 +167,11 @@ bool cp_halo16_supported(const ConvParams& p);
 int cp_launch_halo16(const ConvParams& p, int bn, hipStream_t stream);
 // fused DCNv2 gather + contraction (dcn16.hip); bn = N tile (64 / 128), variant = alternative wave count (tuning)
 int cp_launch_dcn16(const ConvParams& p, int bn, int variant, hipStream_t stream);
+// dcn16p.hip: patch-resident DCNv2 (gather from an LDS-staged halo); N tile 64
+bool cp_dcn16p_supported(const ConvParams& p);
+int cp_dcn16p_blocks(const ConvParams& p);
+int cp_launch_dcn16p(const ConvParams& p, hipStream_t stream);
+#define CP_VARIANT_DCN16P 30
 // `fwd` (may be nullptr = 1): per-output-channel power-of-two factor applied before the split, indexed [coff + co]
 int cp_launch_pack_weight16(const float* w, void* hi, void* lo, int Cout, int Cin, int taps, int Kpad16, int coff,
                             const float* fwd, hipStream_t s);

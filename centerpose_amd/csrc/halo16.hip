@@ -15,7 +15,7 @@
 // order than igemm16p_kernel (results agree to float32 round-off, both inside the parity budget).
 // Requirements (else the launcher falls back to igemm16p_kernel): 3x3, stride 1, pad 1, one source, Cin % 64 == 0,
 // H % 8 == 0, W % 16 == 0, NHWC output, no split-K.
-#include "igemm16_common.h"
+#include "patch16_common.h"
 
 namespace {
 
@@ -212,72 +212,7 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
         }
     }
 
-    // ---- epilogue: y = acc * scale[n] * 2^-e_a + shift[n] (+ residual) -> activation -> NHWC store (full tiles only);
-    //      GroupNorm statistics and |max| tracking as igemm_epilogue ----
-    const int act = p.act;
-    const bool has_res = p.res != nullptr, has_gn = p.gn_stats != nullptr;
-    float amax = 0.f;
-    const int h4 = lane >> 5;  // fragment rows (r & 3) + 8 (r >> 2) + 4 h4
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = tn * BN + wn * (NT * 32) + j * 32 + lcol;
-        const float sc = (p.scale ? p.scale[n] : 1.f) * ainv;
-        const float sh = p.shift ? p.shift[n] : 0.f;
-        const bool n_ok = n < p.Cout;
-        const bool sig_lane = act == CP_ACT_SIGMOID || (act == CP_ACT_SIGMOID_FROM && n >= p.act_from);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            // fragment = tile rows m0 .. m0 + 31 = patch rows y, y + 1 (16 pixels each)
-            const int m0 = wm * (MT * 32) + i * 32;
-            const int pix0 = __builtin_amdgcn_readfirstlane((b * p.H + ty0 + (m0 >> 4)) * p.W + tx0);
-            float v[F::NACC];
-#pragma unroll
-            for (int r = 0; r < F::NACC; ++r) v[r] = acc[i][j][r] * sc + sh;
-            if (has_res) {
-                const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res + (size_t)pix0 * p.res_ld, (unsigned)((p.W + TW) * p.res_ld) * 4u);
-                const unsigned vr = n_ok ? (unsigned)(4 * h4 * p.res_ld + n) * 4u : 0x80000000u;
-#pragma unroll
-                for (int r = 0; r < F::NACC; ++r) {
-                    const int so = (((r >> 3) * p.W) + 8 * ((r >> 2) & 1) + (r & 3)) * p.res_ld * 4;
-                    v[r] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, (int)vr, so, 0));
-                }
-            }
-            if (act == CP_ACT_RELU) {
-#pragma unroll
-                for (int r = 0; r < F::NACC; ++r) v[r] = fmaxf(v[r], 0.f);
-            } else if (act == CP_ACT_SIGMOID || act == CP_ACT_SIGMOID_FROM) {
-#pragma unroll
-                for (int r = 0; r < F::NACC; ++r) v[r] = sig_lane ? 1.f / (1.f + expf(-v[r])) : v[r];
-            }
-#pragma unroll
-            for (int r = 0; r < F::NACC; ++r) amax = fmaxf(amax, fabsf(v[r]));
-            if (has_gn) {
-                float s1 = 0.f, s2 = 0.f;
-                if (n_ok) {
-#pragma unroll
-                    for (int r = 0; r < F::NACC; ++r) { s1 += v[r]; s2 += v[r] * v[r]; }
-                }
-#pragma unroll
-                for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-                s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 32, 64);
-                if ((lane & 7) == 0 && lane < 32 && n_ok) {
-                    double* st = p.gn_stats + ((size_t)b * p.gn_groups + n / p.gn_cpg) * 2;
-                    atomicAdd(st, (double)s1);
-                    atomicAdd(st + 1, (double)s2);
-                }
-            }
-            float* frag_out = p.out + (size_t)pix0 * p.ldo + p.coff;
-            const __amdgpu_buffer_rsrc_t ro = make_rsrc(frag_out, (unsigned)((p.W + TW) * p.ldo) * 4u);
-            const unsigned vo = n_ok ? (unsigned)(4 * h4 * p.ldo + n) * 4u : 0x80000000u;
-#pragma unroll
-            for (int r = 0; r < F::NACC; ++r) {
-                const int so = (((r >> 3) * p.W) + 8 * ((r >> 2) & 1) + (r & 3)) * p.ldo * 4;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, (int)vo, so, 0);
-            }
-        }
-    }
-    if (p.out_amax) cp_amax_commit(p.out_amax, amax);
+    patch_epilogue<MT, NT, WM, WN>(p, acc, b, ty0, tx0, tn, wm, wn, lane, ainv);
 }
 
 template <int MT, int NT, int WM, int WN, bool BDIRECT = false>

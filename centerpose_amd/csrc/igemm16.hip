@@ -979,6 +979,13 @@ static int conv16_tile_n(const ConvParams& p) {
     return (bn < 32 && p.CoutPad >= 32 && p.CoutPad % 32 == 0) ? 32 : bn;
 }
 
+// DCNv2 layers whose launch fills the chip gather from an LDS-staged halo (dcn16p.hip); small launches keep dcn16.hip
+// (split-K).  cp_set_debug: 32768 = never, 65536 = every eligible layer (tests, A/B runs).
+static bool dcn16p_wanted(const ConvParams& p) {
+    if ((p.dbg & 32768) || (p.dbg & 1024) || !cp_dcn16p_supported(p)) return false;
+    return (p.dbg & 65536) != 0;  // (not yet the default: measured 270 vs 322 us stand-alone on 64->64 @128x128 B=32, slower in the step)
+}
+
 static bool halo16_wanted(const ConvParams& p, int bn) {
     if ((p.dbg & 4096) || p.gn_in_a || !cp_halo16_supported(p)) return false;
     return bn == 32 || (p.dbg & 8192);
@@ -1020,6 +1027,7 @@ int cp_launch_conv16(const ConvParams& p, hipStream_t stream) {
             return CP_ERR_INVALID;
         // dcn16.hip: the software-pipelined gather kernel; cp_set_debug(1024) keeps the previous un-pipelined loop
         // (igemm16_kernel<DCN>) for A/B runs, 2048 selects the other wave count of the new kernel
+        if (dcn16p_wanted(p)) return cp_launch_dcn16p(p, stream);
         if (!(p.dbg & 1024)) return cp_launch_dcn16(p, bn, (p.dbg & 2048) ? 1 : 0, stream);
         return bn == 128 ? launch16<2, 2, 2, 2, true, false>(p, stream) : launch16<2, 1, 2, 2, true, false>(p, stream);
     }
@@ -1037,7 +1045,7 @@ int cp_launch_conv16(const ConvParams& p, hipStream_t stream) {
 // kernel-variant ids continue after the exact-f32 ones (cp_conv_variant): 14.. = split-f16 instantiations
 int cp_conv16_variant(const ConvParams& p) {
     const int bn = conv16_tile_n(p);
-    if (p.offmask) return bn == 128 ? 18 : 17;
+    if (p.offmask) return dcn16p_wanted(p) ? CP_VARIANT_DCN16P : bn == 128 ? 18 : 17;
     const int t = bn == 32 ? 0 : bn == 64 ? 1 : 2;
     if (halo16_wanted(p, bn)) return 27 + t;
     return (p.nsrc > 1 ? 19 : 14) + t;

@@ -165,6 +165,44 @@ def test_dcn_both_precisions_vs_oracle(device, precision):
     assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("B,C,Co,H,W,std", [
+    (2, 32, 64, 8, 16, 0.0),       # one patch per image, zero offsets: every sample inside the halo, image border = zero fill
+    (2, 64, 64, 16, 16, 1.5),      # the bench's offset scale: a few exception samples per block
+    (1, 128, 256, 32, 32, 3.0),    # four chunks, four N tiles; blocks over the exception capacity take the buffer-load mode
+    (1, 64, 128, 16, 32, 8.0),     # offsets far beyond the halo and the image: every block in the buffer-load mode
+    (1, 64, 64, 128, 128, 1.5),    # the heaviest layer shape of the network (dla_up 64 -> 64 at 128 x 128)
+])
+def test_dcn_patch_resident_vs_oracle_and_gather_kernel(device, B, C, Co, H, W, std):
+    """dcn16p.hip (samples gathered from an LDS-staged halo, exception samples from spare patch rows, overflowing blocks
+    through buffer loads) against the float64 oracle and against dcn16.hip (cp_set_debug 32768): same products, different
+    summation order.  cp_set_debug 65536 selects it for launches of any size."""
+    hip.set_default_precision("f16x3")
+    try:
+        g = torch.Generator().manual_seed(C + H + int(std * 10))
+        x = torch.randn(B, C, H, W, generator=g)
+        w = torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5
+        b = torch.randn(Co, generator=g)
+        off = torch.randn(B, 18, H, W, generator=g) * std
+        mask = torch.rand(B, 9, H, W, generator=g)
+        ref = odcn.dcn_v2_forward_f64(x, w, b, off, mask)
+        args = [t.to(device) for t in (x, w, b, off, mask)] + [3, 3, 1, 1, 1, 1, 1, 1, 1]
+        hip.lib().cp_set_debug(65536)
+        try:
+            out = hip.dcn_v2_forward(*args).cpu()
+        finally:
+            hip.lib().cp_set_debug(0)
+        hip.lib().cp_set_debug(32768)
+        try:
+            old = hip.dcn_v2_forward(*args).cpu()
+        finally:
+            hip.lib().cp_set_debug(0)
+    finally:
+        hip.set_default_precision("f32")
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert float((out - old).abs().max() / ref.abs().max()) < 2e-6
+    assert C == 32 or not torch.equal(out, old)   # two different kernels really ran (one 32-channel chunk: same order)
+
+
 @pytest.fixture
 def f16x3():
     hip.set_default_precision("f16x3")
