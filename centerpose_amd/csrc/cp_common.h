@@ -101,6 +101,10 @@ struct ConvParams {
     int coff;        // channel offset inside out
     const void* w16_hi;    // split-f16 path: packed weights [CoutPad][Kpad16] binary16 (hi / lo), or nullptr
     const void* w16_lo;
+    // the same two arrays in MFMA B-operand order (cp_launch_frag16_repack), optional: dcn16p.hip loads its weight
+    // fragments straight from them
+    const void* w16f_hi;
+    const void* w16f_lo;
     int Kpad16;
     // GroupNorm fusion (dlav1 heads, GN.py:4-9): the producing conv accumulates per-(image, group) sum / sum of
     // squares of its biased output into gn_stats[B][groups][2] (doubles, zeroed by the caller); the consuming 1x1
@@ -171,6 +175,7 @@ int cp_launch_dcn16(const ConvParams& p, int bn, int variant, hipStream_t stream
 bool cp_dcn16p_supported(const ConvParams& p);
 int cp_dcn16p_blocks(const ConvParams& p);
 int cp_launch_dcn16p(const ConvParams& p, hipStream_t stream);
+int cp_launch_frag16_repack(const void* w16, void* w16f, int CoutPad, int Kpad16, hipStream_t s);
 #define CP_VARIANT_DCN16P 30
 // `fwd` (may be nullptr = 1): per-output-channel power-of-two factor applied before the split, indexed [coff + co]
 int cp_launch_pack_weight16(const float* w, void* hi, void* lo, int Cout, int Cin, int taps, int Kpad16, int coff,

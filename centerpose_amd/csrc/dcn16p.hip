@@ -11,23 +11,31 @@
 // corners are then ds_read_b128s -- 256 B/clk per CU, four times the texture path -- and all 9 taps x 2 K steps of
 // the chunk are served from the same image.
 //   * Pixel rows are 144 bytes apart (128 + 16): consecutive pixels start 9 sixteen-byte bank groups apart, 9 is odd,
-//     so the 16 lanes of a ds_read_b128 group (neighbouring pixels, same channel quad) hit 16 distinct groups; no XOR
-//     swizzle, hence ONE address register per (lane, tap) and every corner / K step / quad is an immediate offset.
+//     so lanes reading neighbouring pixels at the same channel quad spread over the banks; no XOR swizzle, hence ONE
+//     address register per (lane, tap) and every corner / K step / quad is an immediate offset.
 //   * A lane gathers exactly its MFMA A-fragment (pixel = lane % 32, 8 consecutive channels = 2 quads per corner),
 //     blends in float32 (packed FMAs), splits to binary16 hi / lo in registers: the A tile never exists in LDS.
-//     Each wave owns 32 pixels x the whole N tile, so nothing is gathered twice inside a block.
+//     Each wave owns 32 pixels x the whole 64-wide N tile, so nothing is gathered twice inside a block.
+//   * The weight fragments come straight from global memory / L2 in MFMA operand order (ConvParams::w16f_*: one
+//     coalesced 1 KB load per fragment, cp_launch_frag16_repack), three K steps ahead.  With neither operand staged
+//     through a shared tile the K loop has NO barrier inside a chunk: the four waves of a block drift apart and one
+//     wave's gather / blend overlaps another's MFMAs.  (The first version kept the weights in a double-buffered LDS
+//     tile with a barrier per tap: 19 % MFMA busy, waves 45 % parked at s_waitcnt / s_barrier.)
+//   * The gather of K step u + 1 is issued before the blend / MFMAs of step u (two register sets).
 //   * The bilinear set-up (corner address, 4 weights with mask and activation pre-scale folded in) of a lane's 9 taps
-//     lives in 45 registers for the whole kernel (2 waves per SIMD => 256 VGPRs each).
-//   * Samples whose 2x2 corner block leaves the staged halo (|offset| > 2..3 px at the patch border: ~2 % of samples
-//     at sigma = 1.5 px) are "exceptions": the set-up appends them to a block list (LDS atomic) and the staging copies
-//     their 2x2 source pixels into spare patch rows, laid out so that the same four immediates address them -- the K
-//     loop has no branch.  A block with more than ECAP exceptions (huge offsets everywhere) switches, as a whole, to
-//     gathering through buffer loads like dcn16.hip (slower, same results).
+//     lives in 45 registers for the whole kernel.  The two lanes that share a pixel (the two 8-channel halves of a
+//     K step) compute 5 and 4 taps each and swap the results with v_permlane32_swap.
+//   * Samples whose 2x2 corner block leaves the staged halo (|offset| > 2..3 px at the patch border: 2 % of samples
+//     at sigma = 1.5 px, 7 % at 1.9 -- the synthetic network's layers measure 1.4 .. 1.93) are "exceptions": the
+//     set-up appends them (corner, 4 weights) to a block list (LDS atomic) and takes weights (1, 0, 0, 0) itself; the
+//     staging blends each one's four corners per chunk into a spare patch pixel, which the K loop then reads like any
+//     other corner -- no branch.  A block with more than ECAP = 184 exceptions (offsets of sigma > 3 px everywhere)
+//     switches, as a whole, to gathering through buffer loads like dcn16.hip (slower, same results).
 // K order is (32-channel chunk, tap, 16-channel half): same products as dcn16.hip, different summation order.
-// LDS: 440 x 144 B patch + 16 KB weight tiles (double-buffered) = 79.9 KB => two blocks per CU, whose staging /
-// compute phases overlap.
-#include "patch16_common.h"
+// LDS: (308 + 207) x 144 B + 4.4 KB of lists = 78.6 KB => two blocks per CU, whose staging / compute phases overlap.
 #include <type_traits>
+
+#include "patch16_common.h"
 
 namespace {
 
@@ -35,30 +43,49 @@ constexpr int TH = PATCH_TH, TW = PATCH_TW, HALO = 3;
 constexpr int PW = TW + 2 * HALO, PH = TH + 2 * HALO, NPIX = PH * PW;  // 22 x 14 = 308 patch pixels
 constexpr int CKC = 32;                                                // channels per staged chunk
 constexpr int PSTR = CKC * 4 + 16;                                     // bytes between patch pixels
-constexpr int EROWS = 6;                                               // spare patch rows: 2x2 blocks of exception samples
-constexpr int EPR = PW / 2;                                            // exceptions per pair of spare rows
-constexpr int ECAP = (EROWS / 2) * EPR;                                // 33
-constexpr int NPIX_ALL = NPIX + EROWS * PW;                            // 440
-constexpr int ST_REG = (NPIX * 8 + 255) / 256;                         // staging passes over the halo: 10
-constexpr int ST_EXC = (ECAP * 32 + 255) / 256;                        // ... over the exception blocks: 5
+constexpr int ECAP = 184;                                              // exception samples per block (one spare pixel each)
+constexpr int NPIX_ALL = NPIX + ECAP + PW + 1;                         // + the 3 other "corners" of the last one: 515
+constexpr int NSTEP = 18;                                              // K steps (16 channels of one tap) per chunk
 
 __device__ __forceinline__ float4 buf_ld4s(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// both 32-lane halves of `v` for every lane: {lower half's value, upper half's value}
+__device__ __forceinline__ void both_halves(uint32_t v, uint32_t* lo, uint32_t* hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    *lo = r[0];
+    *hi = r[1];
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Packed float32 multiply / FMA whose first operand is ONE dword of a register pair broadcast to both halves
+// (op_sel / op_sel_hi pick dword S for the low and the high product).  Written out because the compiler materialises
+// {w, w} pairs instead: 72 registers for the 36 bilinear weights of a lane, where 36 do.
+template <int S>
+__device__ __forceinline__ f32x2 pk_mul_b(f32x2 w, f32x2 v) {
+    f32x2 d;
+    if (S == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(w), "v"(v));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(w), "v"(v));
+    return d;
+}
+template <int S>
+__device__ __forceinline__ f32x2 pk_fma_b(f32x2 w, f32x2 v, f32x2 c) {
+    f32x2 d;
+    if (S == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(w), "v"(v), "v"(c));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(w), "v"(v), "v"(c));
+    return d;
+}
+
 template <int NT>
 __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
-    constexpr int BN = 32 * NT;
-    constexpr int B_CHUNKS = BN * BK16 * 2 / 16;  // 16-byte chunks per weight array (hi or lo) per 32-deep K tile
-    constexpr int B_SLOTS = (B_CHUNKS + 255) / 256;
-    constexpr int B_SZ = BN * LDH;
-    static_assert(B_CHUNKS % 256 == 0, "whole passes over the weight tile");
     __shared__ __attribute__((aligned(16))) unsigned char patch[NPIX_ALL * PSTR];
-    __shared__ __attribute__((aligned(16))) _Float16 bt[2][2 * B_SZ];  // [buffer][hi | lo]
-    __shared__ int exc_list[ECAP];
+    __shared__ int exc_key[ECAP];   // (h_lo + 1) << 16 | (w_lo + 1) of the sample's top-left corner
+    __shared__ int exc_goff[ECAP];  // that corner's byte offset into the input tensor (may be "before" it: see validity)
+    __shared__ __attribute__((aligned(16))) float exc_w[ECAP][4];  // its four corner weights
     __shared__ int exc_count;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -80,130 +107,107 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     const __amdgpu_buffer_rsrc_t r_x = make_rsrc(p.src[0], img_px * (unsigned)p.Cin * 4u);
     const __amdgpu_buffer_rsrc_t r_om = make_rsrc(p.offmask, img_px * 128u);
     const unsigned w_bytes = (unsigned)((size_t)p.CoutPad * p.Kpad16 * 2);
-    const __amdgpu_buffer_rsrc_t r_wh = make_rsrc(p.w16_hi, w_bytes), r_wl = make_rsrc(p.w16_lo, w_bytes);
+    const __amdgpu_buffer_rsrc_t r_wh = make_rsrc(p.w16f_hi, w_bytes), r_wl = make_rsrc(p.w16f_lo, w_bytes);
     const int cb = p.Cin * 4, rowb = p.W * cb;
 
     if (tid == 0) exc_count = 0;
-    // ---- this lane's pixel: tile row m = 32 wave + lane % 32 -> patch pixel (m / 16, m % 16) ----
-    const int m = wid * 32 + lcol;
-    const int y = ty0 + (m >> 4), x = tx0 + (m & 15);
-    float om[28];  // the pixel's offset / mask record (27 used)
+    // the spare pixels start as zeros: an exception sample reads its blended value with weights (1, 0, 0, 0), and the three
+    // zero-weight "corners" next to it must never be NaN / Inf bit patterns left behind by an earlier kernel
+    for (int i = tid; i < (NPIX_ALL - NPIX) * (PSTR / 16); i += 256)
+        *reinterpret_cast<float4*>(patch + NPIX * PSTR + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- this lane's pixel: fragment row lane % 32 of wave w -> patch rows 2 w, 2 w + 1 in the permuted order of
+    //      patch16_common.h: the 16 lanes of a ds_read_b128 group read 16 consecutive pixels of one row, whose 144-byte
+    //      pitch spreads them over all 16 bank groups (the plain order put 6 of 16 lanes on an occupied group: 54 % of
+    //      the LDS cycles were conflicts) ----
+    const int y = ty0 + 2 * wid + patch_perm_row(lcol), x = tx0 + patch_perm_col(lcol);
+    const unsigned rec = (unsigned)((b * p.H + y) * p.W + x) * 128u;  // the pixel's offset / mask record (32 floats)
+    // this lane's share of the record: taps 5 lrow .. 5 lrow + 4 (slot 4 of the upper half is a dummy, tap "9")
+    float od[12], omk[5];
     {
-        const unsigned rec = (unsigned)((b * p.H + y) * p.W + x) * 128u;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const float4 v = buf_ld4(r_om, rec + 16u * i);
-            om[4 * i] = v.x; om[4 * i + 1] = v.y; om[4 * i + 2] = v.z; om[4 * i + 3] = v.w;
+        for (int i = 0; i < 3; ++i) {
+            const float4 v = buf_ld4(r_om, rec + (unsigned)lrow * 40u + 16u * i);
+            od[4 * i] = v.x; od[4 * i + 1] = v.y; od[4 * i + 2] = v.z; od[4 * i + 3] = v.w;
         }
+        const float4 v = buf_ld4(r_om, rec + 72u + (unsigned)lrow * 20u);
+        omk[0] = v.x; omk[1] = v.y; omk[2] = v.z; omk[3] = v.w;
+        omk[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_om, (int)(rec + 88u + (unsigned)lrow * 20u), 0, 0));
     }
     __syncthreads();  // exc_count = 0 is visible
 
-    // ---- bilinear set-up of the lane's 9 taps (dcn_v2_im2col_cuda.cu:25-54, 150-187), kept in registers ----
-    // corner (h_lo, w_lo) of each tap: its byte address in `patch` + this lane's 32-byte channel half (fast mode) /
-    // its byte offset into the input tensor | 4 corner-validity bits (buffer-load mode); one of them survives the set-up
-    int a_lds[9], g_base[9];
-    float bw[9][4];  // corner weights x mask x activation pre-scale
+    // ---- bilinear set-up (dcn_v2_im2col_cuda.cu:25-54, 150-187): 5 tap slots per lane, then both halves swap ----
+    uint32_t sq[5], sw[5][4];  // patch pixel of corner (h_lo, w_lo); corner weights x mask x activation pre-scale
+    const float fy0 = (float)(y - 1), fx0 = (float)(x - 1);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int kh = t / 3, kw = t % 3;
-        const float dh = om[2 * t], dw = om[2 * t + 1], mk = om[18 + t] * afwd;
-        const float h_im = (float)(y - 1 + kh) + dh;
-        const float w_im = (float)(x - 1 + kw) + dw;
-        int q = 0, gb = 0;
-        float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
-        bool exc = false;
-        int key = 0;
-        if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
-            const int h_lo = (int)floorf(h_im), w_lo = (int)floorf(w_im);
-            const int h_hi = h_lo + 1, w_hi = w_lo + 1;
-            const float lh = h_im - (float)h_lo, lw = w_im - (float)w_lo;
-            const float hh = 1.f - lh, hw = 1.f - lw;
-            int vm = 0;
-            if (h_lo >= 0 && w_lo >= 0) vm |= 1;
-            if (h_lo >= 0 && w_hi <= p.W - 1) vm |= 2;
-            if (h_hi <= p.H - 1 && w_lo >= 0) vm |= 4;
-            if (h_hi <= p.H - 1 && w_hi <= p.W - 1) vm |= 8;
-            gb = (((b * p.H + h_lo) * p.W + w_lo) * cb) | vm;
-            w1 = hh * hw * mk; w2 = hh * lw * mk; w3 = lh * hw * mk; w4 = lh * lw * mk;
-            const int qy = h_lo - (ty0 - HALO), qx = w_lo - (tx0 - HALO);
-            if ((unsigned)qy <= (unsigned)(PH - 2) && (unsigned)qx <= (unsigned)(PW - 2)) q = qy * PW + qx;
-            else {
-                exc = true;
-                key = ((h_lo + 1) << 16) | (w_lo + 1);
-            }
-        }
-        if (exc && lrow == 0) {  // one of the two lanes that share the pixel files the exception
+    for (int j = 0; j < 5; ++j) {
+        // tap 5 lrow + j = (kh, kw): lower half (0,0) (0,1) (0,2) (1,0) (1,1); upper half (1,2) (2,0) (2,1) (2,2) (-)
+        const float khf = lrow ? (float)((5 + j) / 3) : (float)(j / 3);
+        const float kwf = lrow ? (float)((5 + j) % 3) : (float)(j % 3);
+        float h_im = (fy0 + khf) + od[2 * j];
+        float w_im = (fx0 + kwf) + od[2 * j + 1];
+        const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W && !(lrow && j == 4);
+        h_im = valid ? h_im : 0.f;  // keeps the arithmetic below finite; its weights are zeroed through the mask
+        w_im = valid ? w_im : 0.f;
+        const float mk = valid ? omk[j] * afwd : 0.f;
+        const float fh = floorf(h_im), fw = floorf(w_im);
+        const int h_lo = (int)fh, w_lo = (int)fw;
+        const float lh = h_im - fh, lw = w_im - fw;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        sw[j][0] = __float_as_uint(hh * hw * mk);
+        sw[j][1] = __float_as_uint(hh * lw * mk);
+        sw[j][2] = __float_as_uint(lh * hw * mk);
+        sw[j][3] = __float_as_uint(lh * lw * mk);
+        const int qy = h_lo - (ty0 - HALO), qx = w_lo - (tx0 - HALO);
+        const bool inp = (unsigned)qy <= (unsigned)(PH - 2) && (unsigned)qx <= (unsigned)(PW - 2);
+        int q = inp ? qy * PW + qx : 0;
+        if (valid && !inp) {  // exception sample: file its corner and weights; the staging blends it into spare pixel e,
+                              // which this lane then reads with weights (1, 0, 0, 0)
             const int e = atomicAdd(&exc_count, 1);
             if (e < ECAP) {
-                exc_list[e] = key;
-                q = NPIX + (e / EPR) * (2 * PW) + (e % EPR) * 2;
+                exc_key[e] = ((h_lo + 1) << 16) | (w_lo + 1);
+                exc_goff[e] = ((b * p.H + h_lo) * p.W + w_lo) * cb;
+                *reinterpret_cast<float4*>(exc_w[e]) = make_float4(__uint_as_float(sw[j][0]), __uint_as_float(sw[j][1]),
+                                                                   __uint_as_float(sw[j][2]), __uint_as_float(sw[j][3]));
+                sw[j][0] = __float_as_uint(1.f);
+                sw[j][1] = sw[j][2] = sw[j][3] = 0u;
+                q = NPIX + e;
             }
         }
-        q = __shfl(q, lcol, 64);
-        a_lds[t] = q * PSTR + lrow * 32;
-        g_base[t] = gb;
-        bw[t][0] = w1; bw[t][1] = w2; bw[t][2] = w3; bw[t][3] = w4;
+        sq[j] = (uint32_t)q;
+    }
+    int addr[9];     // byte address in `patch` of corner (h_lo, w_lo) + this lane's 32-byte channel half; in the
+                     // buffer-load mode: that corner's byte offset into the input tensor | 4 corner-validity bits
+    f32x2 bw[9][2];  // {w1, w2}, {w3, w4}: corner weights x mask x activation pre-scale
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        uint32_t lo, hi;
+        both_halves(sq[j], &lo, &hi);
+        addr[j] = (int)lo * PSTR + lrow * 32;
+        if (j < 4) addr[5 + j] = (int)hi * PSTR + lrow * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            both_halves(sw[j][c], &lo, &hi);
+            bw[j][c >> 1][c & 1] = __uint_as_float(lo);
+            if (j < 4) bw[5 + j][c >> 1][c & 1] = __uint_as_float(hi);
+        }
     }
     __syncthreads();
     const int nexc_all = __builtin_amdgcn_readfirstlane(exc_count);  // scalar: the mode branches below stay uniform
-    const bool slow = nexc_all > ECAP;  // block-uniform
+    const bool slow = nexc_all > ECAP;                               // block-uniform
     const int nexc = nexc_all < ECAP ? nexc_all : ECAP;
-    int addr[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) addr[t] = slow ? g_base[t] : a_lds[t];
 
-    // ---- staging geometry (chunk-invariant): thread -> (patch pixel, 16-byte channel quad) per pass ----
-    unsigned st_off[ST_REG], ex_off[ST_EXC];
-    int ex_lds[ST_EXC];
-    const int st_lds = (tid >> 3) * PSTR + (tid & 7) * 16;  // + 32 * PSTR per pass
+    // ---- weight fragments: (n tile j of 32, K step g of 16) = 1 KB in lane order at ((j G + g) 64 + lane) 16 B ----
+    const int G = p.Kpad16 / 16, gpt = p.Cin / 16;  // K steps per weight row / per tap
+    unsigned b_voff[NT];
 #pragma unroll
-    for (int s = 0; s < ST_REG; ++s) {
-        const int pix = (tid >> 3) + 32 * s;
-        const int ppy = pix / PW, ppx = pix - ppy * PW;
-        const int iy = ty0 - HALO + ppy, ix = tx0 - HALO + ppx;
-        const bool in = pix < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        st_off[s] = in ? (unsigned)(((b * p.H + iy) * p.W + ix) * cb + (tid & 7) * 16) : OOB;
-    }
+    for (int j = 0; j < NT; ++j) b_voff[j] = (unsigned)(((tn * NT + j) * G) * 1024 + lane * 16);
+    // step u of chunk ch = (tap u / 2, 16-channel half u % 2): K step g = tap * (Cin / 16) + 2 ch + (u % 2)
+    u32x4 wbh[3][NT], wbl[3][NT];  // register set u % 3 (18 steps per chunk keep the rotation consistent)
+    auto issue_b = [&](int set, int g) {
 #pragma unroll
-    for (int s = 0; s < ST_EXC; ++s) {
-        const int idx = tid + 256 * s;
-        const int e = idx >> 5, corner = (idx >> 3) & 3;
-        ex_off[s] = OOB;
-        ex_lds[s] = -1;
-        if (e < nexc && !slow) {
-            const int key = exc_list[e];
-            const int iy = (key >> 16) - 1 + (corner >> 1), ix = (key & 0xffff) - 1 + (corner & 1);
-            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                ex_off[s] = (unsigned)(((b * p.H + iy) * p.W + ix) * cb + (tid & 7) * 16);
-            ex_lds[s] = (NPIX + (e / EPR) * (2 * PW) + (e % EPR) * 2 + (corner >> 1) * PW + (corner & 1)) * PSTR + (tid & 7) * 16;
-        }
-    }
-
-    // ---- weight tile: chunk f -> row n = f / 4, 16-byte column f % 4 of the 32-deep K tile ----
-    unsigned b_off[B_SLOTS];
-#pragma unroll
-    for (int j = 0; j < B_SLOTS; ++j) {
-        const int f = tid + j * 256;
-        b_off[j] = (unsigned)(((size_t)(tn * BN + f / 4) * p.Kpad16 + (f % 4) * 8) * 2);
-    }
-    // Weight tiles are fetched TWO taps ahead (a tap is only 2 K steps = ~0.4 us of work, less than an L2 round trip
-    // under load): tile of tap T lives in register set T % 3 from its issue (tap T - 2) to its LDS store (end of tap
-    // T - 1); 9 taps per chunk keep the rotation consistent across chunks, and only two sets are ever live.
-    u32x4 gbh[3][B_SLOTS], gbl[3][B_SLOTS];
-    auto issue_b = [&](int set, int kbyte) {  // kbyte: byte offset of the K tile inside a weight row (wave-uniform)
-#pragma unroll
-        for (int j = 0; j < B_SLOTS; ++j) {
-            gbh[set][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wh, (int)b_off[j], kbyte, 0);
-            gbl[set][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)b_off[j], kbyte, 0);
-        }
-    };
-    auto store_b = [&](int set, int buf) {
-#pragma unroll
-        for (int j = 0; j < B_SLOTS; ++j) {
-            const int f = tid + j * 256;
-            const int nn = f / 4, c = f % 4;
-            *reinterpret_cast<u32x4*>(bt[buf] + nn * LDH + (c ^ swz(nn)) * 8) = gbh[set][j];
-            *reinterpret_cast<u32x4*>(bt[buf] + B_SZ + nn * LDH + (c ^ swz(nn)) * 8) = gbl[set][j];
+        for (int j = 0; j < NT; ++j) {
+            wbh[set][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wh, (int)b_voff[j], g * 1024, 0);
+            wbl[set][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)b_voff[j], g * 1024, 0);
         }
     };
 
@@ -212,124 +216,195 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < F::NACC; ++r) acc[0][j][r] = 0.f;
-    const int b_frag = lcol * LDH;
-
     const int nch = p.Cin / CKC;
-    const int nkt = nch * 9;
-    issue_b(0, 0);
-    if (!slow) issue_b(1, (1 * p.Cin) * 2);  // (nkt >= 9)
-    // the K loop, instantiated once per mode (SLOW is block-uniform): the fast instance has no control flow inside a
-    // chunk, so the scheduler can hoist fragment reads and the next step's gather above the MFMAs
-    auto k_loop = [&](auto mode) {
-    constexpr bool SLOW = decltype(mode)::value;
-    constexpr int PF = SLOW ? 1 : 2;  // weight tiles in flight ahead of the tap being multiplied
-    int kt = 0;
-    for (int ch = 0; ch < nch; ++ch) {
-        // ---- stage the halo (and the exception blocks) of this 32-channel chunk; every wave left the previous
-        //      chunk's patch at the barrier that ended its last tap ----
-        if (!SLOW) {
-            const int csoff = ch * (CKC * 4);
-            // two rounds (halo rows, then the tail + the exception blocks): half the registers in flight
-            constexpr int H1 = 8;
-            {
-                float4 sv[H1];
+
+    // blend + split of one gathered K step, then its 3 NT MFMAs
+    auto mma_step = [&](const float4 (&r)[4][2], const f32x2 (&w)[2], const u32x4 (&bh)[NT], const u32x4 (&bl)[NT]) {
+        // fma(w4, v4, fma(w3, v3, fma(w2, v2, w1 * v1))) per channel (dcn16.hip's order), two per v_pk_fma_f32
+        uint32_t hi[4], lo[4];
 #pragma unroll
-                for (int s = 0; s < H1; ++s) sv[s] = buf_ld4s(r_x, st_off[s], csoff);
+        for (int hq = 0; hq < 2; ++hq) {
+            const float4 v1 = r[0][hq], v2 = r[1][hq], v3 = r[2][hq], v4 = r[3][hq];
+            f32x2 lo2 = pk_mul_b<0>(w[0], f32x2{v1.x, v1.y}), hi2 = pk_mul_b<0>(w[0], f32x2{v1.z, v1.w});
+            lo2 = pk_fma_b<1>(w[0], f32x2{v2.x, v2.y}, lo2);
+            hi2 = pk_fma_b<1>(w[0], f32x2{v2.z, v2.w}, hi2);
+            lo2 = pk_fma_b<0>(w[1], f32x2{v3.x, v3.y}, lo2);
+            hi2 = pk_fma_b<0>(w[1], f32x2{v3.z, v3.w}, hi2);
+            lo2 = pk_fma_b<1>(w[1], f32x2{v4.x, v4.y}, lo2);
+            hi2 = pk_fma_b<1>(w[1], f32x2{v4.z, v4.w}, hi2);
+            const Split2 s0 = split2(lo2.x, lo2.y), s1 = split2(hi2.x, hi2.y);
+            hi[2 * hq] = s0.hi; hi[2 * hq + 1] = s1.hi;
+            lo[2 * hq] = s0.lo; lo[2 * hq + 1] = s1.lo;
+        }
+        const u32x4 ahv = {hi[0], hi[1], hi[2], hi[3]}, alv = {lo[0], lo[1], lo[2], lo[3]};
+        const h8 ah = *reinterpret_cast<const h8*>(&ahv), al = *reinterpret_cast<const h8*>(&alv);
+        // same term order as igemm16.hip (lo*hi, hi*lo, hi*hi)
 #pragma unroll
-                for (int s = 0; s < H1; ++s) *reinterpret_cast<float4*>(patch + st_lds + s * (32 * PSTR)) = sv[s];
+        for (int j = 0; j < NT; ++j)
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, *reinterpret_cast<const h8*>(&bh[j]), acc[0][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, *reinterpret_cast<const h8*>(&bl[j]), acc[0][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, *reinterpret_cast<const h8*>(&bh[j]), acc[0][j], 0, 0, 0);
+    };
+
+    if (!slow) {
+        // ================= fast mode: every sample is in LDS =================
+        // staging geometry: thread -> (patch column tid / 8 (< PW: 22 of 32 busy), channel quad tid % 8), pass s = patch
+        // row s; one base offset register, the row validity is wave-uniform
+        const int spx = tid >> 3, six = tx0 - HALO + spx;
+        const bool col_ok = spx < PW && (unsigned)six < (unsigned)p.W;
+        const int st_base = ((b * p.H + ty0) * p.W + six) * cb + (tid & 7) * 16;  // row ty0 (always inside the image)
+        const int st_lds = spx * PSTR + (tid & 7) * 16;                            // + PW * PSTR per row
+        auto gather = [&](float4 (&r)[4][2], int a) {  // a: addr[tap] + 64 (K step % 2)
+            const unsigned char* ap = patch + a;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int co = ((c >> 1) * PW + (c & 1)) * PSTR;
+                r[c][0] = *reinterpret_cast<const float4*>(ap + co);
+                r[c][1] = *reinterpret_cast<const float4*>(ap + co + 16);
             }
+        };
+        // weights of steps 0, 1, 2 in flight before the first chunk is staged
+        issue_b(0, 0 * gpt + 0);
+        issue_b(1, 0 * gpt + 1);
+        issue_b(2, 1 * gpt + 0);
+        for (int ch = 0; ch < nch; ++ch) {
+            if (ch > 0) __syncthreads();  // every wave is done with the previous chunk's patch
             {
-                float4 sv[ST_REG - H1], ev[ST_EXC];
+                const int csoff = ch * (CKC * 4);
+                int sb = st_base;
+                asm volatile("" : "+v"(sb));  // per chunk: keeps the 14 row offsets from being hoisted into 14 registers
+                auto row_off = [&](int s) -> unsigned {  // patch row s of this thread's column, or out of range (-> 0)
+                    const bool row_ok = (unsigned)(ty0 - HALO + s) < (unsigned)p.H;
+                    return (row_ok && col_ok) ? (unsigned)(sb + (s - HALO) * rowb) : OOB;
+                };
+                constexpr int H1 = PH / 2;  // two rounds of 7 rows: half the registers in flight
+                {
+                    float4 sv[H1];
 #pragma unroll
-                for (int s = H1; s < ST_REG; ++s) sv[s - H1] = buf_ld4s(r_x, st_off[s], csoff);
+                    for (int s = 0; s < H1; ++s) sv[s] = buf_ld4s(r_x, row_off(s), csoff);
 #pragma unroll
-                for (int s = 0; s < ST_EXC; ++s) ev[s] = buf_ld4s(r_x, ex_off[s], csoff);
+                    for (int s = 0; s < H1; ++s)
+                        if (spx < PW) *reinterpret_cast<float4*>(patch + st_lds + s * (PW * PSTR)) = sv[s];
+                }
+                {
+                    float4 sv[PH - H1];
 #pragma unroll
-                for (int s = H1; s < ST_REG; ++s)
-                    if (s < ST_REG - 1 || (tid >> 3) + 32 * s < NPIX)
-                        *reinterpret_cast<float4*>(patch + st_lds + s * (32 * PSTR)) = sv[s - H1];
+                    for (int s = H1; s < PH; ++s) sv[s - H1] = buf_ld4s(r_x, row_off(s), csoff);
+                    // exception samples: 8 threads each (one channel quad per thread), 32 samples per pass: the four corners
+                    // are blended here (same FMA order as the K loop) into the sample's spare pixel; addresses are rebuilt
+                    // per chunk from the block's list (LDS) -- no registers held across the K loop
+                    for (int e = tid >> 3; e < nexc; e += 32) {
+                        const int key = exc_key[e], go = exc_goff[e] + (tid & 7) * 16;
+                        const float4 w = *reinterpret_cast<const float4*>(exc_w[e]);
+                        const int iy = (key >> 16) - 1, ix = (key & 0xffff) - 1;
+                        const bool y0 = (unsigned)iy < (unsigned)p.H, y1 = (unsigned)(iy + 1) < (unsigned)p.H;
+                        const bool x0 = (unsigned)ix < (unsigned)p.W, x1 = (unsigned)(ix + 1) < (unsigned)p.W;
+                        const float4 v1 = buf_ld4s(r_x, (y0 && x0) ? (unsigned)go : OOB, csoff);
+                        const float4 v2 = buf_ld4s(r_x, (y0 && x1) ? (unsigned)(go + cb) : OOB, csoff);
+                        const float4 v3 = buf_ld4s(r_x, (y1 && x0) ? (unsigned)(go + rowb) : OOB, csoff);
+                        const float4 v4 = buf_ld4s(r_x, (y1 && x1) ? (unsigned)(go + rowb + cb) : OOB, csoff);
+                        float4 o;
+                        o.x = fmaf(w.w, v4.x, fmaf(w.z, v3.x, fmaf(w.y, v2.x, w.x * v1.x)));
+                        o.y = fmaf(w.w, v4.y, fmaf(w.z, v3.y, fmaf(w.y, v2.y, w.x * v1.y)));
+                        o.z = fmaf(w.w, v4.z, fmaf(w.z, v3.z, fmaf(w.y, v2.z, w.x * v1.z)));
+                        o.w = fmaf(w.w, v4.w, fmaf(w.z, v3.w, fmaf(w.y, v2.w, w.x * v1.w)));
+                        *reinterpret_cast<float4*>(patch + (NPIX + e) * PSTR + (tid & 7) * 16) = o;
+                    }
 #pragma unroll
-                for (int s = 0; s < ST_EXC; ++s)
-                    if (ex_lds[s] >= 0) *reinterpret_cast<float4*>(patch + ex_lds[s]) = ev[s];
+                    for (int s = H1; s < PH; ++s)
+                        if (spx < PW) *reinterpret_cast<float4*>(patch + st_lds + s * (PW * PSTR)) = sv[s - H1];
+                }
+            }
+            __syncthreads();
+            float4 raw[2][4][2];
+            gather(raw[0], addr[0]);
+#pragma unroll
+            for (int u = 0; u < NSTEP; ++u) {
+                // the order of the three phases is pinned (sched_barrier): left alone, the scheduler sinks every load to
+                // just above its first use -- no prefetch, a full LDS / L2 round trip exposed per step
+                if (u + 1 < NSTEP) gather(raw[(u + 1) & 1], addr[(u + 1) >> 1] + ((u + 1) & 1) * 64);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_step(raw[u & 1], bw[u >> 1], wbh[u % 3], wbl[u % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                // refill the set just consumed with step u + 3 (of this chunk or the next)
+                const int u3 = u + 3 < NSTEP ? u + 3 : u + 3 - NSTEP, ch3 = u + 3 < NSTEP ? ch : ch + 1;
+                if (ch3 < nch) issue_b(u % 3, (u3 >> 1) * gpt + 2 * ch3 + (u3 & 1));
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (ch == 0) store_b(0, 0);
-        __syncthreads();
+    } else {
+        // ================= buffer-load mode: every block sample through the texture path =================
+        // corner offsets | validity bits and the weights of the lane's 9 taps, from the record again: the fast set-up
+        // does not keep the offsets, and it replaced the weights of the samples it filed as exceptions
+        {
+            float o9[28];
 #pragma unroll
-        for (int t = 0; t < 9; ++t, ++kt) {
-            const int cur = kt & 1;
-            if (kt + PF < nkt) {
-                const int t2 = t + PF < 9 ? t + PF : t + PF - 9, ch2 = t + PF < 9 ? ch : ch + 1;
-                issue_b((t + PF) % 3, (t2 * p.Cin + ch2 * CKC) * 2);
+            for (int i = 0; i < 7; ++i) {
+                const float4 v = buf_ld4(r_om, rec + 16u * i);
+                o9[4 * i] = v.x; o9[4 * i + 1] = v.y; o9[4 * i + 2] = v.z; o9[4 * i + 3] = v.w;
             }
-            const _Float16* Bh = bt[cur] + b_frag;
-            const _Float16* Bl = Bh + B_SZ;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int t = 0; t < 9; ++t) {
+                const float h_im = (float)(y - 1 + t / 3) + o9[2 * t];
+                const float w_im = (float)(x - 1 + t % 3) + o9[2 * t + 1];
+                int gb = 0;
+                float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+                if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
+                    const int h_lo = (int)floorf(h_im), w_lo = (int)floorf(w_im);
+                    const float lh = h_im - (float)h_lo, lw = w_im - (float)w_lo;
+                    const float hh = 1.f - lh, hw = 1.f - lw, mk = o9[18 + t] * afwd;
+                    int vm = 0;
+                    if (h_lo >= 0 && w_lo >= 0) vm |= 1;
+                    if (h_lo >= 0 && w_lo + 1 <= p.W - 1) vm |= 2;
+                    if (h_lo + 1 <= p.H - 1 && w_lo >= 0) vm |= 4;
+                    if (h_lo + 1 <= p.H - 1 && w_lo + 1 <= p.W - 1) vm |= 8;
+                    gb = (((b * p.H + h_lo) * p.W + w_lo) * cb) | vm;
+                    w1 = hh * hw * mk; w2 = hh * lw * mk; w3 = lh * hw * mk; w4 = lh * lw * mk;
+                }
+                addr[t] = gb;
+                bw[t][0] = f32x2{w1, w2};
+                bw[t][1] = f32x2{w3, w4};
+            }
+        }
+        issue_b(0, 0);
+        for (int ch = 0; ch < nch; ++ch) {
+#pragma unroll
+            for (int u = 0; u < NSTEP; ++u) {
+                const int t = u >> 1, ks = u & 1;
+                const int u1 = u + 1 < NSTEP ? u + 1 : 0, ch1 = u + 1 < NSTEP ? ch : ch + 1;
+                if (ch1 < nch) issue_b((u + 1) & 1, (u1 >> 1) * gpt + 2 * ch1 + (u1 & 1));
                 float4 r[4][2];
-                if (!SLOW) {
-                    const unsigned char* ap = patch + addr[t] + ks * 64;
+                const int so = (ch * CKC + ks * 16) * 4;
+                const int base = (addr[t] & ~15) + lrow * 32;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int co = ((c >> 1) * PW + (c & 1)) * PSTR;
-                        r[c][0] = *reinterpret_cast<const float4*>(ap + co);
-                        r[c][1] = *reinterpret_cast<const float4*>(ap + co + 16);
-                    }
-                } else {
-                    // buffer-load mode: corner offsets into the tensor, invalid corners out of range (-> 0)
-                    const int so = (ch * CKC + ks * 16) * 4;
-                    const int base = (addr[t] & ~15) + lrow * 32;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int gi = (addr[t] & (1 << c)) ? base + (c >> 1) * rowb + (c & 1) * cb : (int)OOB_BASE;
-                        r[c][0] = buf_ld4s(r_x, (unsigned)gi, so);
-                        r[c][1] = buf_ld4s(r_x, (unsigned)gi + 16u, so);
-                    }
+                for (int c = 0; c < 4; ++c) {  // invalid corners out of range (-> 0)
+                    const int gi = (addr[t] & (1 << c)) ? base + (c >> 1) * rowb + (c & 1) * cb : (int)OOB_BASE;
+                    r[c][0] = buf_ld4s(r_x, (unsigned)gi, so);
+                    r[c][1] = buf_ld4s(r_x, (unsigned)gi + 16u, so);
                 }
-                h8 bh[NT], bl[NT];
-                const int co = ((ks * 2 + lrow) ^ swz(lcol)) * 8;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    bh[j] = *reinterpret_cast<const h8*>(Bh + j * 32 * LDH + co);
-                    bl[j] = *reinterpret_cast<const h8*>(Bl + j * 32 * LDH + co);
-                }
-                // fma(w4, v4, fma(w3, v3, fma(w2, v2, w1 * v1))) per channel (dcn16.hip's order), two per v_pk_fma_f32
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                const f32x2 w1 = {bw[t][0], bw[t][0]}, w2 = {bw[t][1], bw[t][1]}, w3 = {bw[t][2], bw[t][2]},
-                            w4 = {bw[t][3], bw[t][3]};
-                uint32_t hi[4], lo[4];
-#pragma unroll
-                for (int hq = 0; hq < 2; ++hq) {
-                    const float4 v1 = r[0][hq], v2 = r[1][hq], v3 = r[2][hq], v4 = r[3][hq];
-                    f32x2 lo2 = w1 * f32x2{v1.x, v1.y}, hi2 = w1 * f32x2{v1.z, v1.w};
-                    lo2 = __builtin_elementwise_fma(w2, f32x2{v2.x, v2.y}, lo2);
-                    hi2 = __builtin_elementwise_fma(w2, f32x2{v2.z, v2.w}, hi2);
-                    lo2 = __builtin_elementwise_fma(w3, f32x2{v3.x, v3.y}, lo2);
-                    hi2 = __builtin_elementwise_fma(w3, f32x2{v3.z, v3.w}, hi2);
-                    lo2 = __builtin_elementwise_fma(w4, f32x2{v4.x, v4.y}, lo2);
-                    hi2 = __builtin_elementwise_fma(w4, f32x2{v4.z, v4.w}, hi2);
-                    const Split2 s0 = split2(lo2.x, lo2.y), s1 = split2(hi2.x, hi2.y);
-                    hi[2 * hq] = s0.hi; hi[2 * hq + 1] = s1.hi;
-                    lo[2 * hq] = s0.lo; lo[2 * hq + 1] = s1.lo;
-                }
-                const u32x4 ahv = {hi[0], hi[1], hi[2], hi[3]}, alv = {lo[0], lo[1], lo[2], lo[3]};
-                const h8 ah = *reinterpret_cast<const h8*>(&ahv), al = *reinterpret_cast<const h8*>(&alv);
-                // same term order as igemm16.hip (lo*hi, hi*lo, hi*hi)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[0][j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[0][j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[0][j], 0, 0, 0);
+                mma_step(r, bw[t], wbh[u & 1], wbl[u & 1]);
+                __builtin_amdgcn_sched_barrier(0);  // keep the loads of later steps below: the register file is full
             }
-            if (kt + 1 < nkt) store_b((t + 1) % 3, cur ^ 1);
-            __syncthreads();
         }
     }
-    };
-    if (slow) k_loop(std::true_type{});
-    else k_loop(std::false_type{});
-    patch_epilogue<1, NT, 4, 1>(p, acc, b, ty0, tx0, tn, wid, 0, lane, ainv);
+    patch_epilogue<1, NT, 4, 1, true>(p, acc, b, ty0, tx0, tn, wid, 0, lane, ainv);
+}
+
+// [CoutPad][Kpad16] binary16 -> MFMA B-operand order: fragment (n tile j of 32, K step g of 16) = 64 lanes x 16 bytes,
+// lane l = row 32 j + l % 32, k = 16 g + 8 (l / 32) .. + 7
+__global__ void frag16_repack_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int CoutPad, int Kpad16) {
+    const int G = Kpad16 / 16;
+    const size_t total = (size_t)(CoutPad / 32) * G * 64;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(i & 63);
+        const size_t jg = i >> 6;
+        const int g = (int)(jg % G), j = (int)(jg / G);
+        out[i] = in[((size_t)(32 * j + (l & 31)) * Kpad16 + 16 * g + 8 * (l >> 5)) / 8];
+    }
 }
 
 template <int NT>
@@ -342,14 +417,15 @@ int launch_dcn16p(const ConvParams& p, hipStream_t stream) {
 
 }  // namespace
 
-// Full 8 x 16 patches, NHWC output, no split-K, 32-bit offsets; the caller (cp_launch_conv16) also asks for enough
-// blocks to fill the chip before it prefers this kernel to dcn16.hip's.
+// Full 8 x 16 patches, NHWC output, no split-K, 32-bit offsets, fragment-ordered weights present; the caller
+// (cp_launch_conv16) also asks for enough blocks to fill the chip before it prefers this kernel to dcn16.hip's.
 bool cp_dcn16p_supported(const ConvParams& p) {
-    return p.offmask && p.w16_hi && p.w16_lo && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.nsrc == 1 &&
+    return p.offmask && p.w16f_hi && p.w16f_lo && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.nsrc == 1 &&
            p.H == p.Ho && p.W == p.Wo && p.splitk <= 1 && p.Cin % CKC == 0 && p.H % TH == 0 && p.W % TW == 0 &&
            p.H < 65535 && p.W < 65535 && p.store == CP_STORE_NHWC && p.Kpad16 == 9 * p.Cin && p.CoutPad % 64 == 0 &&
            !p.gn_stats && (size_t)p.B * p.H * p.W * p.Cin * 4 < (size_t)0xf0000000u &&
-           (size_t)p.B * p.H * p.W * 128 < (size_t)0xf0000000u && (size_t)p.B * p.H * p.W * p.ldo * 4 < (size_t)0xf0000000u;
+           (size_t)p.B * p.H * p.W * 128 < (size_t)0xf0000000u && (size_t)p.B * p.H * p.W * p.ldo * 4 < (size_t)0xf0000000u &&
+           (size_t)p.CoutPad * p.Kpad16 * 2 < (size_t)0x7fffffff;
 }
 
 int cp_dcn16p_blocks(const ConvParams& p) { return p.B * (p.H / TH) * (p.W / TW) * (p.CoutPad / 64); }
@@ -357,4 +433,13 @@ int cp_dcn16p_blocks(const ConvParams& p) { return p.B * (p.H / TH) * (p.W / TW)
 int cp_launch_dcn16p(const ConvParams& p, hipStream_t stream) {
     if (!cp_dcn16p_supported(p)) return CP_ERR_INVALID;
     return launch_dcn16p<2>(p, stream);
+}
+
+int cp_launch_frag16_repack(const void* w16, void* w16f, int CoutPad, int Kpad16, hipStream_t s) {
+    if (CoutPad % 32 != 0 || Kpad16 % 16 != 0) return CP_ERR_INVALID;
+    const size_t total = (size_t)CoutPad * Kpad16 / 8;
+    int g = (int)((total + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(frag16_repack_kernel, dim3(g), dim3(256), 0, s, (const uint4*)w16, (uint4*)w16f, CoutPad, Kpad16);
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }

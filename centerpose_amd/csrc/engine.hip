@@ -112,6 +112,8 @@ struct ConvW {
     void* w16_hi = nullptr;  // split-f16 copies [CoutPad][K] (only when every K-step of 32 stays inside one tap)
     void* w16_lo = nullptr;
     int Kpad16 = 0;
+    void* w16f_hi = nullptr;  // DCN main convolutions: the same in MFMA fragment order (dcn16p.hip)
+    void* w16f_lo = nullptr;
     // per-output-channel power-of-two pre-scale of the split-f16 copies: rows are stored times wfwd[co] = 2^e,
     // winv = 2^-e, scale16 = (scale or 1) * winv is what the f16x3 kernels' epilogue multiplies with
     float* wfwd = nullptr;
@@ -365,6 +367,17 @@ struct Packer {
         const auto* bias = get(p + ".conv.bias", cho);
         std::vector<float> sc, sh;
         if (bias && bn_fold(p + ".actf.0", cho, bias, sc, sh)) set_affine(d.main, &sc, sh);
+        if (d.main.w16_hi && d.main.w16_lo && status == CP_OK) {  // fragment-ordered copy for the patch-resident kernel
+            const size_t halfs = (size_t)d.main.CoutPad * d.main.Kpad16;
+            d.main.w16f_hi = dev_alloc((halfs + 1) / 2);
+            d.main.w16f_lo = dev_alloc((halfs + 1) / 2);
+            if (d.main.w16f_hi && d.main.w16f_lo) {
+                int rc = cp_launch_frag16_repack(d.main.w16_hi, d.main.w16f_hi, d.main.CoutPad, d.main.Kpad16, nullptr);
+                if (rc == CP_OK) rc = cp_launch_frag16_repack(d.main.w16_lo, d.main.w16f_lo, d.main.CoutPad, d.main.Kpad16, nullptr);
+                hip_ok(hipDeviceSynchronize());
+                if (rc != CP_OK) status = rc;
+            }
+        }
         m->deforms[p] = d;
     }
     void ida(const std::string& p, int o, const std::vector<int>& channels, const std::vector<int>& up_f) {
@@ -749,6 +762,8 @@ struct Fwd {
             p.gn_in_beta = gn_in_beta;
             p.gn_cpg = w.Cin / 32;
         }
+        p.w16f_hi = w.w16f_hi;
+        p.w16f_lo = w.w16f_lo;
         p.w16_hi = w.w16_hi;
         p.w16_lo = w.w16_lo;
         p.Kpad16 = w.Kpad16;
@@ -892,6 +907,7 @@ struct Fwd {
     Tensor deform(const std::string& p, const Tensor& x) {
         const DeformW& d = m->deforms.at(p);
         Tensor om = conv(d.offset, {&x}, 1, 1, CP_ACT_SIGMOID_FROM, nullptr, nullptr, 18);
+        tap(p + ".offmask", om, 27);
         Tensor o = conv(d.main, {&x}, 1, 1, CP_ACT_RELU, nullptr, &om);
         tap(p, o);
         return o;
@@ -1711,7 +1727,7 @@ size_t cp_dcnv2_workspace_bytes(int B, int C, int H, int W, int Co) {
     const size_t px = (size_t)B * H * W;
     const size_t cpad = align_up((size_t)Co, cp_conv_tile_n(Co));
     return align_up(px * C * 4, 256) + align_up(px * 32 * 4, 256) + align_up(px * Co * 4, 256) +
-           align_up((size_t)9 * C * cpad * 4, 256) + align_up(cpad * 4, 256) + 2 * align_up((size_t)9 * C * cpad * 2, 256) +
+           align_up((size_t)9 * C * cpad * 4, 256) + align_up(cpad * 4, 256) + 4 * align_up((size_t)9 * C * cpad * 2, 256) +
            3 * align_up(cpad * 4, 256) + (size_t)CP_AMAX_SUB * CP_AMAX_STRIDE * sizeof(unsigned);
 }
 
@@ -1807,6 +1823,11 @@ extern "C" int cp_dcnv2_forward(cp_stream_t stream, const float* input, const fl
         if (rc == CP_OK) rc = cp_launch_pack_weight16(weight, (void*)p.w16_hi, (void*)p.w16_lo, Co, C, 9, p.Kpad16, 0, wfwd, s);
         if (rc == CP_OK) rc = cp_launch_scale16(nullptr, winv, sc16, Co, s);
         if (rc == CP_OK) rc = cp_launch_absmax(x_nhwc, px * C, slot, s);
+        char* w16f = (char*)slot + (size_t)CP_AMAX_SUB * CP_AMAX_STRIDE * sizeof(unsigned);
+        if (rc == CP_OK) rc = cp_launch_frag16_repack(p.w16_hi, w16f, cpad, p.Kpad16, s);
+        if (rc == CP_OK) rc = cp_launch_frag16_repack(p.w16_lo, w16f + sz, cpad, p.Kpad16, s);
+        p.w16f_hi = w16f;
+        p.w16f_lo = w16f + sz;
         if (rc != CP_OK) return rc;
         if (cp_conv16_supported(p)) {
             p.scale = sc16;

@@ -983,7 +983,7 @@ static int conv16_tile_n(const ConvParams& p) {
 // (split-K).  cp_set_debug: 32768 = never, 65536 = every eligible layer (tests, A/B runs).
 static bool dcn16p_wanted(const ConvParams& p) {
     if ((p.dbg & 32768) || (p.dbg & 1024) || !cp_dcn16p_supported(p)) return false;
-    return (p.dbg & 65536) != 0;  // (not yet the default: measured 270 vs 322 us stand-alone on 64->64 @128x128 B=32, slower in the step)
+    return (p.dbg & 65536) || cp_dcn16p_blocks(p) >= 256;
 }
 
 static bool halo16_wanted(const ConvParams& p, int bn) {

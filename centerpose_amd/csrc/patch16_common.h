@@ -9,7 +9,13 @@ constexpr int PATCH_TH = 8, PATCH_TW = 16;
 
 // y = acc * scale[n] * 2^-e_a + shift[n] (+ residual) -> activation -> NHWC store (full patches only); GroupNorm
 // statistics and |max| tracking as igemm_epilogue.  (b, ty0, tx0): image and top-left output pixel of the patch.
-template <int MT, int NT, int WM, int WN>
+// PERM: fragment row m of a wave is not pixel (m / 16, m % 16) of its two patch rows but patch_perm_row / patch_perm_col
+// below (dcn16p.hip: every 16-lane group of a ds_read_b128 then covers 16 consecutive pixels of ONE row).
+// Lanes 4 qd .. 4 qd + 3 (qd = m / 4): row [0,1,1,0,1,0,0,1][qd], columns 4 (qd / 2) .. + 3.
+__device__ __forceinline__ int patch_perm_row(int m) { return (0x96 >> (m >> 2)) & 1; }
+__device__ __forceinline__ int patch_perm_col(int m) { return 4 * (m >> 3) + (m & 3); }
+
+template <int MT, int NT, int WM, int WN, bool PERM = false>
 __device__ __forceinline__ void patch_epilogue(const ConvParams& p, Frag<32>::acc_t (&acc)[MT][NT], int b, int ty0, int tx0,
                                                int tn, int wm, int wn, int lane, float ainv) {
     typedef Frag<32> F;
@@ -37,11 +43,16 @@ __device__ __forceinline__ void patch_epilogue(const ConvParams& p, Frag<32>::ac
             for (int r = 0; r < F::NACC; ++r) v[r] = acc[i][j][r] * sc + sh;
             if (has_res) {
                 const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res + (size_t)pix0 * p.res_ld, (unsigned)((p.W + TW) * p.res_ld) * 4u);
-                const unsigned vr = n_ok ? (unsigned)(4 * h4 * p.res_ld + n) * 4u : 0x80000000u;
+                // accumulator r of lane-half h4 = fragment row (r & 3) + 8 (r >> 2) + 4 h4; PERM: patch row h4 ^ [0,1,1,0][r >> 2],
+                // column 4 (r >> 2) + (r & 3)
+                const unsigned vr = n_ok ? (unsigned)((PERM ? h4 * p.W : 4 * h4) * p.res_ld + n) * 4u : 0x80000000u;
+                const unsigned vr1 = n_ok ? (unsigned)((1 - h4) * p.W * p.res_ld + n) * 4u : 0x80000000u;
 #pragma unroll
                 for (int r = 0; r < F::NACC; ++r) {
-                    const int so = (((r >> 3) * p.W) + 8 * ((r >> 2) & 1) + (r & 3)) * p.res_ld * 4;
-                    v[r] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, (int)vr, so, 0));
+                    const int so = PERM ? (4 * (r >> 2) + (r & 3)) * p.res_ld * 4
+                                        : (((r >> 3) * p.W) + 8 * ((r >> 2) & 1) + (r & 3)) * p.res_ld * 4;
+                    const bool flip = PERM && ((0x6 >> (r >> 2)) & 1);
+                    v[r] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, (int)(flip ? vr1 : vr), so, 0));
                 }
             }
             if (act == CP_ACT_RELU) {
@@ -71,11 +82,14 @@ __device__ __forceinline__ void patch_epilogue(const ConvParams& p, Frag<32>::ac
             }
             float* frag_out = p.out + (size_t)pix0 * p.ldo + p.coff;
             const __amdgpu_buffer_rsrc_t ro = make_rsrc(frag_out, (unsigned)((p.W + TW) * p.ldo) * 4u);
-            const unsigned vo = n_ok ? (unsigned)(4 * h4 * p.ldo + n) * 4u : 0x80000000u;
+            const unsigned vo = n_ok ? (unsigned)((PERM ? h4 * p.W : 4 * h4) * p.ldo + n) * 4u : 0x80000000u;
+            const unsigned vo1 = n_ok ? (unsigned)((1 - h4) * p.W * p.ldo + n) * 4u : 0x80000000u;
 #pragma unroll
             for (int r = 0; r < F::NACC; ++r) {
-                const int so = (((r >> 3) * p.W) + 8 * ((r >> 2) & 1) + (r & 3)) * p.ldo * 4;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, (int)vo, so, 0);
+                const int so = PERM ? (4 * (r >> 2) + (r & 3)) * p.ldo * 4
+                                    : (((r >> 3) * p.W) + 8 * ((r >> 2) & 1) + (r & 3)) * p.ldo * 4;
+                const bool flip = PERM && ((0x6 >> (r >> 2)) & 1);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, (int)(flip ? vo1 : vo), so, 0);
             }
         }
     }

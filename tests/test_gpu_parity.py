@@ -167,9 +167,11 @@ def test_dcn_both_precisions_vs_oracle(device, precision):
 
 @pytest.mark.parametrize("B,C,Co,H,W,std", [
     (2, 32, 64, 8, 16, 0.0),       # one patch per image, zero offsets: every sample inside the halo, image border = zero fill
-    (2, 64, 64, 16, 16, 1.5),      # the bench's offset scale: a few exception samples per block
-    (1, 128, 256, 32, 32, 3.0),    # four chunks, four N tiles; blocks over the exception capacity take the buffer-load mode
-    (1, 64, 128, 16, 32, 8.0),     # offsets far beyond the halo and the image: every block in the buffer-load mode
+    (2, 64, 64, 16, 16, 1.5),      # the bench's offset scale: a few dozen exception samples per block
+    (1, 128, 256, 32, 32, 3.0),    # four chunks, four N tiles; some blocks over the exception capacity
+    (1, 64, 128, 16, 32, 8.0),     # offsets far beyond the halo and the image
+    (1, 32, 64, 64, 64, 10.0),     # ... inside a larger image: every block over the exception capacity (buffer-load mode)
+    (2, 64, 64, 32, 32, 2.0),      # the upper end of the synthetic network's offset scale: ~100 exception samples per block
     (1, 64, 64, 128, 128, 1.5),    # the heaviest layer shape of the network (dla_up 64 -> 64 at 128 x 128)
 ])
 def test_dcn_patch_resident_vs_oracle_and_gather_kernel(device, B, C, Co, H, W, std):

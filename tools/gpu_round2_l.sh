@@ -3,7 +3,7 @@
 cd /root/repo; mkdir -p gpurun_out/l; export TMPDIR=/tmp
 [ -n "${SKIP_TESTS:-}" ] || timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "dcn" 2>&1 | tail -3
 R=$PWD; cd /tmp
-for args in "--std 1.5" "--std 0.5" "--std 1.5 --c 128 --co 128 --hw 64" "--std 1.5 --c 256 --co 256 --hw 32" "--std 1.5 --dbg 32768" "--std 1.5 --c 128 --co 128 --hw 64 --dbg 32768"; do
+for args in "--std 1.5 --dbg 65536" "--std 0.5 --dbg 65536" "--std 2.0 --dbg 65536" "--std 1.5 --c 128 --co 128 --hw 64 --dbg 65536" "--std 1.5 --c 256 --co 256 --hw 32 --dbg 65536" "--std 1.5 --dbg 32768" "--std 1.5 --c 128 --co 128 --hw 64 --dbg 32768"; do
   rm -rf $R/gpurun_out/l/kt
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/l/kt -- python $R/tools/dcn_bench.py --n 5 $args > $R/gpurun_out/l/kt.log 2>&1
   f=$(find $R/gpurun_out/l/kt -name "*kernel_stats.csv" | head -1)
