@@ -367,13 +367,16 @@ struct Packer {
         const auto* bias = get(p + ".conv.bias", cho);
         std::vector<float> sc, sh;
         if (bias && bn_fold(p + ".actf.0", cho, bias, sc, sh)) set_affine(d.main, &sc, sh);
-        if (d.main.w16_hi && d.main.w16_lo && status == CP_OK) {  // fragment-ordered copy for the patch-resident kernel
-            const size_t halfs = (size_t)d.main.CoutPad * d.main.Kpad16;
-            d.main.w16f_hi = dev_alloc((halfs + 1) / 2);
-            d.main.w16f_lo = dev_alloc((halfs + 1) / 2);
-            if (d.main.w16f_hi && d.main.w16f_lo) {
-                int rc = cp_launch_frag16_repack(d.main.w16_hi, d.main.w16f_hi, d.main.CoutPad, d.main.Kpad16, nullptr);
-                if (rc == CP_OK) rc = cp_launch_frag16_repack(d.main.w16_lo, d.main.w16f_lo, d.main.CoutPad, d.main.Kpad16, nullptr);
+        // fragment-ordered copies of both weight sets: dcn16p.hip (main) and halo16.hip's N = 32 tile (conv_offset_mask) load
+        // their MFMA operands straight from them
+        for (ConvW* c : {&d.main, &d.offset}) {
+            if (!c->w16_hi || !c->w16_lo || status != CP_OK) continue;
+            const size_t halfs = (size_t)c->CoutPad * c->Kpad16;
+            c->w16f_hi = dev_alloc((halfs + 1) / 2);
+            c->w16f_lo = dev_alloc((halfs + 1) / 2);
+            if (c->w16f_hi && c->w16f_lo) {
+                int rc = cp_launch_frag16_repack(c->w16_hi, c->w16f_hi, c->CoutPad, c->Kpad16, nullptr);
+                if (rc == CP_OK) rc = cp_launch_frag16_repack(c->w16_lo, c->w16f_lo, c->CoutPad, c->Kpad16, nullptr);
                 hip_ok(hipDeviceSynchronize());
                 if (rc != CP_OK) status = rc;
             }
@@ -1553,7 +1556,8 @@ size_t cp_conv2d_workspace_bytes(int Cin, int Cout, int KH, int KW) {
     const size_t cpad = align_up((size_t)Cout, cp_conv_tile_n(Cout));
     // f32 packed weights + (split-f16 path) two binary16 copies + per-channel weight scales (2^e, 2^-e, scale * 2^-e)
     // + the input's |max| slot
-    return align_up(kpad * cpad * sizeof(float), 256) + 2 * align_up(kpad * cpad * 2, 256) +
+    // (+ the fragment-ordered copies of the binary16 weights)
+    return align_up(kpad * cpad * sizeof(float), 256) + 4 * align_up(kpad * cpad * 2, 256) +
            3 * align_up(cpad * sizeof(float), 256) + (size_t)CP_AMAX_SUB * CP_AMAX_STRIDE * sizeof(unsigned);
 }
 
@@ -1619,6 +1623,14 @@ int cp_conv2d_nhwc(cp_stream_t stream, const float* x, const float* w, const flo
         if (rc == CP_OK) rc = cp_launch_pack_weight16(w, (void*)p.w16_hi, (void*)p.w16_lo, Cout, Cin, KH * KW, p.Kpad16, 0, wfwd, s);
         if (rc == CP_OK) rc = cp_launch_scale16(scale, winv, sc16, Cout, s);
         if (rc == CP_OK) rc = cp_launch_absmax(x, (size_t)B * H * W * Cin, slot, s);
+        if (rc == CP_OK && p.CoutPad % 32 == 0 && p.Kpad16 % 16 == 0) {
+            char* w16f = (char*)slot + (size_t)CP_AMAX_SUB * CP_AMAX_STRIDE * sizeof(unsigned);
+            const size_t fsz = align_up((size_t)p.Kpad * p.CoutPad * 2, 256);
+            rc = cp_launch_frag16_repack(p.w16_hi, w16f, p.CoutPad, p.Kpad16, s);
+            if (rc == CP_OK) rc = cp_launch_frag16_repack(p.w16_lo, w16f + fsz, p.CoutPad, p.Kpad16, s);
+            p.w16f_hi = w16f;
+            p.w16f_lo = w16f + fsz;
+        }
         if (rc != CP_OK) return rc;
         if (cp_conv16_supported(p)) {
             p.scale = sc16;

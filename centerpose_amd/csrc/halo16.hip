@@ -28,12 +28,12 @@ constexpr int PROW = CK;                                                  // hal
 // writes of 8 lanes (one pixel, 8 chunks) do too
 __device__ __forceinline__ int pswz(int q) { return q & 7; }
 
-// BDIRECT (experiment, off by default): the weight fragments of the 32-wide N tile loaded from global memory straight
-// into the MFMA operand registers (a lane's fragment -- row n = lane % 32, 8 consecutive k -- is one 16-byte load of the
-// k-contiguous packed weights), one K tile ahead, so that the K loop has no barrier at all.  Measured on the B=32 step
-// (profiles/r02_halo_ab.txt): 80 TFLOP/s against 106 for the LDS-staged tile -- neighbouring lanes read different
-// weight rows (1152 B apart), every lane its own cache line, and the texture addresser needs 4x the cycles of a
-// coalesced load; 8 such loads per wave and K tile cost more than the barrier they remove.
+// BDIRECT: the weight fragments of the 32-wide N tile come from global memory / L2 straight into the MFMA operand
+// registers, two K tiles ahead, out of the fragment-ordered copy of the weights (ConvParams::w16f_*, one coalesced 1 KB
+// load per fragment), so that the K loop has no barrier inside a chunk: with N = 32 a K tile is only 6 MFMAs per wave,
+// and the barrier + LDS round trip of the shared weight tile cost more than that.  (A first attempt read the fragments
+// from the k-contiguous [Cout][K] layout: every lane its own cache line, 80 TFLOP/s against 106 for the LDS tile --
+// profiles/r02_halo_ab.txt.)
 template <int MT, int NT, int WM, int WN, bool BDIRECT = false>
 __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     typedef Frag<32> F;
@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
     const unsigned img_bytes = (unsigned)p.B * p.H * p.W * (unsigned)p.Cin * 4u;
     const __amdgpu_buffer_rsrc_t r_x = make_rsrc(p.src[0], img_bytes);
     const unsigned w_bytes = (unsigned)((size_t)p.CoutPad * p.Kpad16 * 2);
-    const __amdgpu_buffer_rsrc_t r_wh = make_rsrc(p.w16_hi, w_bytes), r_wl = make_rsrc(p.w16_lo, w_bytes);
+    const __amdgpu_buffer_rsrc_t r_wh = make_rsrc(BDIRECT ? p.w16f_hi : p.w16_hi, w_bytes),
+                                 r_wl = make_rsrc(BDIRECT ? p.w16f_lo : p.w16_lo, w_bytes);
 
     // ---- staging geometry: slot s of this thread = patch pixel (tid / 16) + 16 s, float4 column tid % 16 ----
     constexpr int ST = (NPIX + 15) / 16;  // 12 passes of 16 pixels x 16 float4
@@ -113,27 +114,34 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
     }
     const int b_frag = (wn * (NT * 32) + lcol) * LDH;
 
-    // BDIRECT: this lane's fragment rows of the packed weights (n = wn tile + j * 32 + lcol), 16-byte k chunk lrow (+ 2 ks)
+    // BDIRECT: fragment (n tile j, K step g of 16) = 1 KB in lane order at ((j G + g) 64 + lane) 16 bytes
+    const int G = p.Kpad16 / 16, gpt = p.Cin / 16;  // K steps per weight row / per tap
     unsigned bd_off[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-        bd_off[j] = (unsigned)(((size_t)(tn * BN + wn * (NT * 32) + j * 32 + lcol) * p.Kpad16 + lrow * 8) * 2);
-    u32x4 dbh[2][2][NT], dbl[2][2][NT];  // [register set][k-step][fragment]
-    auto issue_bd = [&](int set, int kbyte) {
+    for (int j = 0; j < NT; ++j) bd_off[j] = (unsigned)((((tn * (BN / 32) + wn * NT + j) * G) * 64 + lane) * 16);
+    u32x4 dbh[3][2][NT], dbl[3][2][NT];  // [register set = K tile % 3][k-step][fragment]
+    const int nchunks = p.Cin / CK;
+    // K tile kt of chunk c = (tap kt / 2, 32-channel half kt % 2) -> first K step g = tap (Cin / 16) + 4 c + 2 (kt % 2)
+    auto issue_bd = [&](int set, int c, int kt) {
+        if (kt >= 18) { kt -= 18; ++c; }
+        if (c >= nchunks) return;
+        const int g = (kt >> 1) * gpt + 4 * c + 2 * (kt & 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                dbh[set][ks][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wh, (int)bd_off[j] + ks * 32, kbyte, 0);
-                dbl[set][ks][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)bd_off[j] + ks * 32, kbyte, 0);
+                dbh[set][ks][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wh, (int)bd_off[j], (g + ks) * 1024, 0);
+                dbl[set][ks][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)bd_off[j], (g + ks) * 1024, 0);
             }
     };
+    if (BDIRECT) {  // K tiles 0 and 1 in flight while the first patch is staged
+        issue_bd(0, 0, 0);
+        issue_bd(1, 0, 1);
+    }
 
-    const int nchunks = p.Cin / CK;
     for (int ch = 0; ch < nchunks; ++ch) {
         // first weight tile of the chunk in flight while the patch is staged
-        if (BDIRECT) issue_bd(0, ((0 * p.Cin) + ch * CK) * 2);
-        else issue_b(((0 * p.Cin) + ch * CK) * 2);
+        if (!BDIRECT) issue_b(((0 * p.Cin) + ch * CK) * 2);
         if (ch > 0) __syncthreads();  // every wave is done reading the previous chunk's patch
         // ---- stage the halo patch of this 64-channel chunk: float32 global -> hi / lo binary16 planes ----
 #pragma unroll 4
@@ -154,19 +162,10 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
         if (!BDIRECT) store_b(0);
         __syncthreads();
         // ---- 18 K tiles: (tap, 32-channel half) ----
-#pragma unroll 2
-        for (int kt = 0; kt < 18; ++kt) {
-            const int cur = kt & 1;
+        auto k_tile = [&](int kt, const _Float16* Bh, const _Float16* Bl, const u32x4 (&fh)[2][NT], const u32x4 (&fl)[2][NT]) {
             const int tap = kt >> 1, half = kt & 1;
-            if (kt + 1 < 18) {
-                const int tap1 = (kt + 1) >> 1, half1 = (kt + 1) & 1;
-                if (BDIRECT) issue_bd(cur ^ 1, (tap1 * p.Cin + ch * CK + half1 * 32) * 2);
-                else issue_b((tap1 * p.Cin + ch * CK + half1 * 32) * 2);
-            }
             const int kh = tap / 3, kw = tap - kh * 3;
             const int dq = kh * PW + kw;
-            const _Float16* Bh = bt[cur] + b_frag;
-            const _Float16* Bl = Bh + B_SZ;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 h8 ah[MT], al[MT], bh[NT], bl[NT];
@@ -182,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     if (BDIRECT) {
-                        bh[j] = *reinterpret_cast<const h8*>(&dbh[cur][ks][j]);
-                        bl[j] = *reinterpret_cast<const h8*>(&dbl[cur][ks][j]);
+                        bh[j] = *reinterpret_cast<const h8*>(&fh[ks][j]);
+                        bl[j] = *reinterpret_cast<const h8*>(&fl[ks][j]);
                     } else {
                         bh[j] = *reinterpret_cast<const h8*>(Bh + j * 32 * LDH + co);
                         bl[j] = *reinterpret_cast<const h8*>(Bl + j * 32 * LDH + co);
@@ -205,7 +204,25 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             }
-            if (!BDIRECT) {
+        };
+        if (BDIRECT) {
+#pragma unroll
+            for (int kt = 0; kt < 18; ++kt) {
+                // (phase order pinned: the scheduler would otherwise sink the loads to just above their use)
+                issue_bd((kt + 2) % 3, ch, kt + 2);  // set (kt + 2) % 3 = (kt - 1) % 3 was consumed by the previous tile
+                __builtin_amdgcn_sched_barrier(0);
+                k_tile(kt, nullptr, nullptr, dbh[kt % 3], dbl[kt % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll 2
+            for (int kt = 0; kt < 18; ++kt) {
+                const int cur = kt & 1;
+                if (kt + 1 < 18) {
+                    const int tap1 = (kt + 1) >> 1, half1 = (kt + 1) & 1;
+                    issue_b((tap1 * p.Cin + ch * CK + half1 * 32) * 2);
+                }
+                k_tile(kt, bt[cur] + b_frag, bt[cur] + b_frag + B_SZ, dbh[0], dbl[0]);
                 if (kt + 1 < 18) store_b(cur ^ 1);
                 __syncthreads();
             }
@@ -238,7 +255,10 @@ int cp_launch_halo16(const ConvParams& p, int bn, hipStream_t stream) {
     if (!cp_halo16_supported(p) || p.CoutPad % bn != 0) return CP_ERR_INVALID;
     if (bn == 128) return launch_halo<2, 2, 2, 2>(p, stream);
     if (bn == 64) return launch_halo<2, 1, 2, 2>(p, stream);
-    // (cp_set_debug 16384: the BDIRECT experiment -- measured SLOWER, 80 vs 106 TFLOP/s: see the template's comment)
-    if (bn == 32) return (p.dbg & 16384) ? launch_halo<1, 1, 4, 1, true>(p, stream) : launch_halo<1, 1, 4, 1>(p, stream);
+    // N tile 32: weight fragments straight from the fragment-ordered copy when the layer has one (cp_set_debug 16384:
+    // the LDS-staged weight tile instead, A/B runs)
+    if (bn == 32)
+        return (p.w16f_hi && p.w16f_lo && !(p.dbg & 16384)) ? launch_halo<1, 1, 4, 1, true>(p, stream)
+                                                             : launch_halo<1, 1, 4, 1>(p, stream);
     return CP_ERR_INVALID;
 }
