@@ -160,7 +160,7 @@ int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream);
 // K steps (of 16 for the f32 kernels, 32 for f16x3) and output tiles of the launch cp_launch_conv[16] would make
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 31
+#define CP_NUM_CONV_VARIANTS 32
 #define CP_VARIANT_GRU 26
 // split-f16 ("f16x3") implicit GEMM (igemm16.hip)
 bool cp_conv16_supported(const ConvParams& p);
@@ -177,6 +177,7 @@ int cp_dcn16p_blocks(const ConvParams& p);
 int cp_launch_dcn16p(const ConvParams& p, hipStream_t stream);
 int cp_launch_frag16_repack(const void* w16, void* w16f, int CoutPad, int Kpad16, hipStream_t s);
 #define CP_VARIANT_DCN16P 30
+#define CP_VARIANT_GN_FINAL 31
 // `fwd` (may be nullptr = 1): per-output-channel power-of-two factor applied before the split, indexed [coff + co]
 int cp_launch_pack_weight16(const float* w, void* hi, void* lo, int Cout, int Cin, int taps, int Kpad16, int coff,
                             const float* fwd, hipStream_t s);
@@ -234,6 +235,8 @@ int cp_launch_groupnorm_relu(float* x, const float* gamma, const float* beta, do
 // (sum, sum of squares) per (image, group) -> per (image, channel) affine a = rstd*gamma, d = beta - mean*rstd*gamma
 // x_amax / y_amax (optional): |max| slot of the un-normalised tensor, and the slot that receives the bound
 // max over (image, channel) of |a| * max|x| + |d| >= max|relu(a*x + d)| for the consumer's activation pre-scale
+int cp_launch_gn_final(const float* x, const float* ga, const float* gd, const float* wp, const float* bias, float* out,
+                       int B, int HW, int C, int N, int wld, int sigmoid, hipStream_t s);
 int cp_launch_gn_affine(const double* stats, const float* gamma, const float* beta, float* a, float* d, int B, int C,
                         int groups, double count, float eps, const unsigned* x_amax, unsigned* y_amax, hipStream_t s);
 int cp_launch_gn_finalize(const double* stats, float* mr, int n, double count, float eps, hipStream_t s);

@@ -131,7 +131,7 @@ int g_default_precision = CP_PREC_F32;
 // split-K policy: launches with fewer output tiles than kSplitTiles (and >= 8 K steps) are cut into K slices until
 // about kSplitTarget workgroups exist
 constexpr int kSplitTiles = 128, kSplitTarget = 384;  // (384 / 512 measured: B=32 equal, hourglass B=1 latency +7 %)
-int g_dbg = 0;  // cp_set_debug (A/B switches for tests and tuning): 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel, 256 unfused ConvGRU step, 512 no activation |max| tracking / pre-scale, 1024 previous DCN loop, 2048 alternative DCN wave counts
+int g_dbg = 0;  // cp_set_debug (A/B switches for tests and tuning): 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel, 256 unfused ConvGRU step, 512 no activation |max| tracking / pre-scale, 1024 previous DCN loop, 2048 alternative DCN wave counts, 4096 / 8192 halo kernel never / everywhere, 16384 LDS-staged weights in the N=32 halo kernel, 32768 / 65536 patch-resident DCN never / everywhere, 131072 GroupNorm'd heads' 1x1 on the matrix cores
 
 struct DeformW {
     ConvW offset;  // conv_offset_mask (27 -> 32 padded), shift = bias
@@ -1259,6 +1259,35 @@ struct Fwd {
                 }
             }
             role = CP_ROLE_HEAD_FINAL;
+            if (gn_in_a && !(g_dbg & 131072) && hid.C % 64 == 0 && hid.C <= 256 && (hid.H * hid.W) % 64 == 0 &&
+                ((size_t)B * hid.H * hid.W) % 256 == 0 && hw.classes <= 16 && !m->tap_name) {
+                // float32 vector-ALU kernel (ewise.hip: gn_final_kernel): the layer is an HBM stream of the hidden tensor
+                auto launch = [&]() -> int {
+                    return cp_launch_gn_final(hid.ptr(), gn_in_a, gn_in_d, hw.c1.wp, hw.c1.shift, head_out[i], B, hid.H * hid.W,
+                                              hid.C, hw.classes, hw.c1.CoutPad, sg ? 1 : 0, s);
+                };
+                if (m->profile) {
+                    cp_model::ProfRec r;
+                    r.variant = CP_VARIANT_GN_FINAL;
+                    r.role = CP_ROLE_HEAD_FINAL;
+                    const double M = (double)B * hid.H * hid.W;
+                    r.flops = 2.0 * M * hw.classes * (double)hid.C;
+                    r.bytes = 4.0 * (M * hid.C + M * hw.classes + (double)hid.C * hw.classes);
+                    r.M = (int)M; r.N = hw.classes; r.K = hid.C; r.kh = 1; r.stride = 1;
+                    r.e0 = m->get_event();
+                    r.e1 = m->get_event();
+                    (void)hipEventRecord(r.e0, s);
+                    chk(launch());
+                    (void)hipEventRecord(r.e1, s);
+                    m->prof.push_back(r);
+                } else {
+                    chk(launch());
+                }
+                gn_in_a = gn_in_d = nullptr;
+                gn_in_amax = nullptr;
+                role = -1;
+                continue;
+            }
             conv(hw.c1, {&hid}, 1, 0, sg ? CP_ACT_SIGMOID : CP_ACT_NONE, nullptr, nullptr, 0,
                  m->dry ? (float*)0x1000 : head_out[i], hw.classes);
         }

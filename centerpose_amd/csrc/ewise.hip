@@ -298,6 +298,92 @@ __global__ void gn_affine_kernel(const double* __restrict__ stats, const float* 
     }
 }
 
+// Final 1x1 convolution of a GroupNorm'd prediction head (pose_dla_dcn.py:505-520: conv3x3 -> GroupNorm -> ReLU ->
+// conv1x1 with 1..16 output maps): y[m][n] = bias[n] + sum_c relu(a[b][c] x[m][c] + d[b][c]) w[c][n] on the vector ALUs
+// in float32.  The layer reads a 256-channel hidden tensor (1 KB per pixel, 537 MB at batch 32) to write <= 64 bytes
+// per pixel: it is an HBM stream, and the matrix-core version (igemm16p_kernel<.., GNIN>, 128-pixel tiles, a barrier
+// per 32 channels) measured 3.8 TB/s on it.  Here 16 lanes share a pixel (16 channels each: four 16-byte loads, each
+// 16-lane group reading 256 contiguous bytes), every lane accumulates its partial sums for all n, the 16 partials are
+// combined with DPP row rotations, and a wave hands 64 consecutive pixels per output map to one coalesced store.
+// Weights sit in LDS as [n / 4][row][4] with row = (16 (4 i + k) + j) for channel 4 j + 64 i + k: the 16 lanes of a pixel
+// (j = 0..15, same i, k) read 16 consecutive 16-byte rows -- conflict-free.
+template <int NQ>
+__global__ __launch_bounds__(256) void gn_final_kernel(const float* __restrict__ x, const float* __restrict__ ga,
+                                                       const float* __restrict__ gd, const float* __restrict__ wp,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int C,
+                                                       int N, int wld, int HW, int sigmoid) {
+    constexpr int NP = 4 * NQ;
+    extern __shared__ __attribute__((aligned(16))) float gw[];  // [NQ][C][4]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < C * NP; i += 256) {
+        const int c = i / NP, n = i - c * NP;
+        const int row = 16 * (4 * (c >> 6) + (c & 3)) + ((c & 63) >> 2);
+        gw[((n >> 2) * C + row) * 4 + (n & 3)] = n < N ? wp[(size_t)c * wld + n] : 0.f;
+    }
+    __syncthreads();
+    const int j = lane & 15, g = lane >> 4;
+    const size_t px0 = ((size_t)blockIdx.x * 4 + wid) * 64;  // this wave's 64 consecutive pixels (one image: HW % 64 == 0)
+    const int b = (int)(px0 / HW);
+    const int CI = C / 64;  // float4 per lane and pixel (channels 4 j + 64 i .. + 3), <= 4
+    float keep[NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) keep[n] = 0.f;
+    float4 a4[4], d4[4];  // the GroupNorm affine of this lane's channels (one image per wave)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c0 = 4 * j + 64 * (i < CI ? i : 0);
+        a4[i] = *reinterpret_cast<const float4*>(ga + (size_t)b * C + c0);
+        d4[i] = *reinterpret_cast<const float4*>(gd + (size_t)b * C + c0);
+    }
+    for (int t = 0; t < 16; ++t) {
+        const float* xp = x + (px0 + 4 * t + g) * C;
+        float acc[NP];
+#pragma unroll
+        for (int n = 0; n < NP; ++n) acc[n] = 0.f;
+        float4 xv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < CI) xv[i] = *reinterpret_cast<const float4*>(xp + 4 * j + 64 * i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= CI) break;
+            const float4 v = xv[i];
+            const float h[4] = {fmaxf(fmaf(a4[i].x, v.x, d4[i].x), 0.f), fmaxf(fmaf(a4[i].y, v.y, d4[i].y), 0.f),
+                                fmaxf(fmaf(a4[i].z, v.z, d4[i].z), 0.f), fmaxf(fmaf(a4[i].w, v.w, d4[i].w), 0.f)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float* wr = gw + (16 * (4 * i + k) + j) * 4;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(wr + q * C * 4);
+                    acc[4 * q] = fmaf(h[k], w4.x, acc[4 * q]);
+                    acc[4 * q + 1] = fmaf(h[k], w4.y, acc[4 * q + 1]);
+                    acc[4 * q + 2] = fmaf(h[k], w4.z, acc[4 * q + 2]);
+                    acc[4 * q + 3] = fmaf(h[k], w4.w, acc[4 * q + 3]);
+                }
+            }
+        }
+        // sum over the 16 lanes of the pixel: rotations inside the DPP row (row_ror:8 / 4 / 2 / 1)
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            float v = acc[n];
+            v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x128, 0xf, 0xf, false));
+            v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x124, 0xf, 0xf, false));
+            v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x122, 0xf, 0xf, false));
+            v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x121, 0xf, 0xf, false));
+            keep[n] = (j == t) ? v : keep[n];  // lane (g, j) ends up with pixel 4 j + g
+        }
+    }
+    const size_t hw = px0 - (size_t)b * HW + 4 * j + g;
+#pragma unroll
+    for (int n = 0; n < NP; ++n)
+        if (n < N) {
+            float y = keep[n] + (bias ? bias[n] : 0.f);
+            if (sigmoid) y = 1.f / (1.f + expf(-y));
+            out[((size_t)b * N + n) * HW + hw] = y;
+        }
+}
+
 // BaseDetector.pre_process on device (base_detector.py:127-134): cv2.warpAffine(INTER_LINEAR, constant 0 border) of an
 // 8-bit HWC BGR frame to the network input size, then (x / 255 - mean) / std, written NCHW float32.
 // The warp follows OpenCV's fixed-point arithmetic (imgwarp.cpp WarpAffineInvoker + remapBilinear, restated in
@@ -483,6 +569,23 @@ int cp_launch_gn_affine(const double* stats, const float* gamma, const float* be
     if (C % groups) return CP_ERR_INVALID;
     hipLaunchKernelGGL(gn_affine_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, stats, gamma, beta, a, d, B, C, groups,
                        count, eps, x_amax, y_amax);
+    return check();
+}
+
+// x [B * HW][C] NHWC hidden tensor, ga / gd [B][C] (cp_launch_gn_affine), wp [C][wld] (ConvW::wp of the 1x1), out NCHW
+// [B][N][HW].  Requirements (else CP_ERR_INVALID, the caller keeps the matrix-core path): C % 64 == 0, HW % 64 == 0,
+// 1 <= N <= 16.
+int cp_launch_gn_final(const float* x, const float* ga, const float* gd, const float* wp, const float* bias, float* out,
+                       int B, int HW, int C, int N, int wld, int sigmoid, hipStream_t s) {
+    if (C % 64 != 0 || HW % 64 != 0 || N < 1 || N > 16 || C > 256) return CP_ERR_INVALID;
+    const size_t M = (size_t)B * HW;
+    if (M % 256 != 0) return CP_ERR_INVALID;
+    const int nq = (N + 3) / 4 == 3 ? 4 : (N + 3) / 4;
+    const dim3 grid((unsigned)(M / 256)), block(256);
+    const size_t lds = (size_t)C * 4 * nq * sizeof(float);
+    if (nq == 1) hipLaunchKernelGGL(gn_final_kernel<1>, grid, block, lds, s, x, ga, gd, wp, bias, out, C, N, wld, HW, sigmoid);
+    else if (nq == 2) hipLaunchKernelGGL(gn_final_kernel<2>, grid, block, lds, s, x, ga, gd, wp, bias, out, C, N, wld, HW, sigmoid);
+    else hipLaunchKernelGGL(gn_final_kernel<4>, grid, block, lds, s, x, ga, gd, wp, bias, out, C, N, wld, HW, sigmoid);
     return check();
 }
 

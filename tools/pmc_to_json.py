@@ -30,6 +30,8 @@ def variant(kname):
     if md:  # <MT, NT, WM, WN, OCC>
         mt, nt, wm, wn = (int(md.group(i)) for i in range(1, 5))
         return "dcn_igemm16_f16x3_m%dn%d" % (32 * mt * wm, 32 * nt * wn)
+    if "gn_final_kernel" in kname:
+        return "gn_final_f32_valu"
     if "dcn16p_kernel" in kname:
         return "dcn16p_f16x3_p128n64"
     mh = re.search(r"halo16_kernel<(\d+), (\d+), (\d+), (\d+)", kname)
