@@ -243,6 +243,19 @@ struct Packer {
         if (d) hip_ok(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
         return d;
     }
+    // fragment-ordered copies of the split-f16 weights (3x3 layers): dcn16p.hip and halo16.hip load their MFMA B operands
+    // straight from them
+    void frag_copies(ConvW& c) {
+        if (c.w16f_hi) return;
+        const size_t halfs = (size_t)c.CoutPad * c.Kpad16;
+        c.w16f_hi = dev_alloc((halfs + 1) / 2);
+        c.w16f_lo = dev_alloc((halfs + 1) / 2);
+        if (!c.w16f_hi || !c.w16f_lo) return;
+        int rc = cp_launch_frag16_repack(c.w16_hi, c.w16f_hi, c.CoutPad, c.Kpad16, nullptr);
+        if (rc == CP_OK) rc = cp_launch_frag16_repack(c.w16_lo, c.w16f_lo, c.CoutPad, c.Kpad16, nullptr);
+        hip_ok(hipDeviceSynchronize());
+        if (rc != CP_OK) status = rc;
+    }
     // Pack several PyTorch-layout weights side by side along Cout (GRU gates) into one GEMM operand.
     ConvW pack(const std::vector<std::string>& wnames, int cout_each, int cin, int kh, int kw, int cin_pad = 0,
                int cout_pad_min = 0) {
@@ -292,6 +305,7 @@ struct Packer {
             (void)hipFree(tmp);
             if (rc != CP_OK) status = rc;
         }
+        if (c.w16_hi && c.w16_lo && kh == 3 && kw == 3 && status == CP_OK) frag_copies(c);
         if (c.scale16 && status == CP_OK) {  // no affine yet: scale16 = winv (set_affine folds a scale in later)
             const int rc = cp_launch_scale16(nullptr, c.winv, c.scale16, c.CoutPad, nullptr);
             hip_ok(hipDeviceSynchronize());
@@ -367,20 +381,6 @@ struct Packer {
         const auto* bias = get(p + ".conv.bias", cho);
         std::vector<float> sc, sh;
         if (bias && bn_fold(p + ".actf.0", cho, bias, sc, sh)) set_affine(d.main, &sc, sh);
-        // fragment-ordered copies of both weight sets: dcn16p.hip (main) and halo16.hip's N = 32 tile (conv_offset_mask) load
-        // their MFMA operands straight from them
-        for (ConvW* c : {&d.main, &d.offset}) {
-            if (!c->w16_hi || !c->w16_lo || status != CP_OK) continue;
-            const size_t halfs = (size_t)c->CoutPad * c->Kpad16;
-            c->w16f_hi = dev_alloc((halfs + 1) / 2);
-            c->w16f_lo = dev_alloc((halfs + 1) / 2);
-            if (c->w16f_hi && c->w16f_lo) {
-                int rc = cp_launch_frag16_repack(c->w16_hi, c->w16f_hi, c->CoutPad, c->Kpad16, nullptr);
-                if (rc == CP_OK) rc = cp_launch_frag16_repack(c->w16_lo, c->w16f_lo, c->CoutPad, c->Kpad16, nullptr);
-                hip_ok(hipDeviceSynchronize());
-                if (rc != CP_OK) status = rc;
-            }
-        }
         m->deforms[p] = d;
     }
     void ida(const std::string& p, int o, const std::vector<int>& channels, const std::vector<int>& up_f) {

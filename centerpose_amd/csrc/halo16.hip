@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
     __shared__ __attribute__((aligned(16))) _Float16 patch_lo[NPIX * PROW];
     __shared__ __attribute__((aligned(16))) _Float16 bt[BDIRECT ? 1 : 2][BDIRECT ? 8 : 2 * B_SZ];  // [buffer][hi | lo]
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar register
     const int wm = wid / WN, wn = wid % WN;
     const int tile = tile_of_block(tiles_m, tiles_n);
     const int tn = tile % tiles_n;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
 
     // ---- staging geometry: slot s of this thread = patch pixel (tid / 16) + 16 s, float4 column tid % 16 ----
     constexpr int ST = (NPIX + 15) / 16;  // 12 passes of 16 pixels x 16 float4
-    const int c4 = tid & 15;
+
     // ---- weight tile loads: chunk f -> row n = f / 4, 16-byte column f % 4 of the 32-deep K tile ----
     unsigned b_off[B_SLOTS];
 #pragma unroll
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
     unsigned bd_off[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) bd_off[j] = (unsigned)((((tn * (BN / 32) + wn * NT + j) * G) * 64 + lane) * 16);
-    u32x4 dbh[3][2][NT], dbl[3][2][NT];  // [register set = K tile % 3][k-step][fragment]
+    constexpr int NSET = MT * NT == 1 ? 3 : 2;  // K tiles in flight + 1 (18 tiles per chunk: both rotations stay consistent)
+    u32x4 dbh[NSET][2][NT], dbl[NSET][2][NT];  // [register set = K tile % NSET][k-step][fragment]
     const int nchunks = p.Cin / CK;
     // K tile kt of chunk c = (tap kt / 2, 32-channel half kt % 2) -> first K step g = tap (Cin / 16) + 4 c + 2 (kt % 2)
     auto issue_bd = [&](int set, int c, int kt) {
@@ -134,9 +136,9 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
                 dbl[set][ks][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)bd_off[j], (g + ks) * 1024, 0);
             }
     };
-    if (BDIRECT) {  // K tiles 0 and 1 in flight while the first patch is staged
+    if (BDIRECT) {  // the first K tiles in flight while the first patch is staged
         issue_bd(0, 0, 0);
-        issue_bd(1, 0, 1);
+        if (NSET == 3) issue_bd(1, 0, 1);
     }
 
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -144,19 +146,35 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
         if (!BDIRECT) issue_b(((0 * p.Cin) + ch * CK) * 2);
         if (ch > 0) __syncthreads();  // every wave is done reading the previous chunk's patch
         // ---- stage the halo patch of this 64-channel chunk: float32 global -> hi / lo binary16 planes ----
-#pragma unroll 4
-        for (int s = 0; s < ST; ++s) {
-            const int q = (tid >> 4) + 16 * s;
-            if (q < NPIX) {
+        // all loads of a round are issued before the first conversion: one HBM round trip per round instead of one per
+        // slot (the round size is what the register file leaves: 6 slots next to 128 accumulators' worth of state)
+        constexpr int SR = (BDIRECT || MT * NT >= 4) ? 6 : 12;
+        // the thread id is rebuilt per chunk (not held in a vector register across the K loop)
+        int lane_c = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane_c));
+        const int tid_c = wid * 64 + lane_c, c4c = tid_c & 15;
+#pragma unroll
+        for (int s0 = 0; s0 < ST; s0 += SR) {
+            float4 sv[SR];
+#pragma unroll
+            for (int s = 0; s < SR; ++s) {
+                const int q = (tid_c >> 4) + 16 * (s0 + s);
                 const int py = q / PW, px = q - py * PW;
                 const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
-                const bool in = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const unsigned off = in ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + ch * CK + c4 * 4) * 4u : OOB;
-                const float4 v = buf_ld4(r_x, off);
-                const Split2 s0 = split2(v.x * afwd, v.y * afwd), s1 = split2(v.z * afwd, v.w * afwd);
-                const int col = ((((c4 >> 1) ^ pswz(q)) << 1) | (c4 & 1)) * 4;  // halfs
-                *reinterpret_cast<u32x2*>(patch_hi + q * PROW + col) = u32x2{s0.hi, s1.hi};
-                *reinterpret_cast<u32x2*>(patch_lo + q * PROW + col) = u32x2{s0.lo, s1.lo};
+                const bool in = q < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const unsigned off = in ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + ch * CK + c4c * 4) * 4u : OOB;
+                sv[s] = buf_ld4(r_x, off);
+            }
+#pragma unroll
+            for (int s = 0; s < SR; ++s) {
+                const int q = (tid_c >> 4) + 16 * (s0 + s);
+                if (q < NPIX) {
+                    const float4 v = sv[s];
+                    const Split2 h0 = split2(v.x * afwd, v.y * afwd), h1 = split2(v.z * afwd, v.w * afwd);
+                    const int col = ((((c4c >> 1) ^ pswz(q)) << 1) | (c4c & 1)) * 4;  // halfs
+                    *reinterpret_cast<u32x2*>(patch_hi + q * PROW + col) = u32x2{h0.hi, h1.hi};
+                    *reinterpret_cast<u32x2*>(patch_lo + q * PROW + col) = u32x2{h0.lo, h1.lo};
+                }
             }
         }
         if (!BDIRECT) store_b(0);
@@ -209,9 +227,10 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
 #pragma unroll
             for (int kt = 0; kt < 18; ++kt) {
                 // (phase order pinned: the scheduler would otherwise sink the loads to just above their use)
-                issue_bd((kt + 2) % 3, ch, kt + 2);  // set (kt + 2) % 3 = (kt - 1) % 3 was consumed by the previous tile
+                // set (kt + NSET - 1) % NSET = (kt - 1) % NSET was consumed by the previous tile
+                issue_bd((kt + NSET - 1) % NSET, ch, kt + NSET - 1);
                 __builtin_amdgcn_sched_barrier(0);
-                k_tile(kt, nullptr, nullptr, dbh[kt % 3], dbl[kt % 3]);
+                k_tile(kt, nullptr, nullptr, dbh[kt % NSET], dbl[kt % NSET]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -229,7 +248,9 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
         }
     }
 
-    patch_epilogue<MT, NT, WM, WN>(p, acc, b, ty0, tx0, tn, wm, wn, lane, ainv);
+    // (the lane id is rebuilt here instead of living in a vector register across the K loop)
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    patch_epilogue<MT, NT, WM, WN>(p, acc, b, ty0, tx0, tn, wm, wn, lane_e, ainv);
 }
 
 template <int MT, int NT, int WM, int WN, bool BDIRECT = false>
@@ -253,12 +274,11 @@ bool cp_halo16_supported(const ConvParams& p) {
 // bn: N tile the weights were padded for (32 / 64 / 128)
 int cp_launch_halo16(const ConvParams& p, int bn, hipStream_t stream) {
     if (!cp_halo16_supported(p) || p.CoutPad % bn != 0) return CP_ERR_INVALID;
-    if (bn == 128) return launch_halo<2, 2, 2, 2>(p, stream);
-    if (bn == 64) return launch_halo<2, 1, 2, 2>(p, stream);
-    // N tile 32: weight fragments straight from the fragment-ordered copy when the layer has one (cp_set_debug 16384:
-    // the LDS-staged weight tile instead, A/B runs)
-    if (bn == 32)
-        return (p.w16f_hi && p.w16f_lo && !(p.dbg & 16384)) ? launch_halo<1, 1, 4, 1, true>(p, stream)
-                                                             : launch_halo<1, 1, 4, 1>(p, stream);
+    // weight fragments straight from the fragment-ordered copy when the layer has one (cp_set_debug 16384: the LDS-staged
+    // weight tile instead, A/B runs)
+    const bool direct = p.w16f_hi && p.w16f_lo && !(p.dbg & 16384);
+    if (bn == 128) return direct ? launch_halo<2, 2, 2, 2, true>(p, stream) : launch_halo<2, 2, 2, 2>(p, stream);
+    if (bn == 64) return direct ? launch_halo<2, 1, 2, 2, true>(p, stream) : launch_halo<2, 1, 2, 2>(p, stream);
+    if (bn == 32) return direct ? launch_halo<1, 1, 4, 1, true>(p, stream) : launch_halo<1, 1, 4, 1>(p, stream);
     return CP_ERR_INVALID;
 }

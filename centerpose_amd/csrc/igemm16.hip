@@ -988,7 +988,9 @@ static bool dcn16p_wanted(const ConvParams& p) {
 
 static bool halo16_wanted(const ConvParams& p, int bn) {
     if ((p.dbg & 4096) || p.gn_in_a || !cp_halo16_supported(p)) return false;
-    return bn == 32 || (p.dbg & 8192);
+    // with the weight fragments coming straight from L2 (no barrier inside a chunk) the halo kernel beats the per-tap
+    // implicit GEMM on every N tile; with an LDS weight tile only on the 32-wide one (8192: everywhere anyway, A/B runs)
+    return bn == 32 || (p.w16f_hi && p.w16f_lo && !(p.dbg & 16384)) || (p.dbg & 8192);
 }
 
 bool cp_conv16_supported(const ConvParams& p) {
