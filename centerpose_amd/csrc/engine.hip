@@ -166,6 +166,8 @@ struct cp_model {
     ConvW gru_x, gru_h;
     void* gru_h16_hi = nullptr;  // hidden-side GRU weights re-ordered [tile][r|z|n][32] for the fused-gate kernel
     void* gru_h16_lo = nullptr;
+    void* gru_h16f_hi = nullptr;  // ... and in MFMA fragment order (halo16.hip)
+    void* gru_h16f_lo = nullptr;
     float* gru_h16_fwd = nullptr;  // [192] per-row 2^e of the fused-order copies, and the matching 2^-e
     float* gru_h16_inv = nullptr;
     std::vector<void*> device_allocs;
@@ -530,6 +532,16 @@ struct Packer {
                     }
                     hip_ok(hipDeviceSynchronize());
                 }
+                if (m->gru_h16_hi && m->gru_h16_lo && status == CP_OK) {
+                    m->gru_h16f_hi = dev_alloc(halfs / 2);
+                    m->gru_h16f_lo = dev_alloc(halfs / 2);
+                    if (m->gru_h16f_hi && m->gru_h16f_lo) {
+                        int rc = cp_launch_frag16_repack(m->gru_h16_hi, m->gru_h16f_hi, 192, 576, nullptr);
+                        if (rc == CP_OK) rc = cp_launch_frag16_repack(m->gru_h16_lo, m->gru_h16f_lo, 192, 576, nullptr);
+                        hip_ok(hipDeviceSynchronize());
+                        if (rc != CP_OK) status = rc;
+                    }
+                }
             }
         }
         const int hc = m->head_conv;
@@ -667,6 +679,8 @@ struct Fwd {
         p.act = CP_ACT_RELU;
         p.w16_hi = w.w16_hi;
         p.w16_lo = w.w16_lo;
+        p.w16f_hi = w.w16f_hi;
+        p.w16f_lo = w.w16f_lo;
         p.Kpad16 = w.Kpad16;
         p.splitk = 1;
         p.dbg = g_dbg;
@@ -690,7 +704,7 @@ struct Fwd {
         if (m->dry) return true;
         if (m->profile) {
             cp_model::ProfRec r;
-            r.variant = CP_VARIANT_FUSED_HEAD;
+            r.variant = cp_halo16_fused_head_supported(p) ? CP_VARIANT_HALO_HEAD : CP_VARIANT_FUSED_HEAD;
             r.role = CP_ROLE_HEAD;
             const double M = (double)B * p.Ho * p.Wo;
             r.flops = 2.0 * M * w.Cout * (double)(w.KH * w.KW * w.Cin) + 2.0 * M * hw.classes * (double)w.Cout;
@@ -1150,6 +1164,8 @@ struct Fwd {
                         p.K = 576; p.Kpad = 576; p.Kpad16 = 576;
                         p.Cout = 192; p.CoutPad = 192;
                         p.w16_hi = m->gru_h16_hi; p.w16_lo = m->gru_h16_lo;
+                        p.w16f_hi = m->gru_h16f_hi; p.w16f_lo = m->gru_h16f_lo;
+                        p.dbg = g_dbg;
                         p.scale = m->gru_h16_inv;  // 2^-e of the fused-order weight rows (the hidden-side convs have no affine)
                         p.in_amax[0] = h.amax;
                         p.out_amax = hn.amax;
@@ -1160,7 +1176,7 @@ struct Fwd {
                         auto launch = [&]() { return cp_launch_conv16_gru(p, s); };
                         if (m->profile) {
                             cp_model::ProfRec r;
-                            r.variant = CP_VARIANT_GRU;
+                            r.variant = cp_halo16_gru_supported(p) ? CP_VARIANT_HALO_GRU : CP_VARIANT_GRU;
                             r.role = CP_ROLE_GRU;
                             r.flops = 2.0 * (double)M * 192 * 576;
                             r.bytes = 4.0 * ((double)M * (64 + 192 + 64 + 64) + 576.0 * 192);

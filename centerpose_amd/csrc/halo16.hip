@@ -34,11 +34,15 @@ __device__ __forceinline__ int pswz(int q) { return q & 7; }
 // and the barrier + LDS round trip of the shared weight tile cost more than that.  (A first attempt read the fragments
 // from the k-contiguous [Cout][K] layout: every lane its own cache line, 80 TFLOP/s against 106 for the LDS tile --
 // profiles/r02_halo_ab.txt.)
-template <int MT, int NT, int WM, int WN, bool BDIRECT = false>
+// EPI: 0 = plain epilogue (patch16_common.h); 1 = fused prediction head (igemm16.hip: FUSE -- transposed main product,
+// bias + ReLU, second MFMA product with the 1x1 weights, slices to fuse_out); 2 = fused ConvGRU gates (igemm16.hip: GRU).
+template <int MT, int NT, int WM, int WN, bool BDIRECT = false, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
     static_assert(WM * WN == 4 && 32 * MT * WM == TH * TW, "4 waves over a 128-pixel patch");
+    static_assert(EPI != 1 || (MT == 2 && NT == 2 && WM == 2 && WN == 2), "fused head: 128 x 128 tiles");
+    static_assert(EPI != 2 || (MT == 1 && NT == 3 && WM == 4 && WN == 1), "GRU: 128 x 96 tiles");
     constexpr int BN = 32 * NT * WN;
     constexpr int B_CHUNKS = BN * BK16 * 2 / 16;  // 16-byte chunks per weight array (hi or lo) per 32-deep K tile
     constexpr int B_SLOTS = (B_CHUNKS + 255) / 256;
@@ -206,21 +210,25 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
                         bl[j] = *reinterpret_cast<const h8*>(Bl + j * 32 * LDH + co);
                     }
                 }
+                // (fused head: transposed product -- rows = output channels, columns = pixels)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = EPI == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = EPI == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = EPI == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             }
         };
         if (BDIRECT) {
@@ -250,15 +258,144 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
 
     // (the lane id is rebuilt here instead of living in a vector register across the K loop)
     const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if constexpr (EPI == 1) {
+        // ---- fused prediction head (the arithmetic of igemm16.hip's FUSE epilogue on this kernel's pixel order) ----
+        const int M = p.B * p.H * p.W;
+        const u32x4* w2h = reinterpret_cast<const u32x4*>(p.fuse_w2_hi) + (size_t)((tn * WN + wn) * 4) * 64 + lane_e;
+        const u32x4* w2l = reinterpret_cast<const u32x4*>(p.fuse_w2_lo) + (size_t)((tn * WN + wn) * 4) * 64 + lane_e;
+        h8 wh[2][2], wl[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const u32x4 a = w2h[(j * 2 + ks) * 64], c = w2l[(j * 2 + ks) * 64];
+                wh[j][ks] = *reinterpret_cast<const h8*>(&a);
+                wl[j][ks] = *reinterpret_cast<const h8*>(&c);
+            }
+        acc_t acc2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
+        const bool relu = p.act == CP_ACT_RELU;
+        float hmax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = tn * BN + wn * 64 + j * 32 + F::row(r, lane_e);
+                const float sc = (p.scale ? p.scale[ch] : 1.f) * ainv, sh = p.shift ? p.shift[ch] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float x = acc[i][j][r] * sc + sh;
+                    if (relu) x = fmaxf(x, 0.f);
+                    acc[i][j][r] = x;
+                    hmax = fmaxf(hmax, fabsf(x));
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hmax = fmaxf(hmax, __shfl_xor(hmax, o, 64));
+        float hfwd, hinv;
+        cp_amax_to_scale(__float_as_uint(hmax), &hfwd, &hinv);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    uint32_t hh[4], hl[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = ks * 8 + q * 2;
+                        const Split2 sp = split2(acc[i][j][r] * hfwd, acc[i][j][r + 1] * hfwd);
+                        hh[q] = sp.hi;
+                        hl[q] = sp.lo;
+                    }
+                    const u32x4 vh = {hh[0], hh[1], hh[2], hh[3]}, vl = {hl[0], hl[1], hl[2], hl[3]};
+                    const h8 bhh = *reinterpret_cast<const h8*>(&vh), bhl = *reinterpret_cast<const h8*>(&vl);
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j][ks], bhh, acc2[i], 0, 0, 0);
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j][ks], bhl, acc2[i], 0, 0, 0);
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j][ks], bhh, acc2[i], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();  // every wave is done with the patch planes
+        float* red = reinterpret_cast<float*>(patch_hi);  // [wm][i][r][lane]: 16 KB of the 23 KB plane
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float wi = (p.fuse_w2_inv ? p.fuse_w2_inv[F::row(r, lane_e)] : 1.f) * hinv;
+            acc2[0][r] *= wi;
+            acc2[1][r] *= wi;
+        }
+        if (wn == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((wm * 2 + i) * 16 + r) * 64 + lane_e] = acc2[i][r];
+        }
+        __syncthreads();
+        if (wn == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ml = wm * 64 + i * 32 + (lane_e & 31);  // tile row -> patch pixel (ml / 16, ml % 16)
+                const int m = (b * p.H + ty0 + (ml >> 4)) * p.W + tx0 + (ml & 15);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = F::row(r, lane_e);
+                    const float v = acc2[i][r] + red[((wm * 2 + i) * 16 + r) * 64 + lane_e];
+                    if (c < p.fuse_c2) p.fuse_out[((size_t)tn * p.fuse_c2 + c) * M + m] = v;
+                }
+            }
+        }
+        return;
+    }
+    if constexpr (EPI == 2) {
+        // ---- fused ConvGRU gates (igemm16.hip's GRU epilogue): r = sig(x_r + h_r); z = sig(x_z + h_z);
+        //      n = tanh(x_n + r * h_n); h' = (1 - z) * n + z * h   (convGRU.py:32-39) ----
+        const int lc = lane_e & 31, h4 = lane_e >> 5;
+        const int ch = tn * 32 + lc;
+        {
+            const int row0 = tn * 96 + lc;
+            const float s0 = (p.scale ? p.scale[row0] : 1.f) * ainv, s1 = (p.scale ? p.scale[row0 + 32] : 1.f) * ainv,
+                        s2 = (p.scale ? p.scale[row0 + 64] : 1.f) * ainv;
+#pragma unroll
+            for (int r = 0; r < F::NACC; ++r) { acc[0][0][r] *= s0; acc[0][1][r] *= s1; acc[0][2][r] *= s2; }
+        }
+        float amax = 0.f;
+        // fragment of wave wm = patch rows 2 wm, 2 wm + 1; accumulator r of lane half h4 = pixel (r / 8, 8 (r / 4 % 2) + r % 4 + 4 h4)
+        const int pix0 = __builtin_amdgcn_readfirstlane((b * p.H + ty0 + 2 * wm) * p.W + tx0);
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.gru_x3 + (size_t)pix0 * 192, (unsigned)(p.W + TW) * 192u * 4u);
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(p.gru_hprev + (size_t)pix0 * 64, (unsigned)(p.W + TW) * 64u * 4u);
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + (size_t)pix0 * 64, (unsigned)(p.W + TW) * 64u * 4u);
+        const int vx = (4 * h4 * 192 + ch) * 4, vh = (4 * h4 * 64 + ch) * 4;
+#pragma unroll
+        for (int r = 0; r < F::NACC; ++r) {
+            const int po = (r >> 3) * p.W + 8 * ((r >> 2) & 1) + (r & 3);
+            const int sx = po * 192 * 4, sh = po * 64 * 4;
+            const float xr = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx, sx, 0));
+            const float xz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx + 64 * 4, sx, 0));
+            const float xn = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx + 128 * 4, sx, 0));
+            const float hp = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rh, vh, sh, 0));
+            const float rg = 1.f / (1.f + expf(-(xr + acc[0][0][r])));
+            const float zg = 1.f / (1.f + expf(-(xz + acc[0][1][r])));
+            const float ng = tanhf(xn + rg * acc[0][2][r]);
+            const float hv = (1.f - zg) * ng + zg * hp;
+            amax = fmaxf(amax, fabsf(hv));
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), ro, vh, sh, 0);
+        }
+        if (p.out_amax) cp_amax_commit(p.out_amax, amax);
+        return;
+    }
     patch_epilogue<MT, NT, WM, WN>(p, acc, b, ty0, tx0, tn, wm, wn, lane_e, ainv);
 }
 
-template <int MT, int NT, int WM, int WN, bool BDIRECT = false>
+template <int MT, int NT, int WM, int WN, bool BDIRECT = false, int EPI = 0>
 int launch_halo(const ConvParams& p, hipStream_t stream) {
     constexpr int BN = 32 * NT * WN;
     const int tiles_m = p.B * (p.H / TH) * (p.W / TW), tiles_n = p.CoutPad / BN;
-    hipLaunchKernelGGL((halo16_kernel<MT, NT, WM, WN, BDIRECT>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m,
-                       tiles_n);
+    hipLaunchKernelGGL((halo16_kernel<MT, NT, WM, WN, BDIRECT, EPI>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p,
+                       tiles_m, tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
@@ -281,4 +418,31 @@ int cp_launch_halo16(const ConvParams& p, int bn, hipStream_t stream) {
     if (bn == 64) return direct ? launch_halo<2, 1, 2, 2, true>(p, stream) : launch_halo<2, 1, 2, 2>(p, stream);
     if (bn == 32) return direct ? launch_halo<1, 1, 4, 1, true>(p, stream) : launch_halo<1, 1, 4, 1>(p, stream);
     return CP_ERR_INVALID;
+}
+
+// the geometry / operand conditions of the two fused forms (their own launchers check the epilogue operands)
+static bool halo16_fused_geometry(const ConvParams& p) {
+    return p.w16f_hi && p.w16f_lo && !(p.dbg & 4096) && !(p.dbg & 16384) && p.KH == 3 && p.KW == 3 && p.stride == 1 &&
+           p.pad == 1 && p.nsrc == 1 && !p.offmask && !p.gn_in_a && !p.gn_in_mr && !p.gn_stats && p.splitk <= 1 &&
+           p.Cin % CK == 0 && p.H % TH == 0 && p.W % TW == 0 && p.H == p.Ho && p.W == p.Wo && p.Kpad16 == 9 * p.Cin &&
+           (size_t)p.B * p.H * p.W * p.Cin * 4 < (size_t)0xf0000000u;
+}
+
+// fused prediction head on the halo-resident kernel (same operands as cp_launch_conv16_fused_head)
+bool cp_halo16_fused_head_supported(const ConvParams& p) {
+    return halo16_fused_geometry(p) && p.CoutPad % 128 == 0 && p.fuse_w2_hi && p.fuse_w2_lo && p.fuse_out;
+}
+int cp_launch_halo16_fused_head(const ConvParams& p, hipStream_t stream) {
+    if (!cp_halo16_fused_head_supported(p)) return CP_ERR_INVALID;
+    return launch_halo<2, 2, 2, 2, true, 1>(p, stream);
+}
+
+// fused ConvGRU hidden-side step on the halo-resident kernel (same operands as cp_launch_conv16_gru)
+bool cp_halo16_gru_supported(const ConvParams& p) {
+    return halo16_fused_geometry(p) && p.CoutPad == 192 && p.Cin == 64 && p.gru_x3 && p.gru_hprev && p.out &&
+           (size_t)p.B * p.H * p.W * 192 * 4 < (size_t)0xf0000000u;
+}
+int cp_launch_halo16_gru(const ConvParams& p, hipStream_t stream) {
+    if (!cp_halo16_gru_supported(p)) return CP_ERR_INVALID;
+    return launch_halo<1, 3, 4, 1, true, 2>(p, stream);
 }

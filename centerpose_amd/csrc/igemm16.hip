@@ -1072,6 +1072,7 @@ bool cp_head_fuse_supported(const ConvParams& p, int c2) {
 int cp_launch_conv16_fused_head(const ConvParams& p, hipStream_t stream) {
     if (!cp_head_fuse_supported(p, p.fuse_c2) || !p.fuse_w2_hi || !p.fuse_w2_lo || !p.fuse_out || p.splitk > 1)
         return CP_ERR_INVALID;
+    if (cp_halo16_fused_head_supported(p)) return cp_launch_halo16_fused_head(p, stream);  // halo16.hip
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = (M + 127) / 128, tiles_n = p.CoutPad / 128;
     hipLaunchKernelGGL((igemm16p_kernel<2, 2, 2, 2, false, true>), dim3(tiles_m * tiles_n), dim3(NT16), 0, stream, p,
@@ -1112,6 +1113,7 @@ int cp_launch_conv16_gru(const ConvParams& p, hipStream_t stream) {
         p.CoutPad != 192 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.Kpad16 != 576 || p.splitk > 1 ||
         (size_t)p.B * p.H * p.W * 192 * 4 >= (size_t)0xf0000000u)
         return CP_ERR_INVALID;
+    if (cp_halo16_gru_supported(p)) return cp_launch_halo16_gru(p, stream);  // halo16.hip
     const int M = p.B * p.Ho * p.Wo;
     const int tiles_m = (M + 127) / 128, tiles_n = 2;
     hipLaunchKernelGGL((igemm16p_kernel<1, 3, 4, 1, false, false, false, true>), dim3(tiles_m * tiles_n), dim3(NT16), 0,

@@ -426,7 +426,9 @@ def test_fused_head_matches_unfused_path(device):
     model = hip.HipModel("dla_34", heads, sd, precision="f16x3")
     model.profile(True)
     model(x, sigmoid_hm=True)
-    assert "igemm16_head_f16x3_m128n128" in model.profile_read()   # the fused kernel is what runs
+    prof = model.profile_read()
+    # the fused kernel is what runs: on the halo-resident kernel for maps that tile into 8x16 patches (64x64 here)
+    assert "halo16_head_f16x3_m128n128" in prof or "igemm16_head_f16x3_m128n128" in prof, list(prof)
     model.profile(False)
     z = {k: v.clone() for k, v in model(x, sigmoid_hm=True).items()}
     z2 = model(x, sigmoid_hm=True)
@@ -435,10 +437,47 @@ def test_fused_head_matches_unfused_path(device):
         zu = {k: v.clone() for k, v in model(x, sigmoid_hm=True).items()}
     finally:
         hip.lib().cp_set_debug(0)
+    hip.lib().cp_set_debug(4096)   # the same fusion on the per-tap implicit-GEMM kernel (what ragged maps fall back to)
+    try:
+        model.profile(True)
+        zi = {k: v.clone() for k, v in model(x, sigmoid_hm=True).items()}
+        assert "igemm16_head_f16x3_m128n128" in model.profile_read()
+        model.profile(False)
+    finally:
+        hip.lib().cp_set_debug(0)
     for k in heads:
         assert torch.equal(z[k], z2[k]), k
         assert z[k].shape == zu[k].shape
         assert float((z[k] - zu[k]).abs().max()) < 2e-5 * max(1.0, float(zu[k].abs().max())), k
+        assert float((z[k] - zi[k]).abs().max()) < 2e-5 * max(1.0, float(zu[k].abs().max())), k
+
+
+def test_convgru_step_kernels_agree(device):
+    """dlav1_34's ConvGRU hidden-side step (convGRU.py:32-39) has three implementations: the gate arithmetic fused into
+    the halo-resident kernel (maps that tile into 8x16 patches), into the per-tap implicit-GEMM kernel (cp_set_debug 4096,
+    what ragged maps fall back to) and the unfused convolution + gate kernel (256).  Same products, different summation
+    orders: the heads must agree to float32 round-off."""
+    heads = synth.HEADS_POSE
+    sd = synth.make_state_dict("dlav1_34", heads)
+    x = synth.frames(2, seed=31, h=256, w=256).to(device)
+    model = hip.HipModel("dlav1_34", heads, sd, precision="f16x3")
+    model.profile(True)
+    z = {k: v.clone() for k, v in model(x, sigmoid_hm=True).items()}
+    assert "halo16_gru_f16x3_m128n96" in model.profile_read()
+    outs = {}
+    for flag, name in ((4096, "igemm16_gru_f16x3_m128n96"), (256, None)):
+        hip.lib().cp_set_debug(flag)
+        try:
+            outs[flag] = {k: v.clone() for k, v in model(x, sigmoid_hm=True).items()}
+            if name:
+                assert name in model.profile_read()
+        finally:
+            hip.lib().cp_set_debug(0)
+    model.profile(False)
+    for k in heads:
+        for flag in outs:
+            tol = 2e-5 * max(1.0, float(z[k].abs().max()))
+            assert float((z[k] - outs[flag][k]).abs().max()) < tol, (k, flag)
 
 
 def test_previous_frame_stems_are_independent(device):

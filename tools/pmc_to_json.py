@@ -34,10 +34,11 @@ def variant(kname):
         return "gn_final_f32_valu"
     if "dcn16p_kernel" in kname:
         return "dcn16p_f16x3_p128n64"
-    mh = re.search(r"halo16_kernel<(\d+), (\d+), (\d+), (\d+)", kname)
-    if mh:
+    mh = re.search(r"halo16_kernel<(\d+), (\d+), (\d+), (\d+)(?:, (?:true|false)(?:, (\d+))?)?", kname)
+    if mh:  # <MT, NT, WM, WN[, BDIRECT[, EPI]]>
         mt, nt, wm, wn = (int(mh.group(i)) for i in range(1, 5))
-        return "halo16_f16x3_m%dn%d" % (32 * mt * wm, 32 * nt * wn)
+        pre = {"1": "halo16_head", "2": "halo16_gru"}.get(mh.group(5) or "0", "halo16")
+        return "%s_f16x3_m%dn%d" % (pre, 32 * mt * wm, 32 * nt * wn)
     ml = re.search(r"lowc_kernel<(\d+), (\d+), (\d+), ", kname)
     if ml:
         return {("4", "1"): "lowc_stem7x7_f16x3", ("16", "1"): "lowc_3x3_c16_f16x3",
