@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs2", action="store_true", help="skip the BASELINE configs[2] leg of the default run")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--serial-pnp", action="store_true",
+                    help="full: run the PnP solve on the network's stream (A/B against the side-stream default)")
     ap.add_argument("--dbg", type=int, default=0, help="cp_set_debug flags (kernel A/B switches, tuning only)")
     return ap.parse_args()
 
@@ -74,7 +76,8 @@ def parse():
 class Pipeline(object):
     """frames -> heads -> detections [-> poses], all on device."""
 
-    def __init__(self, workload, batch, device, seed, precision="f32"):
+    def __init__(self, workload, batch, device, seed, precision="f32", serial_pnp=False):
+        self.serial_pnp = serial_pnp
         self.workload = workload
         self.arch = "dlav1_34" if workload in ("decode", "track_gru") else "hourglass" if workload == "hourglass" else "dla_34"
         self.track = workload in ("track", "track_gru")
@@ -84,6 +87,7 @@ class Pipeline(object):
         sd = synth.make_state_dict(self.arch, self.heads, self.track)
         self.model = hip.HipModel(self.arch, self.heads, sd, tracking_task=self.track, precision=precision)
         self.extra = {}
+        self._stages = {}
         if self.track:  # previous frame + rendered previous heat-maps (base_detector.py:150-388)
             g = synth._gen(seed, "pre")
             self.extra = dict(
@@ -121,10 +125,17 @@ class Pipeline(object):
             # the tracker of every video needs all detections: one RCCL all-gather of the fixed-size records
             return cpd.allgather_detections(det)
         # configs[2]: post-process + soft-NMS (cp_postprocess), PnP input assembly for rep_mode 1 and the batched solve
-        # (cp_pnp_from_post) -- library launches only, no torch indexing and no host synchronisation inside the step
+        # (cp_pnp_from_post) -- library launches only, no torch indexing and no host synchronisation inside the step.
+        # The solve (a few dozen latency-bound float64 wavefronts) is queued on hip.PoseStage's side stream and runs under
+        # the next batch's network; every solve has finished before the timed region's closing device synchronisation.
         n = det.shape[0]
-        post, cnt = hip.postprocess(det, self.meta[:n], 0.3, nms=True)
-        poses = hip.pnp_from_post(post, cnt, self.cam[:n], rep_mode=1)
+        if self.serial_pnp:
+            post, cnt = hip.postprocess(det, self.meta[:n], 0.3, nms=True)
+            return det, hip.pnp_from_post(post, cnt, self.cam[:n], rep_mode=1)
+        stage = self._stages.get(n)
+        if stage is None:
+            stage = self._stages[n] = hip.PoseStage(n, det.shape[1], self.device, depth=2)
+        post, cnt, poses, done = stage.submit(det, self.meta[:n], self.cam[:n], 0.3, nms=True, rep_mode=1)
         return det, poses
 
 
@@ -268,7 +279,8 @@ def main():
     if args.dbg:
         hip.lib().cp_set_debug(args.dbg)
     batch = args.batch or {"decode": 32, "full": 64, "track": 16, "track_gru": 16, "hourglass": 8}[args.workload]
-    pipe = Pipeline(args.workload, batch, device, seed=317 + 1000 * rank, precision=args.precision)
+    pipe = Pipeline(args.workload, batch, device, seed=317 + 1000 * rank, precision=args.precision,
+                    serial_pnp=args.serial_pnp)
 
     def barrier():
         if dist is not None:
@@ -341,7 +353,7 @@ def main():
             # BASELINE configs[2] in the same run: dla_34, batch 64, backbone + decode + batched PnP
             del pipe.model
             torch.cuda.empty_cache()
-            p2 = Pipeline("full", 64, device, seed=317, precision=args.precision)
+            p2 = Pipeline("full", 64, device, seed=317, precision=args.precision, serial_pnp=args.serial_pnp)
             k2 = max(4, min(args.steps, 12))
             dt2, prof2, roles2, sampled2 = timed_region(p2, k2, max(1, min(args.warmup, 2)), barrier)
             n2, r2 = max(prof2.items(), key=lambda kv: kv[1]["ms"])

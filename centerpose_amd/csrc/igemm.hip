@@ -408,8 +408,17 @@ __global__ void splitk_epilogue_kernel(const ConvParams p) {
         int m, n;
         if (p.store == CP_STORE_NHWC) { m = (int)(i / p.Cout); n = (int)(i - (size_t)m * p.Cout); }
         else { n = (int)(i / M); m = (int)(i - (size_t)n * M); }
+        // eight slab loads in flight per lane, then summed in slice order (a missing slice adds an exact 0)
         float acc = 0.f;
-        for (int z = 0; z < p.splitk; ++z) acc += p.partial[((size_t)z * M + m) * p.CoutPad + n];
+        const float* src = p.partial + (size_t)m * p.CoutPad + n;
+        const size_t slab = (size_t)M * p.CoutPad;
+        for (int z0 = 0; z0 < p.splitk; z0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (z0 + j < p.splitk) ? src[(size_t)(z0 + j) * slab] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
         float y = acc * ((p.scale ? p.scale[n] : 1.f) * ainv) + (p.shift ? p.shift[n] : 0.f);
         if (p.res) y += p.res[(size_t)m * p.res_ld + n];
         if (p.act == CP_ACT_RELU) y = fmaxf(y, 0.f);

@@ -246,20 +246,26 @@ POST_FIELDS = OrderedDict([  # field -> (offset, width) inside a post-processed 
     ("kps_heatmap_std", (96, 16)), ("kps_heatmap_height", (112, 8))])
 
 
-def postprocess(det, meta, vis_thresh, nms=True, div_scale=1.0):
+def postprocess(det, meta, vis_thresh, nms=True, div_scale=1.0, out=None, cnt=None, ws=None):
     """Device post-process + Gaussian soft-NMS of a whole batch (object_pose.py:167-197).
     det [B,K,118] float32 device; meta [B,8] float64 (inverse affine 6, ratio, pad) -> (records [B,K,120] float64
-    device, counts [B] int32 device); image b keeps records[b, :counts[b]] in the reference's final order."""
+    device, counts [B] int32 device); image b keeps records[b, :counts[b]] in the reference's final order.
+    ``out`` / ``cnt`` / ``ws``: caller-owned result and workspace tensors (PoseStage rotates its own)."""
     L = lib()
     if not (det.is_cuda and det.dtype == torch.float32 and det.is_contiguous() and det.dim() == 3
             and det.shape[2] == DET_STRIDE):
         raise RuntimeError("postprocess: det must be a contiguous float32 device tensor [B,K,118]")
     B, K = int(det.shape[0]), int(det.shape[1])
     meta = torch.as_tensor(meta, dtype=torch.float64).reshape(B, 8).contiguous().to(det.device)
-    out = torch.empty(B, K, POST_STRIDE, dtype=torch.float64, device=det.device)
-    cnt = torch.empty(B, dtype=torch.int32, device=det.device)
+    if out is None:
+        out = torch.empty(B, K, POST_STRIDE, dtype=torch.float64, device=det.device)
+    if cnt is None:
+        cnt = torch.empty(B, dtype=torch.int32, device=det.device)
     n = L.cp_postprocess_workspace_bytes(B, K)
-    ws = torch.empty(n, dtype=torch.uint8, device=det.device)
+    if ws is None:
+        ws = torch.empty(n, dtype=torch.uint8, device=det.device)
+    if tuple(out.shape) != (B, K, POST_STRIDE) or out.dtype != torch.float64 or cnt.numel() != B or ws.numel() < n:
+        raise RuntimeError("postprocess: out / cnt / ws do not fit this batch")
     rc = L.cp_postprocess(_stream(), _ptr(det), B, K, _ptr(meta), float(vis_thresh), int(bool(nms)), float(div_scale),
                           _ptr(out), _ptr(cnt), _ptr(ws), n)
     _check(rc, "cp_postprocess")
@@ -292,24 +298,71 @@ def pnp_solve(pts, scale, cam):
 _pnp_ws_cache = {}
 
 
-def pnp_from_post(post, count, cam, rep_mode=1):
+def pnp_from_post(post, count, cam, rep_mode=1, out=None, ws=None):
     """PnP of every post-processed slot on the device (cp_pnp_from_post): post [B,K,120] float64 + count [B] int32 from
     ``postprocess``, cam [B,4] float64 (fx, fy, cx, cy).  Returns [B,K,40] float64; rows k >= count[b] carry status -1.
-    No host synchronisation."""
+    No host synchronisation.  ``out`` / ``ws``: caller-owned result and workspace (default: a fresh result, one cached
+    workspace per shape -- calls on different streams must pass their own)."""
     L = lib()
     B, K = int(post.shape[0]), int(post.shape[1])
     if not (post.is_cuda and post.dtype == torch.float64 and post.is_contiguous() and count.is_cuda and cam.is_cuda):
         raise RuntimeError("pnp_from_post: contiguous device tensors expected (no CPU path)")
     cam = cam.contiguous().double().reshape(B, 4)
-    out = torch.empty(B, K, PNP_STRIDE, dtype=torch.float64, device=post.device)
+    if out is None:
+        out = torch.empty(B, K, PNP_STRIDE, dtype=torch.float64, device=post.device)
     n = L.cp_pnp_from_post_workspace_bytes(B, K)
-    key = (B, K, post.device)
-    ws = _pnp_ws_cache.get(key)
     if ws is None:
-        ws = _pnp_ws_cache[key] = torch.empty(n, dtype=torch.uint8, device=post.device)
+        key = (B, K, post.device)
+        ws = _pnp_ws_cache.get(key)
+        if ws is None:
+            ws = _pnp_ws_cache[key] = torch.empty(n, dtype=torch.uint8, device=post.device)
+    if tuple(out.shape) != (B, K, PNP_STRIDE) or out.dtype != torch.float64 or ws.numel() < n:
+        raise RuntimeError("pnp_from_post: out / ws do not fit this batch")
     _check(L.cp_pnp_from_post(_stream(), _ptr(post), _ptr(count), B, K, int(rep_mode), _ptr(cam), _ptr(out), _ptr(ws), n),
            "cp_pnp_from_post")
     return out
+
+
+class PoseStage(object):
+    """Post-process + soft-NMS + batched PnP of decoded batches (base_detector.py:547-654 for a whole batch), with the
+    PnP on a side stream.  The solve is at most B*K independent float64 problems of ~1e5 operations each: a few dozen
+    wavefronts whose run time is the slowest lane's Levenberg-Marquardt walk (0.5 - 2.5 ms), during which the rest of
+    the chip would idle.  ``submit`` therefore queues post-process on the caller's stream and the solve on the stage's
+    own stream, so that the solve of batch i runs under the network of batch i+1; ``depth`` sets of result buffers
+    rotate, and the caller's stream waits for the solve that last used a set before post-process overwrites it.
+
+    submit() -> (post [B,K,120], count [B], poses [B,K,40], done): the tensors are valid once ``done`` (a
+    torch.cuda.Event) has completed -- ``done.synchronize()`` on the host or ``stream.wait_event(done)``."""
+
+    def __init__(self, B, K, device, depth=2):
+        L = lib()
+        self.B, self.K, self.depth, self.i = int(B), int(K), int(depth), 0
+        self.side = torch.cuda.Stream(device=device)
+        n_post, n_pnp = L.cp_postprocess_workspace_bytes(B, K), L.cp_pnp_from_post_workspace_bytes(B, K)
+        self.sets = []
+        for _ in range(self.depth):
+            self.sets.append(dict(
+                post=torch.empty(B, K, POST_STRIDE, dtype=torch.float64, device=device),
+                cnt=torch.empty(B, dtype=torch.int32, device=device),
+                poses=torch.empty(B, K, PNP_STRIDE, dtype=torch.float64, device=device),
+                ws_post=torch.empty(n_post, dtype=torch.uint8, device=device),
+                ws_pnp=torch.empty(n_pnp, dtype=torch.uint8, device=device),
+                ready=torch.cuda.Event(), done=torch.cuda.Event()))
+
+    def submit(self, det, meta, cam, vis_thresh, nms=True, rep_mode=1):
+        s = self.sets[self.i % self.depth]
+        first_use = self.i < self.depth
+        self.i += 1
+        main = torch.cuda.current_stream()
+        if not first_use:
+            main.wait_event(s["done"])  # the solve that read this set `depth` batches ago
+        postprocess(det, meta, vis_thresh, nms=nms, out=s["post"], cnt=s["cnt"], ws=s["ws_post"])
+        s["ready"].record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(s["ready"])
+            pnp_from_post(s["post"], s["cnt"], cam, rep_mode=rep_mode, out=s["poses"], ws=s["ws_pnp"])
+            s["done"].record(self.side)
+        return s["post"], s["cnt"], s["poses"], s["done"]
 
 
 class HipModel(object):

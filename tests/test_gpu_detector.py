@@ -200,3 +200,56 @@ def test_device_gaussian_render_matches_reference_golden(device):
     out2 = hip.render_gaussians(recs[::-1].copy(), 9, 128, 128, device).cpu().numpy()
     assert np.array_equal(out, out2)   # max() merge: record order does not matter
     assert float(hip.render_gaussians(np.zeros((0, 5)), 1, 8, 8, device).abs().sum()) == 0.0
+
+
+def test_pose_stage_side_stream_matches_serial_path(device):
+    """hip.PoseStage (post-process on the caller's stream, PnP on a side stream, two rotating buffer sets) must return,
+    for every batch of a stream of different batches, exactly what the serial postprocess -> pnp_from_post path
+    returns -- including when a buffer set is reused while the previous solve that read it is still in flight."""
+    B, K = 4, 100
+    meta = np.zeros((B, 8))
+    from centerpose_amd.lib.utils.image import get_affine_transform
+
+    meta[:, :6] = get_affine_transform(np.array([256.0, 256.0], np.float32), 512.0, 0, (128, 128), inv=1).reshape(-1)
+    meta[:, 6] = 4.0
+    meta_d = torch.from_numpy(meta).to(device)
+    cam = torch.tensor([scene.K_DEMO[0, 0], scene.K_DEMO[1, 1], scene.K_DEMO[0, 2], scene.K_DEMO[1, 2]],
+                       dtype=torch.float64, device=device).repeat(B, 1).contiguous()
+    dets = []
+    for seed in (3, 4, 5, 6, 7):
+        heads, _ = scene.render(B, 3, seed=seed)
+        g = {k: torch.from_numpy(v).to(device) for k, v in heads.items()}
+        dets.append(hip.decode_raw(g["hm"], g["hps"], g["wh"], g["hm_hp"], None, g["scale"], None, g["reg"],
+                                   g["hp_offset"], None, None, K=K, rep_mode=1).clone())
+    serial = []
+    for d in dets:
+        post, cnt = hip.postprocess(d, meta_d, 0.3, nms=True)
+        serial.append((post.cpu(), cnt.cpu(), hip.pnp_from_post(post, cnt, cam, rep_mode=1).cpu()))
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=device)
+    got = []
+    with torch.cuda.stream(side):
+        stage = hip.PoseStage(B, K, device, depth=2)
+        for d in dets:
+            post, cnt, poses, done = stage.submit(d, meta_d, cam, 0.3, nms=True, rep_mode=1)
+            if len(got) % 2 == 0:
+                done.synchronize()  # odd batches are read only after later submits were queued behind them
+                got.append((post.cpu().clone(), cnt.cpu().clone(), poses.cpu().clone()))
+            else:
+                got.append((post, cnt, poses, done))
+            if len(got) >= 2 and len(got[-2]) == 4:
+                p2, c2, q2, d2 = got[-2]
+                # queued two submits ago on the other buffer set: still intact until the NEXT submit reuses that set
+                d2.synchronize()
+                got[-2] = (p2.cpu().clone(), c2.cpu().clone(), q2.cpu().clone())
+    torch.cuda.synchronize()
+    n_solved = 0
+    for i, ((p0, c0, q0), g1) in enumerate(zip(serial, got)):
+        p1, c1, q1 = g1[:3]
+        assert torch.equal(c0, c1), "batch %d counts" % i
+        for b in range(B):
+            n = int(c0[b])
+            assert torch.equal(p0[b, :n], p1[b, :n]), "batch %d image %d records" % (i, b)
+            assert torch.equal(q0[b, :n], q1[b, :n]), "batch %d image %d poses" % (i, b)
+            n_solved += int((q0[b, :n, 0] == 1).sum())
+    assert n_solved >= 5 * B
