@@ -70,6 +70,17 @@ __device__ __forceinline__ void cp_amax_commit(unsigned* slot, float local) {
         if (b > __hip_atomic_load(sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(sub, b);
     }
 }
+
+// Gate non-linearities of the fused ConvGRU epilogues (f16x3 mode): hardware exp2 / rcp, absolute error < 3e-7 (sigmoid)
+// and < 6e-7 (tanh) against expf / tanhf, i.e. at float32 round-off of the gate values.  The library forms cost ~80 VALU
+// instructions per output (range reduction, IEEE division, tanhf's branches) -- with 48 outputs per lane that was more
+// vector-ALU time than the K loop has matrix time.  The exact-f32 mode and the stand-alone gate kernel keep expf / tanhf.
+__device__ __forceinline__ float cp_fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float cp_fast_tanh(float x) {
+    return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.f;
+}
 #endif
 
 // One implicit-GEMM convolution:  out[m, n] = act( (sum_k A[m,k] * Wp[k,n]) * scale[n] + shift[n] + res[m,n] )

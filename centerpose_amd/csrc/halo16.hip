@@ -377,9 +377,9 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
             const float xz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx + 64 * 4, sx, 0));
             const float xn = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx + 128 * 4, sx, 0));
             const float hp = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rh, vh, sh, 0));
-            const float rg = 1.f / (1.f + expf(-(xr + acc[0][0][r])));
-            const float zg = 1.f / (1.f + expf(-(xz + acc[0][1][r])));
-            const float ng = tanhf(xn + rg * acc[0][2][r]);
+            const float rg = cp_fast_sigmoid(xr + acc[0][0][r]);
+            const float zg = cp_fast_sigmoid(xz + acc[0][1][r]);
+            const float ng = cp_fast_tanh(xn + rg * acc[0][2][r]);
             const float hv = (1.f - zg) * ng + zg * hp;
             amax = fmaxf(amax, fabsf(hv));
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), ro, vh, sh, 0);

@@ -819,9 +819,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
                 const float xz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx + 64 * 4, sx, 0));
                 const float xn = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx + 128 * 4, sx, 0));
                 const float hp = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rh, vh, sh, 0));
-                const float rg = 1.f / (1.f + expf(-(xr + acc[0][0][r])));
-                const float zg = 1.f / (1.f + expf(-(xz + acc[0][1][r])));
-                const float ng = tanhf(xn + rg * acc[0][2][r]);
+                const float rg = cp_fast_sigmoid(xr + acc[0][0][r]);
+                const float zg = cp_fast_sigmoid(xz + acc[0][1][r]);
+                const float ng = cp_fast_tanh(xn + rg * acc[0][2][r]);
                 const float hv = (1.f - zg) * ng + zg * hp;
                 amax = fmaxf(amax, fabsf(hv));
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), ro, vh, sh, 0);
@@ -833,9 +833,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
                 if (m >= M) continue;
                 const float* x3 = p.gru_x3 + (size_t)m * 192 + ch;
                 const float hp = p.gru_hprev[(size_t)m * 64 + ch];
-                const float rg = 1.f / (1.f + expf(-(x3[0] + acc[0][0][r])));
-                const float zg = 1.f / (1.f + expf(-(x3[64] + acc[0][1][r])));
-                const float ng = tanhf(x3[128] + rg * acc[0][2][r]);
+                const float rg = cp_fast_sigmoid(x3[0] + acc[0][0][r]);
+                const float zg = cp_fast_sigmoid(x3[64] + acc[0][1][r]);
+                const float ng = cp_fast_tanh(x3[128] + rg * acc[0][2][r]);
                 const float hv = (1.f - zg) * ng + zg * hp;
                 amax = fmaxf(amax, fabsf(hv));
                 p.out[(size_t)m * 64 + ch] = hv;
