@@ -359,6 +359,9 @@ def main():
             n2, r2 = max(prof2.items(), key=lambda kv: kv[1]["ms"])
             cfg2 = {"workload": "dla_34 512x512 batch=64, Objectron-shaped synthetic frames, backbone + sigmoid + decode + "
                                 "batched PnP (BASELINE configs[2])",
+                    "pnp": ("on the network's stream" if args.serial_pnp else
+                            "hip.PoseStage: queued on a side stream, runs under the next batch's network; all solves finish "
+                            "inside the timed region"),
                     "value": round(64 * k2 / dt2, 2), "unit": "images/sec", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 3),
                     "whole_step_tflops": round(64 * k2 / dt2 * GFLOP_PER_IMG["dla_34"] / 1e3, 2),
                     "dominant_kernel": {"kernel": n2, "tflops": round(r2["flops"] / (r2["ms"] * 1e-3) / 1e12, 1),
