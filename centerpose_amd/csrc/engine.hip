@@ -491,6 +491,7 @@ struct Packer {
         lowc("base.level1", "base.level1.0", 2, 32, 16, 3);
         if (has_pre_img) lowc("base.pre_img_layer", "base.pre_img_layer.0", 0, 16, 3, 7);
         if (has_pre_hm) lowc("base.pre_hm_layer", "base.pre_hm_layer.0", 0, 16, 1, 7);
+        if (has_pre_hm_hp) lowc("base.pre_hm_hp_layer", "base.pre_hm_hp_layer.0", 3, 16, 8, 7);
         tree("base.level2", 1, 32, 64, false);
         tree("base.level3", 2, 64, 128, true);
         tree("base.level4", 2, 128, 256, true);
@@ -952,7 +953,8 @@ struct Fwd {
         if (m->precision != CP_PREC_F16X3 || it == m->lowc.end() || (g_dbg & 64)) return Tensor();
         const ConvW& w = cw(name);
         const int Ho = kind == 2 ? (H - 1) / 2 + 1 : H, Wo = kind == 2 ? (W - 1) / 2 + 1 : W;
-        const int cout = kind == 2 ? 32 : 16, cin = kind == 0 ? planes : 16, k = kind == 0 ? 7 : 3;
+        const bool stem = kind == 0 || kind == 3;  // 3: the 8-plane stem (two groups of 4 planes)
+        const int cout = kind == 2 ? 32 : 16, cin = stem ? planes : 16, k = stem ? 7 : 3;
         Tensor out = make(cout, Ho, Wo);
         if (m->dry) return out;
         auto launch = [&]() {
@@ -961,7 +963,7 @@ struct Fwd {
         };
         if (m->profile) {
             cp_model::ProfRec r;
-            r.variant = CP_VARIANT_LOWC0 + kind;
+            r.variant = CP_VARIANT_LOWC0 + (kind == 3 ? 0 : kind);
             r.role = CP_ROLE_LOWC;
             const double M = (double)B * Ho * Wo;
             r.flops = 2.0 * M * cout * (double)(k * k * cin);
@@ -1087,8 +1089,12 @@ struct Fwd {
                 }
             }
             if (pre_hm_hp) {
-                Tensor in = to_nhwc(pre_hm_hp, 8, 8, H, W);
-                c = conv(cw("base.pre_hm_hp_layer"), {&in}, 1, 3, CP_ACT_RELU);
+                c = lowc("base.pre_hm_hp_layer", 3, pre_hm_hp, H, W, 8,
+                         use_lowc && !m->dry ? input_slot(pre_hm_hp, (size_t)B * 8 * H * W) : nullptr);
+                if (!c.valid()) {
+                    Tensor in = to_nhwc(pre_hm_hp, 8, 8, H, W);
+                    c = conv(cw("base.pre_hm_hp_layer"), {&in}, 1, 3, CP_ACT_RELU);
+                }
             }
             // x = x + pre_img_layer(..) + pre_hm_layer(..) + pre_hm_hp_layer(..)  (left-to-right, :312-318)
             std::vector<const Tensor*> adds;

@@ -14,7 +14,8 @@
 //
 // K layout (what pack_lowc_weights mirrors):
 //   CIN == 4  (stem; input planes 0..2 real, channel 3 zero):  k-step s = kh, lane chunk q = lane / 16 covers kernel
-//             columns 2q, 2q+1 (x 4 channels); column 7 is padding (zero weights).  K = 7 x 32.
+//             columns 2q, 2q+1 (x 4 channels); column 7 is padding (zero weights).  K = 7 x 32.  The 8-plane stem
+//             (pre_hm_hp_layer, pose_dla_dcn.py:262-265) is NG = 2 such groups of 4 planes: two LDS images, K = 14 x 32.
 //   CIN == 16 (3x3):  k-step s covers taps 2s, 2s+1 (tap = kh*3 + kw; tap 9 is padding), chunk q -> tap 2s + q/2,
 //             channels 8*(q%2) .. +7.  K = 5 x 32.
 #include "cp_common.h"
@@ -49,17 +50,19 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t* hi, uint32_t*
     *lo = *reinterpret_cast<uint32_t*>(&l);
 }
 
-template <int CIN, int KS, int S, int COUT, int TW, int TH, bool NCHW_IN>
+template <int CIN, int KS, int S, int COUT, int TW, int TH, bool NCHW_IN, int NG = 1>
 __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
     static_assert(CIN == 4 || CIN == 16, "channel layouts");
-    constexpr int KSTEPS = CIN == 4 ? KS : (KS * KS * CIN + 31) / 32;
+    static_assert(NG == 1 || (CIN == 4 && NCHW_IN), "plane groups: NCHW stems only");
+    constexpr int KSTEPS1 = CIN == 4 ? KS : (KS * KS * CIN + 31) / 32;  // per plane group
+    constexpr int KSTEPS = NG * KSTEPS1;
     constexpr int NF = COUT / 16;
     constexpr int XF = TW / 16;                // x fragments per tile row
     constexpr int IH = (TH - 1) * S + KS + 1;  // + 1: the padding tap / column reads finite data, never out of bounds
     constexpr int IW = (TW - 1) * S + KS + 1;
     constexpr int PLANE = IH * IW * CIN;       // halfs per LDS plane
-    __shared__ __attribute__((aligned(16))) _Float16 img_hi[PLANE];
-    __shared__ __attribute__((aligned(16))) _Float16 img_lo[PLANE];
+    __shared__ __attribute__((aligned(16))) _Float16 img_hi[NG * PLANE];
+    __shared__ __attribute__((aligned(16))) _Float16 img_lo[NG * PLANE];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
@@ -99,30 +102,35 @@ __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
         constexpr int NI = (IH * IW + 255) / 256, SRN = 1;
 #pragma unroll 1
         for (int r0 = 0; r0 < NI; r0 += SRN) {
-            float v[SRN][4];
+            float v[SRN][NG][4];
 #pragma unroll
             for (int k = 0; k < SRN; ++k) {
                 const int i = tid + (r0 + k) * 256;
                 const int r = i / IW, c = i - r * IW;
                 const int iy = iy0 + r, ix = ix0 + c;
-                v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.f;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) v[k][g][0] = v[k][g][1] = v[k][g][2] = v[k][g][3] = 0.f;
                 if (i < IH * IW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
                     const float* q = base + (size_t)iy * p.W + ix;
-                    v[k][0] = q[0];
-                    if (p.planes > 1) v[k][1] = q[plane_sz];
-                    if (p.planes > 2) v[k][2] = q[2 * plane_sz];
-                    if (p.planes > 3) v[k][3] = q[3 * plane_sz];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4)
+                            if (p.planes > 4 * g + c4) v[k][g][c4] = q[(size_t)(4 * g + c4) * plane_sz];
                 }
             }
 #pragma unroll
             for (int k = 0; k < SRN; ++k) {
                 const int i = tid + (r0 + k) * 256;
                 if (i >= IH * IW) continue;
-                uint32_t h0, l0, h1, l1;
-                split2(v[k][0] * afwd, v[k][1] * afwd, &h0, &l0);
-                split2(v[k][2] * afwd, v[k][3] * afwd, &h1, &l1);
-                *reinterpret_cast<u32x2*>(img_hi + i * 4) = u32x2{h0, h1};
-                *reinterpret_cast<u32x2*>(img_lo + i * 4) = u32x2{l0, l1};
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    uint32_t h0, l0, h1, l1;
+                    split2(v[k][g][0] * afwd, v[k][g][1] * afwd, &h0, &l0);
+                    split2(v[k][g][2] * afwd, v[k][g][3] * afwd, &h1, &l1);
+                    *reinterpret_cast<u32x2*>(img_hi + g * PLANE + i * 4) = u32x2{h0, h1};
+                    *reinterpret_cast<u32x2*>(img_lo + g * PLANE + i * 4) = u32x2{l0, l1};
+                }
             }
         }
     } else {
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
         for (int s = 0; s < KSTEPS; ++s) {
             h8 ah, al;
             if (CIN == 4) {
-                const int off = ((row * S + s) * IW + lx + 2 * q) * 4;  // 8-byte aligned
+                const int off = (s / KSTEPS1) * PLANE + ((row * S + s % KSTEPS1) * IW + lx + 2 * q) * 4;  // 8-byte aligned
                 const u32x2 h0 = *reinterpret_cast<const u32x2*>(img_hi + off), h1 = *reinterpret_cast<const u32x2*>(img_hi + off + 4);
                 const u32x2 l0 = *reinterpret_cast<const u32x2*>(img_lo + off), l1 = *reinterpret_cast<const u32x2*>(img_lo + off + 4);
                 const u32x4 hv = {h0.x, h0.y, h1.x, h1.y}, lv = {l0.x, l0.y, l1.x, l1.y};
@@ -216,9 +224,10 @@ __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
 }
 
 // PyTorch [COUT][cin][KS][KS] float32 -> hi / lo B fragments in the K layout described at the top of the file
+// ci0: first input channel of this plane group (CIN == 4 only)
 template <int CIN, int KS>
 __global__ void pack_lowc_weights(const float* __restrict__ w, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
-                                  const float* __restrict__ fwd, int cout, int cin) {
+                                  const float* __restrict__ fwd, int cout, int cin, int ci0) {
     constexpr int KSTEPS = CIN == 4 ? KS : (KS * KS * CIN + 31) / 32;
     const int nf = cout / 16, total = KSTEPS * nf * 64 * 8;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -227,7 +236,7 @@ __global__ void pack_lowc_weights(const float* __restrict__ w, uint16_t* __restr
         const int co = f * 16 + (lane & 15), q = lane >> 4;
         float v = 0.f;
         if (CIN == 4) {
-            const int kh = s, kw = 2 * q + (j >> 2), ci = j & 3;
+            const int kh = s, kw = 2 * q + (j >> 2), ci = ci0 + (j & 3);
             if (kw < KS && ci < cin) v = w[(((size_t)co * cin + ci) * KS + kh) * KS + kw];
         } else {
             const int tap = 2 * s + (q >> 1), ci = (q & 1) * 8 + j;
@@ -240,25 +249,30 @@ __global__ void pack_lowc_weights(const float* __restrict__ w, uint16_t* __restr
     }
 }
 
-template <int CIN, int KS, int S, int COUT, int TW, int TH, bool NCHW_IN>
+template <int CIN, int KS, int S, int COUT, int TW, int TH, bool NCHW_IN, int NG = 1>
 int launch_lowc(const LowcParams& p, hipStream_t s) {
     const int tiles = ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH) * p.B;
-    hipLaunchKernelGGL((lowc_kernel<CIN, KS, S, COUT, TW, TH, NCHW_IN>), dim3(tiles), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((lowc_kernel<CIN, KS, S, COUT, TW, TH, NCHW_IN, NG>), dim3(tiles), dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
 }  // namespace
 
-// kind: 0 stem 7x7 (NCHW input with `planes` <= 4 channels, pad 3) -> 16; 1 level0 3x3 16->16; 2 level1 3x3/2 16->32
+// kind: 0 stem 7x7 (NCHW input with `planes` <= 4 channels, pad 3) -> 16; 1 level0 3x3 16->16; 2 level1 3x3/2 16->32;
+//       3 stem 7x7 with 5..8 input planes (two groups of 4) -> 16
 size_t cp_lowc_weight_halfs(int kind) {
-    return kind == 0 ? (size_t)7 * 1 * 512 : kind == 1 ? (size_t)5 * 1 * 512 : (size_t)5 * 2 * 512;
+    return kind == 0 ? (size_t)7 * 1 * 512 : kind == 1 ? (size_t)5 * 1 * 512 : kind == 2 ? (size_t)5 * 2 * 512 : (size_t)14 * 512;
 }
 
 int cp_launch_pack_lowc(int kind, const float* w, void* hi, void* lo, const float* fwd, int cin, hipStream_t s) {
-    if (kind == 0) hipLaunchKernelGGL((pack_lowc_weights<4, 7>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, fwd, 16, cin);
-    else if (kind == 1) hipLaunchKernelGGL((pack_lowc_weights<16, 3>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, fwd, 16, cin);
-    else if (kind == 2) hipLaunchKernelGGL((pack_lowc_weights<16, 3>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, fwd, 32, cin);
-    else return CP_ERR_INVALID;
+    if (kind == 0) hipLaunchKernelGGL((pack_lowc_weights<4, 7>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, fwd, 16, cin, 0);
+    else if (kind == 1) hipLaunchKernelGGL((pack_lowc_weights<16, 3>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, fwd, 16, cin, 0);
+    else if (kind == 2) hipLaunchKernelGGL((pack_lowc_weights<16, 3>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, fwd, 32, cin, 0);
+    else if (kind == 3) {  // plane groups 0..3 and 4..7: fragments [group][kh][lane][8]
+        hipLaunchKernelGGL((pack_lowc_weights<4, 7>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, fwd, 16, cin, 0);
+        hipLaunchKernelGGL((pack_lowc_weights<4, 7>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi + 7 * 512, (uint16_t*)lo + 7 * 512,
+                           fwd, 16, cin, 4);
+    } else return CP_ERR_INVALID;
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
@@ -290,6 +304,11 @@ int cp_launch_lowc(int kind, const float* in, float* out, const void* w_hi, cons
     if (kind == 2) {
         p.Ho = (H + 2 - 3) / 2 + 1; p.Wo = (W + 2 - 3) / 2 + 1; p.pad = 1;
         return launch_lowc<16, 3, 2, 32, 32, 8, false>(p, s);
+    }
+    if (kind == 3) {
+        if (planes < 5 || planes > 8) return CP_ERR_INVALID;
+        p.Ho = H; p.Wo = W; p.pad = 3;
+        return launch_lowc<4, 7, 1, 16, 64, 8, true, 2>(p, s);
     }
     return CP_ERR_INVALID;
 }
