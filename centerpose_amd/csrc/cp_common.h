@@ -171,7 +171,7 @@ int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream);
 // K steps (of 16 for the f32 kernels, 32 for f16x3) and output tiles of the launch cp_launch_conv[16] would make
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 34
+#define CP_NUM_CONV_VARIANTS 36
 #define CP_VARIANT_GRU 26
 // split-f16 ("f16x3") implicit GEMM (igemm16.hip)
 bool cp_conv16_supported(const ConvParams& p);
@@ -187,6 +187,9 @@ int cp_launch_halo16(const ConvParams& p, int bn, hipStream_t stream);
 // fused DCNv2 gather + contraction (dcn16.hip); bn = N tile (64 / 128), variant = alternative wave count (tuning)
 int cp_launch_dcn16(const ConvParams& p, int bn, int variant, hipStream_t stream);
 // dcn16p.hip: patch-resident DCNv2 (gather from an LDS-staged halo); N tile 64
+// pw16.hip: 1x1 / stride-1 layers (incl. virtual concats) as a register-only stream, weight fragments from w16f_*
+bool cp_pw16_supported(const ConvParams& p);
+int cp_launch_pw16(const ConvParams& p, hipStream_t stream);
 bool cp_dcn16p_supported(const ConvParams& p);
 int cp_dcn16p_blocks(const ConvParams& p);
 int cp_launch_dcn16p(const ConvParams& p, hipStream_t stream);
@@ -195,6 +198,7 @@ int cp_launch_frag16_repack(const void* w16, void* w16f, int CoutPad, int Kpad16
 #define CP_VARIANT_GN_FINAL 31
 #define CP_VARIANT_HALO_HEAD 32
 #define CP_VARIANT_HALO_GRU 33
+#define CP_VARIANT_PW16 34  // + 1 for the 128-wide N tile
 // `fwd` (may be nullptr = 1): per-output-channel power-of-two factor applied before the split, indexed [coff + co]
 int cp_launch_pack_weight16(const float* w, void* hi, void* lo, int Cout, int Cin, int taps, int Kpad16, int coff,
                             const float* fwd, hipStream_t s);

@@ -993,6 +993,9 @@ static bool halo16_wanted(const ConvParams& p, int bn) {
     return bn == 32 || (p.w16f_hi && p.w16f_lo && !(p.dbg & 16384)) || (p.dbg & 8192);
 }
 
+// 1x1 layers: the register-only stream of pw16.hip (cp_set_debug 4194304: the LDS-staged loop instead, A/B runs)
+static bool pw16_wanted(const ConvParams& p) { return !(p.dbg & 4194304) && cp_pw16_supported(p); }
+
 bool cp_conv16_supported(const ConvParams& p) {
     if (!p.w16_hi || !p.w16_lo || p.Cin % BK16 != 0 || p.KH * p.KW > 32) return false;
     for (int s = 0; s < p.nsrc; ++s)
@@ -1039,6 +1042,7 @@ int cp_launch_conv16(const ConvParams& p, hipStream_t stream) {
     // clock, not by the A-side loads / conversion the halo removes, so only the 32-wide tile uses it by default.
     // cp_set_debug: 4096 = never, 8192 = every eligible layer (A/B runs).
     if (halo16_wanted(p, bn)) return cp_launch_halo16(p, bn, stream);
+    if (pw16_wanted(p)) return cp_launch_pw16(p, stream);
     if (bn == 128) return cat ? launch16<2, 2, 2, 2, false, true>(p, stream) : launch16<2, 2, 2, 2, false, false>(p, stream);
     if (bn == 64) return cat ? launch16<2, 1, 2, 2, false, true>(p, stream) : launch16<2, 1, 2, 2, false, false>(p, stream);
     return cat ? launch16<1, 1, 4, 1, false, true>(p, stream) : launch16<1, 1, 4, 1, false, false>(p, stream);
@@ -1050,6 +1054,7 @@ int cp_conv16_variant(const ConvParams& p) {
     if (p.offmask) return dcn16p_wanted(p) ? CP_VARIANT_DCN16P : bn == 128 ? 18 : 17;
     const int t = bn == 32 ? 0 : bn == 64 ? 1 : 2;
     if (halo16_wanted(p, bn)) return 27 + t;
+    if (pw16_wanted(p)) return CP_VARIANT_PW16 + (p.CoutPad % 128 == 0 ? 1 : 0);
     return (p.nsrc > 1 ? 19 : 14) + t;
 }
 

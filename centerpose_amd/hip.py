@@ -410,7 +410,7 @@ class HipModel(object):
 
     def profile_read(self):
         """-> {kernel name: dict(launches, ms, flops, bytes)} accumulated since the last read."""
-        nv = 34  # CP_NUM_KERNEL_VARIANTS (include/centerpose_hip.h)
+        nv = 36  # CP_NUM_KERNEL_VARIANTS (include/centerpose_hip.h)
         buf = (ctypes.c_double * (nv * 4))()
         _check(lib().cp_model_profile_read(self._h, buf, nv), "cp_model_profile_read")
         out = OrderedDict()

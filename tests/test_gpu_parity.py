@@ -120,6 +120,37 @@ def test_conv_both_precisions_vs_float64(device, precision, Cin, Cout, k, s, res
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,res,act", [
+    (2, 16, 16, 32, 64, False, 0),     # two K steps, N tile 64
+    (1, 20, 24, 448, 128, True, 1),    # M % 128 != 0 (ragged last tile), residual + ReLU, N tile 128
+    (3, 8, 8, 1280, 512, False, 1),    # the deepest Root node's shape: 80 K steps, four N tiles
+    (1, 12, 20, 64, 256, True, 0),
+])
+def test_pointwise_stream_kernel_vs_float64_and_lds_loop(device, f16x3, B, H, W, Cin, Cout, res, act):
+    """pw16.hip (1x1 layers as a register-only stream: A fragments straight from global memory, weight fragments from the
+    fragment-ordered copy) against a float64 convolution and against the LDS-staged loop it replaces (cp_set_debug
+    4194304): the same products summed in the same order."""
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    y = F.conv2d(x.double(), w.double())
+    r = torch.randn(y.shape, generator=g) if res else None
+    ref = y + r.double() if res else y
+    if act:
+        ref = ref.clamp(min=0)
+    args = (x.permute(0, 2, 3, 1).contiguous().to(device), w.to(device), None, None,
+            r.permute(0, 2, 3, 1).contiguous().to(device) if res else None, 1, 0, act)
+    out = hip.conv2d_nhwc(*args).permute(0, 3, 1, 2).cpu()
+    hip.lib().cp_set_debug(4194304)
+    try:
+        old = hip.conv2d_nhwc(*args).permute(0, 3, 1, 2).cpu()
+    finally:
+        hip.lib().cp_set_debug(0)
+    scale = float(ref.abs().max())
+    assert float((out.double() - ref).abs().max()) < 2e-5 * scale
+    assert float((out - old).abs().max()) < 2e-6 * scale
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,res,act", [
     (2, 16, 32, 64, 128, False, 1),     # N tile 128, one 64-channel chunk
     (1, 24, 16, 128, 64, True, 1),      # N tile 64, two chunks, residual (BasicBlock conv2)
     (3, 8, 48, 64, 27, False, 0),       # N tile 32 (conv_offset_mask shape)
