@@ -1208,6 +1208,14 @@ struct Fwd {
             }
         }
 
+        // GroupNorm statistics of every head (32 groups x (sum, sumsq) doubles per image = 128 floats per image and head):
+        // one block, zeroed by one memset per forward pass instead of one per head
+        Tensor stats_all;
+        if (m->gru) {
+            stats_all = make(128 * (int)m->headw.size(), 1, 1);
+            if (!m->dry && hipMemsetAsync(stats_all.ptr(), 0, sizeof(double) * 64 * B * m->headw.size(), s) != hipSuccess)
+                chk(CP_ERR_LAUNCH);
+        }
         for (size_t i = 0; i < m->headw.size(); ++i) {
             const HeadW& hw = m->headw[i];
             const Tensor* src = &feat;
@@ -1230,18 +1238,12 @@ struct Fwd {
                 }
                 src = &gru_out[r];
             }
-            Tensor stats, mr, ad;
+            Tensor mr, ad;
+            double* stats = m->gru && !m->dry ? (double*)stats_all.ptr() + (size_t)i * 64 * B : nullptr;
             const bool fuse_gn = m->gru && ((src->H * src->W) % 32 == 0) && hw.c0.Cout % 32 == 0 && (hw.c0.Cout / 32) % 4 == 0;
             if (m->gru) {
-                // GroupNorm statistics: 32 groups x (sum, sumsq) doubles per image = 128 floats per image
-                stats = make(128, 1, 1);
                 mr = make(64, 1, 1);
-                if (fuse_gn) {
-                    if (!m->dry) {
-                        if (hipMemsetAsync(stats.ptr(), 0, sizeof(double) * 64 * B, s) != hipSuccess) chk(CP_ERR_LAUNCH);
-                        gn_stats_out = (double*)stats.ptr();
-                    }
-                }
+                if (fuse_gn && !m->dry) gn_stats_out = stats;
             }
             const bool sg = sigmoid_hm && (hw.name == "hm" || hw.name == "hm_hp");
             if (!m->gru && hw.w2_hi && m->precision == CP_PREC_F16X3 && !m->tap_name && !(g_dbg & 32) &&
@@ -1261,14 +1263,14 @@ struct Fwd {
                             float* ap = ad.ptr();
                             float* dp = ap + (size_t)B * hid.C;
                             unsigned* bound = new_slot();
-                            chk(cp_launch_gn_affine((const double*)stats.ptr(), hw.gn_gamma, hw.gn_beta, ap, dp, B, hid.C, 32,
+                            chk(cp_launch_gn_affine((const double*)stats, hw.gn_gamma, hw.gn_beta, ap, dp, B, hid.C, 32,
                                                     (double)hid.H * hid.W * (hid.C / 32), 1e-5f, hid.amax, bound, s));
                             gn_in_a = ap;
                             gn_in_d = dp;
                             gn_in_amax = bound;
                         }
                     } else if (!m->dry) {
-                        chk(cp_launch_gn_finalize((const double*)stats.ptr(), mr.ptr(), B * 32,
+                        chk(cp_launch_gn_finalize((const double*)stats, mr.ptr(), B * 32,
                                                   (double)hid.H * hid.W * (hid.C / 32), 1e-5f, s));
                         gn_in_mr = mr.ptr();
                         gn_in_gamma = hw.gn_gamma;
@@ -1276,7 +1278,7 @@ struct Fwd {
                     }
                 } else if (!m->dry) {
                     // in place: the slot keeps the larger of the raw and the normalised |max| -- a valid bound
-                    chk(cp_launch_groupnorm_relu(hid.ptr(), hw.gn_gamma, hw.gn_beta, (double*)stats.ptr(), B,
+                    chk(cp_launch_groupnorm_relu(hid.ptr(), hw.gn_gamma, hw.gn_beta, stats, B,
                                                  hid.H * hid.W, hid.C, 32, 1e-5f, hid.amax, s));
                 }
             }
