@@ -1,4 +1,4 @@
-// Batched cuboid PnP on device, float64, one lane per detection.
+// Batched cuboid PnP on device, float64, sixteen lanes per detection (one per image point) in the common case.
 //
 // Replaces the per-detection host loop `pnp_shell` -> `CuboidPNPSolver.solve_pnp` ->
 // `cv2.solvePnPGeneric(flags=SOLVEPNP_ITERATIVE)` + `cv2.projectPoints`
@@ -16,8 +16,14 @@
 // z < 0 rejection, OpenGL conversion and axis-angle quaternion follow the reference's Python.
 //
 // The work is ~10^5 float64 operations per detection and a few hundred detections per batch: it is
-// latency-bound, not bandwidth- or MFMA-bound; one lane per detection keeps every solve independent
-// and deterministic, and the whole batch is one launch instead of a Python loop.
+// latency-bound, not bandwidth- or MFMA-bound, and the whole batch is one launch instead of a Python loop.
+// pnp_kernel gives a detection the 16 lanes of one DPP row: lane k owns image point k for everything that is a sum
+// over points (the DLT normal matrix, LM's J^T J / J^T e / reprojection error), reduced with an xor butterfly whose
+// result is bit-identical on all 16 lanes, so the small dense algebra in between (eigenvector, polar factor, Rodrigues,
+// the 6x6 solve) runs redundantly and every data-dependent branch of the Levenberg-Marquardt walk stays uniform
+// inside the group.  Per iteration that is ~1500 instead of ~5300 dependent instructions, and a wavefront now holds 4
+// detections instead of 64, so one slow walk (20 iterations on a poorly conditioned point set) no longer holds 63
+// finished ones.  Results are deterministic; they differ from the one-lane order only in the summation order over points.
 #include "cp_common.h"
 
 namespace {
@@ -340,6 +346,125 @@ __device__ __forceinline__ void write_pose(const Problem& q, const double param[
     o[0] = (param[5] < 0) ? 2.0 : 1.0;  // 2: solved but behind the camera -> the reference drops it (:207-220)
 }
 
+// ---- sixteen lanes per detection (pnp_kernel) ----
+// sum over the 16 lanes of the group: xor butterfly; a + b == b + a bit for bit, so every lane ends with the same value
+__device__ __forceinline__ double gsum16(double v) {
+    v += __shfl_xor(v, 1, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 8, 16);
+    return v;
+}
+
+// lm_refine with lane `sub` owning image point `sub`: the sums over points are group reductions, everything else (and
+// every branch) is computed identically by the 16 lanes
+__device__ __forceinline__ int lm_refine16(const Problem& q, double param[6], int sub) {
+    const Cam cam = q.cam;
+    const bool pv = sub < q.npts && pt_valid(q, sub);
+    const double* M = q.V3[(sub < q.npts ? sub : 0) / q.per];
+    const double pu = pv ? (double)q.P[2 * sub] : 0.0, pw = pv ? (double)q.P[2 * sub + 1] : 0.0;
+    double prev[6];
+    int lambda_lg10 = -3, iters = 0;
+    double prev_err = 0, JtJ[36], JtE[6];
+    bool calc_j = true;
+    for (int guard = 0; guard < 2000; ++guard) {
+        double R[9], dR[27];
+        if (calc_j) {
+            rodrigues(param, R, dR);
+            double u, v, x, y, z;
+            project1(R, param + 3, cam, M, u, v, x, y, z);
+            const double eu = pv ? u - pu : 0.0, evv = pv ? v - pw : 0.0;
+            double ju[6], jv[6];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double dx0 = M[0] * dR[j * 9 + 0] + M[1] * dR[j * 9 + 1] + M[2] * dR[j * 9 + 2];
+                const double dy0 = M[0] * dR[j * 9 + 3] + M[1] * dR[j * 9 + 4] + M[2] * dR[j * 9 + 5];
+                const double dz0 = M[0] * dR[j * 9 + 6] + M[1] * dR[j * 9 + 7] + M[2] * dR[j * 9 + 8];
+                ju[j] = pv ? cam.fx * z * (dx0 - x * dz0) : 0.0;
+                jv[j] = pv ? cam.fy * z * (dy0 - y * dz0) : 0.0;
+            }
+            ju[3] = pv ? cam.fx * z : 0.0; ju[4] = 0; ju[5] = pv ? -cam.fx * x * z : 0.0;
+            jv[3] = 0; jv[4] = pv ? cam.fy * z : 0.0; jv[5] = pv ? -cam.fy * y * z : 0.0;
+            const double e2 = gsum16(eu * eu + evv * evv);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                JtE[a] = gsum16(ju[a] * eu + jv[a] * evv);
+#pragma unroll
+                for (int b = a; b < 6; ++b) {
+                    const double t = gsum16(ju[a] * ju[b] + jv[a] * jv[b]);
+                    JtJ[a * 6 + b] = t;
+                    JtJ[b * 6 + a] = t;
+                }
+            }
+            for (int k = 0; k < 6; ++k) prev[k] = param[k];
+            if (iters == 0) prev_err = sqrt(e2);
+            calc_j = false;
+        } else {
+            rodrigues(param, R, nullptr);
+            double u, v, x, y, z;
+            project1(R, param + 3, cam, M, u, v, x, y, z);
+            const double eu = pv ? u - pu : 0.0, evv = pv ? v - pw : 0.0;
+            const double err = sqrt(gsum16(eu * eu + evv * evv));
+            bool retry = false;
+            if (err > prev_err) {
+                ++lambda_lg10;
+                if (lambda_lg10 <= 16) retry = true;
+            }
+            if (!retry) {
+                lambda_lg10 = lambda_lg10 - 1 < -16 ? -16 : lambda_lg10 - 1;
+                ++iters;
+                double dn = 0, pn = 0;
+                for (int k = 0; k < 6; ++k) { dn += (param[k] - prev[k]) * (param[k] - prev[k]); pn += prev[k] * prev[k]; }
+                const double rel = sqrt(dn) / (pn > 0 ? sqrt(pn) : 1.0);
+                if (iters >= 20 || rel < FLT_EPS) break;
+                prev_err = err;
+                calc_j = true;
+                continue;
+            }
+        }
+        // step(): param = prev - solve(JtJ with diag *= 1 + lambda, JtErr)
+        double Aq[36], bq[6], dx[6];
+        const double lam = exp(lambda_lg10 * log(10.0));
+        for (int k = 0; k < 36; ++k) Aq[k] = JtJ[k];
+        for (int k = 0; k < 6; ++k) { Aq[k * 7] *= 1.0 + lam; bq[k] = JtE[k]; }
+        solve6(Aq, bq, dx);
+        for (int k = 0; k < 6; ++k) param[k] = prev[k] - dx[k];
+    }
+    return iters;
+}
+
+// write_pose with the reprojection error summed over the group; only lane 0 of the group writes
+__device__ __forceinline__ void write_pose16(const Problem& q, const double param[6], int iters, double* o, int sub) {
+    double R[9];
+    rodrigues(param, R, nullptr);
+    const bool pv = sub < q.npts && pt_valid(q, sub);
+    double e2 = 0;
+    {
+        double u, v, x, y, z;
+        project1(R, param + 3, q.cam, q.V3[(sub < q.npts ? sub : 0) / q.per], u, v, x, y, z);
+        const double du = pv ? u - q.P[2 * sub] : 0.0, dv = pv ? v - q.P[2 * sub + 1] : 0.0;
+        e2 = gsum16(du * du + dv * dv);
+    }
+    if (sub != 0) return;
+    for (int k = 0; k < 6; ++k) o[1 + k] = param[k];
+    o[7] = sqrt(e2) / sqrt(2.0 * q.nv);
+    for (int v = 0; v < 8; ++v) {
+        double u, vv, x, y, z;
+        project1(R, param + 3, q.cam, q.V3[v], u, vv, x, y, z);
+        o[8 + 2 * v] = u;
+        o[9 + 2 * v] = vv;
+    }
+    axis_angle_quat(param, o + 24);
+    // OpenGL convention: M = [[0,1,0],[1,0,0],[0,0,-1]] applied on the left (cuboid_pnp_solver.py:179-196)
+    const double Rg[9] = {R[3], R[4], R[5], R[0], R[1], R[2], -R[6], -R[7], -R[8]};
+    o[28] = param[4]; o[29] = param[3]; o[30] = -param[5];
+    double rg[3];
+    rot_to_rvec(Rg, rg);
+    axis_angle_quat(rg, o + 31);
+    o[36] = iters;
+    o[0] = (param[5] < 0) ? 2.0 : 1.0;  // 2: solved but behind the camera -> the reference drops it (:207-220)
+}
+
 // cuboid model + valid-point count of detection i
 __device__ __forceinline__ void load_problem(Problem& q, const float* pts, const float* scale, const double* camp, int i, int npts) {
     q.cam = {camp[i * 4 + 0], camp[i * 4 + 1], camp[i * 4 + 2], camp[i * 4 + 3]};
@@ -361,80 +486,75 @@ __device__ __forceinline__ void load_problem(Problem& q, const float* pts, const
 
 // pts [N][npts][2] float (npts = 8 or 16), scale [N][3] float, cam [N][4] double (fx, fy, cx, cy)
 // out [N][CP_PNP_STRIDE] double;  scratch: unused since the eigen-solver moved into registers (kept in the ABI).
+// Sixteen consecutive lanes = one detection (4 detections per wavefront); lane `sub` owns image point `sub`.
 __global__ __launch_bounds__(64) void pnp_kernel(const float* __restrict__ pts, const float* __restrict__ scale,
                                                  const double* __restrict__ camp, int N, int npts,
                                                  double* __restrict__ out, double* __restrict__ scratch) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gi >> 4, sub = gi & 15;
+    if (i >= N) return;  // whole groups leave together
     double* o = out + (size_t)i * CP_PNP_STRIDE;
-    for (int k = 0; k < CP_PNP_STRIDE; ++k) o[k] = 0.0;
-    const Cam cam = {camp[i * 4 + 0], camp[i * 4 + 1], camp[i * 4 + 2], camp[i * 4 + 3]};
-    // cuboid: size = scale / scale[1]  (cuboid_pnp_shell.py:12), vertices cuboid_objectron.py:97-109
-    const double s1 = (double)scale[i * 3 + 1];
-    const double hw = 0.5 * ((double)scale[i * 3 + 0] / s1), hh = 0.5 * ((double)scale[i * 3 + 1] / s1),
-                 hd = 0.5 * ((double)scale[i * 3 + 2] / s1);
-    double V3[8][3];
-    for (int v = 0; v < 8; ++v) {
-        V3[v][0] = (v & 4) ? hw : -hw;
-        V3[v][1] = (v & 2) ? hh : -hh;
-        V3[v][2] = (v & 1) ? hd : -hd;
-    }
-    const int per = npts / 8;
-    const float* P = pts + (size_t)i * npts * 2;
-    // valid points
-    int nv = 0;
+    if (sub == 0)
+        for (int k = 0; k < CP_PNP_STRIDE; ++k) o[k] = 0.0;
+    Problem q;
+    load_problem(q, pts, scale, camp, i, npts);
+    const Cam cam = q.cam;
+    const int per = q.per, nv = q.nv;
+    const float* P = q.P;
     double Mc[3] = {0, 0, 0};
     for (int k = 0; k < npts; ++k) {
-        if (P[2 * k] < -5000.f || P[2 * k + 1] < -5000.f) continue;
-        ++nv;
-        for (int d = 0; d < 3; ++d) Mc[d] += V3[k / per][d];
+        if (!pt_valid(q, k)) continue;
+        for (int d = 0; d < 3; ++d) Mc[d] += q.V3[k / per][d];
     }
-    o[35] = nv;
-    if (nv < 4) { o[0] = -1; return; }
-    if (nv < 6) { o[0] = -2; return; }  // EPnP branch of the reference (cuboid_pnp_solver.py:162-163): pnp_rare_kernel
+    if (nv < 6) {  // < 4: no pose; 4-5: EPnP branch of the reference (cuboid_pnp_solver.py:162-163), pnp_rare_kernel
+        if (sub == 0) { o[35] = nv; o[0] = nv < 4 ? -1 : -2; }
+        return;
+    }
     for (int d = 0; d < 3; ++d) Mc[d] /= nv;
     // planarity test of cvFindExtrinsicCameraParams2: second/third singular value of the 3x3 scatter
     {
         double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < npts; ++k) {
-            if (P[2 * k] < -5000.f || P[2 * k + 1] < -5000.f) continue;
+            if (!pt_valid(q, k)) continue;
             double dd[3];
-            for (int d = 0; d < 3; ++d) dd[d] = V3[k / per][d] - Mc[d];
+            for (int d = 0; d < 3; ++d) dd[d] = q.V3[k / per][d] - Mc[d];
             for (int a = 0; a < 3; ++a)
                 for (int b = 0; b < 3; ++b) S[a * 3 + b] += dd[a] * dd[b];
         }
         // eigenvalues of symmetric 3x3 by Jacobi
         for (int sw = 0; sw < 20; ++sw)
-            for (int p = 0; p < 2; ++p)
-                for (int q = p + 1; q < 3; ++q) {
-                    const double apq = S[p * 3 + q];
+            for (int pp = 0; pp < 2; ++pp)
+                for (int qq = pp + 1; qq < 3; ++qq) {
+                    const double apq = S[pp * 3 + qq];
                     if (fabs(apq) < 1e-300) continue;
-                    const double tau = (S[q * 3 + q] - S[p * 3 + p]) / (2 * apq);
+                    const double tau = (S[qq * 3 + qq] - S[pp * 3 + pp]) / (2 * apq);
                     const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1 + tau * tau));
-                    const double c = 1 / sqrt(1 + t * t), s = t * c;
-                    for (int k = 0; k < 3; ++k) { const double a = S[k * 3 + p], b = S[k * 3 + q]; S[k * 3 + p] = c * a - s * b; S[k * 3 + q] = s * a + c * b; }
-                    for (int k = 0; k < 3; ++k) { const double a = S[p * 3 + k], b = S[q * 3 + k]; S[p * 3 + k] = c * a - s * b; S[q * 3 + k] = s * a + c * b; }
+                    const double c = 1 / sqrt(1 + t * t), sn = t * c;
+                    for (int k = 0; k < 3; ++k) { const double a = S[k * 3 + pp], bb = S[k * 3 + qq]; S[k * 3 + pp] = c * a - sn * bb; S[k * 3 + qq] = sn * a + c * bb; }
+                    for (int k = 0; k < 3; ++k) { const double a = S[pp * 3 + k], bb = S[qq * 3 + k]; S[pp * 3 + k] = c * a - sn * bb; S[qq * 3 + k] = sn * a + c * bb; }
                 }
         double e0 = S[0], e1 = S[4], e2 = S[8], tmp;
         if (e0 < e1) { tmp = e0; e0 = e1; e1 = tmp; }
         if (e1 < e2) { tmp = e1; e1 = e2; e2 = tmp; }
         if (e0 < e1) { tmp = e0; e0 = e1; e1 = tmp; }
-        if (e2 / e1 < 1e-3) { o[0] = -3; return; }  // planar: homography initialisation, pnp_rare_kernel
+        if (e2 / e1 < 1e-3) {  // planar: homography initialisation, pnp_rare_kernel
+            if (sub == 0) { o[35] = nv; o[0] = -3; }
+            return;
+        }
     }
-    // ---- DLT ----  L^T L accumulated as a packed lower triangle in registers
+    // ---- DLT ----  L^T L as a packed lower triangle in registers: this lane's point, then summed over the group
     double As[78];
-#pragma unroll
-    for (int k = 0; k < 78; ++k) As[k] = 0.0;
-    for (int k = 0; k < npts; ++k) {
-        if (P[2 * k] < -5000.f || P[2 * k + 1] < -5000.f) continue;
-        const double* M = V3[k / per];
-        const double x = -((double)P[2 * k] - cam.cx) / cam.fx, y = -((double)P[2 * k + 1] - cam.cy) / cam.fy;
-        const double r0[12] = {M[0], M[1], M[2], 1, 0, 0, 0, 0, x * M[0], x * M[1], x * M[2], x};
-        const double r1[12] = {0, 0, 0, 0, M[0], M[1], M[2], 1, y * M[0], y * M[1], y * M[2], y};
+    {
+        const bool pv = sub < npts && pt_valid(q, sub);
+        const double* M = q.V3[(sub < npts ? sub : 0) / per];
+        const double x = pv ? -((double)P[2 * sub] - cam.cx) / cam.fx : 0.0, y = pv ? -((double)P[2 * sub + 1] - cam.cy) / cam.fy : 0.0;
+        const double w = pv ? 1.0 : 0.0;  // an invalid / absent point contributes two zero rows
+        const double r0[12] = {w * M[0], w * M[1], w * M[2], w, 0, 0, 0, 0, x * M[0], x * M[1], x * M[2], x};
+        const double r1[12] = {0, 0, 0, 0, w * M[0], w * M[1], w * M[2], w, y * M[0], y * M[1], y * M[2], y};
 #pragma unroll
         for (int a = 0; a < 12; ++a)
 #pragma unroll
-            for (int b = 0; b <= a; ++b) As[TRI(a, b)] += r0[a] * r0[b] + r1[a] * r1[b];
+            for (int b = 0; b <= a; ++b) As[TRI(a, b)] = gsum16(r0[a] * r0[b] + r1[a] * r1[b]);
     }
     double ev[12];
     smallest_eigvec<12>(As, ev);
@@ -449,7 +569,10 @@ __global__ __launch_bounds__(64) void pnp_kernel(const float* __restrict__ pts, 
     double sc = 0;
     for (int k = 0; k < 9; ++k) sc += RR[k] * RR[k];
     sc = sqrt(sc);
-    if (!(sc > DBL_EPS)) { o[0] = 0; return; }
+    if (!(sc > DBL_EPS)) {
+        if (sub == 0) { o[35] = nv; o[0] = 0; }
+        return;
+    }
     double R0[9];
     polar3(RR, R0);
     const double f = sqrt(3.0) / sc;  // |R|_F of an orthonormal matrix is sqrt(3)
@@ -457,10 +580,9 @@ __global__ __launch_bounds__(64) void pnp_kernel(const float* __restrict__ pts, 
     rot_to_rvec(R0, param);
     param[3] = tt[0] * f; param[4] = tt[1] * f; param[5] = tt[2] * f;
 
-    Problem q;
-    load_problem(q, pts, scale, camp, i, npts);
-    const int iters = lm_refine(q, param);
-    write_pose(q, param, iters, o);
+    const int iters = lm_refine16(q, param, sub);
+    if (sub == 0) o[35] = nv;
+    write_pose16(q, param, iters, o, sub);
 }
 
 
@@ -869,7 +991,7 @@ int cp_launch_pnp(hipStream_t s, const float* pts, const float* scale, const dou
                   void* ws) {
     if (N < 1) return CP_OK;
     if (npts != 8 && npts != 16) return CP_ERR_INVALID;
-    hipLaunchKernelGGL(pnp_kernel, dim3((N + 63) / 64), dim3(64), 0, s, pts, scale, cam, N, npts, out, (double*)ws);
+    hipLaunchKernelGGL(pnp_kernel, dim3((N * 16 + 63) / 64), dim3(64), 0, s, pts, scale, cam, N, npts, out, (double*)ws);
     // detections the common-case kernel marked -2 (4-5 valid points) / -3 (planar model); a no-op otherwise
     hipLaunchKernelGGL(pnp_rare_kernel, dim3((N + RARE_LANES - 1) / RARE_LANES), dim3(64), 0, s, pts, scale, cam, N, npts,
                        out);
