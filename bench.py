@@ -367,6 +367,19 @@ def main():
                     "dominant_kernel": {"kernel": n2, "tflops": round(r2["flops"] / (r2["ms"] * 1e-3) / 1e12, 1),
                                         "avg_launch_us": round(r2["ms"] * 1e3 / r2["launches"], 2)}}
             cfg2.update(north_star_figures(roles2, sampled2, 64, args.precision))
+            if not args.no_latency:  # per-frame latency of the whole chain at batch 1: network graph + post-process + PnP
+                x1 = p2.x[:1].contiguous()
+                for _ in range(3):
+                    p2.step(x1, graph=True)
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(50):
+                    t1 = time.perf_counter()
+                    p2.step(x1, graph=True)
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                ts.sort()
+                cfg2["p50_frame_ms_batch1"] = round(ts[len(ts) // 2], 3)
             del p2
             torch.cuda.empty_cache()
         cpu = None
