@@ -30,6 +30,22 @@ def test_library_exports_every_declared_symbol(built):
     assert b"gfx950" in built.cp_version()
 
 
+def test_kernel_variant_and_role_tables_match_the_header(built):
+    """CP_NUM_KERNEL_VARIANTS / CP_NUM_ROLES of the header, the name tables inside the library and the counts the ctypes
+    binding sizes its profile buffers with must agree (a new kernel variant touches all three)."""
+    header = open(os.path.join(REPO, "include", "centerpose_hip.h")).read()
+    nv = int(re.search(r"#define\s+CP_NUM_KERNEL_VARIANTS\s+(\d+)", header).group(1))
+    nr = int(re.search(r"#define\s+CP_NUM_ROLES\s+(\d+)", header).group(1))
+    names = [built.cp_kernel_variant_name(v).decode() for v in range(nv)]
+    assert all(n and n != "?" for n in names) and len(set(names)) == nv, names
+    assert built.cp_kernel_variant_name(nv).decode() == "?"
+    roles = [built.cp_role_name(r).decode() for r in range(nr)]
+    assert all(n and n != "?" for n in roles) and len(set(roles)) == nr, roles
+    src = open(os.path.join(REPO, "centerpose_amd", "hip.py")).read()
+    assert int(re.search(r"nv = (\d+)\s+# CP_NUM_KERNEL_VARIANTS", src).group(1)) == nv
+    assert int(re.search(r"nr = (\d+)\s+# CP_NUM_ROLES", src).group(1)) == nr
+
+
 def test_argument_validation_without_gpu(built):
     import ctypes
 
