@@ -287,6 +287,11 @@ int cp_launch_decode(hipStream_t s, int B, int J, int H, int W, float* hm, const
                      const float* hp_offset, const float* tracking, const float* tracking_hp, int K, int rep_mode,
                      int fit_gaussian, float balance, int legacy_bool_mask, int apply_sigmoid, float* det, void* ws);
 
+// ---- generic DCNv2 forward on the reference's NCHW layouts (dcn_generic.hip): any C / kernel / stride / dilation / dg ----
+int cp_launch_dcn_generic(hipStream_t s, const float* x, const float* w, const float* bias, const float* offset,
+                          const float* mask, float* out, int B, int C, int H, int W, int Co, int Ho, int Wo, int kh, int kw,
+                          int sh, int sw, int ph, int pw, int dh, int dw, int dg);
+
 // ---- batched PnP (pnp.hip) ----
 #define CP_PNP_STRIDE 40
 size_t cp_pnp_ws_bytes(int N);

@@ -1340,7 +1340,10 @@ int forward_impl(cp_model* m, hipStream_t stream, int B, int H, int W, const flo
 // ============================================ C ABI ==============================================
 extern "C" {
 
-const char* cp_version(void) { return "centerpose_hip 0.2.0 (gfx950; f32 and split-f16 MFMA)"; }
+const char* cp_version(void) { return "centerpose_hip 0.3.0 (gfx950; f32 and split-f16 MFMA)"; }
+int cp_abi_version(void) { return CP_ABI_VERSION; }
+int cp_num_kernel_variants(void) { return CP_NUM_KERNEL_VARIANTS; }
+int cp_num_roles(void) { return CP_NUM_ROLES; }
 const char* cp_last_error(void) { return g_err.c_str(); }
 
 int cp_model_create(const char* arch, int tracking_task, int num_heads, const char* const* head_names,
@@ -1821,12 +1824,22 @@ extern "C" int cp_dcnv2_forward(cp_stream_t stream, const float* input, const fl
                                 int deformable_group, void* workspace, size_t workspace_bytes) {
     if (!input || !weight || !bias || !offset || !mask || !output || !workspace)
         return fail(CP_ERR_INVALID, "null argument");
-    if (kh != 3 || kw != 3 || sh != 1 || sw != 1 || ph != 1 || pw != 1 || dh != 1 || dw != 1 || deformable_group != 1)
-        return fail(CP_ERR_INVALID, "only 3x3 / stride 1 / pad 1 / dilation 1 / deformable_group 1 is supported");
-    if (C % 16 != 0) return fail(CP_ERR_INVALID, "C must be a multiple of 16");
-    if (cp_conv_tile_n(Co) < 64) return fail(CP_ERR_INVALID, "Co must be > 32");
-    if (workspace_bytes < cp_dcnv2_workspace_bytes(B, C, H, W, Co)) return fail(CP_ERR_INVALID, "workspace too small");
+    if (B < 1 || C < 1 || H < 1 || W < 1 || Co < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1 || ph < 0 || pw < 0 || dh < 1 ||
+        dw < 1 || deformable_group < 1 || C % deformable_group != 0)
+        return fail(CP_ERR_INVALID, "dcn_v2_forward: bad shape argument (C must be divisible by deformable_group)");
     hipStream_t s = (hipStream_t)stream;
+    const bool fast = kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 &&
+                      deformable_group == 1 && C % 16 == 0 && cp_conv_tile_n(Co) >= 64 && !(g_dbg & 8388608);
+    if (!fast) {
+        // everything CenterPose does not use (other kernels / strides / dilations, deformable groups, tiny channel
+        // counts): the generic float32 kernel on the reference's own layouts, no workspace
+        const int Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1, Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
+        if (Ho < 1 || Wo < 1) return fail(CP_ERR_INVALID, "dcn_v2_forward: empty output");
+        const int rc = cp_launch_dcn_generic(s, input, weight, bias, offset, mask, output, B, C, H, W, Co, Ho, Wo, kh, kw, sh,
+                                             sw, ph, pw, dh, dw, deformable_group);
+        return rc == CP_OK ? CP_OK : fail(rc, "dcn_v2_forward: generic kernel launch failed");
+    }
+    if (workspace_bytes < cp_dcnv2_workspace_bytes(B, C, H, W, Co)) return fail(CP_ERR_INVALID, "workspace too small");
     const size_t px = (size_t)B * H * W;
     const int cpad = (int)align_up((size_t)Co, cp_conv_tile_n(Co));
     char* w8 = (char*)workspace;

@@ -431,11 +431,15 @@ __global__ void preprocess_kernel(const unsigned char* __restrict__ img, int H, 
 // cv2.resize(img, (OW, OH)) (INTER_LINEAR) of an 8-bit HWC frame, OpenCV's fixed-point form (resize.cpp: coefficients
 // with 11 fractional bits, horizontal pass in int32, vertical ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
 // the `scale != 1` branch of pre_process (base_detector.py:128), multi-scale testing.
+// Coefficient set-up in OpenCV's order (resize.cpp, the INTER_LINEAR branch of cv::resize): scale_x = 1. / inv_scale_x with
+// inv_scale_x = (double)dsize / ssize; fx = (float)((dx + 0.5) * scale_x - 0.5) is rounded to float BEFORE cvFloor and the
+// subtraction (fx -= sx, in float), then clamped at both borders.  PARITY UNPINNED until checked against a real cv2.
 __device__ __forceinline__ void resize_coef(int d, int dst, int src, int* s0, int* s1, int* a0, int* a1) {
-    const double scale = (double)src / (double)dst;
-    double f = ((double)d + 0.5) * scale - 0.5;
-    int s = (int)floor(f);
-    float ff = (float)(f - (double)s);
+    const double inv_scale = (double)dst / (double)src;
+    const double scale = 1.0 / inv_scale;
+    float ff = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(ff);
+    ff -= (float)s;
     if (s < 0) { ff = 0.f; s = 0; }
     if (s >= src - 1) { ff = 0.f; s = src - 1; }
     *s0 = s;

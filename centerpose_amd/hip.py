@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CENTERPOSE_HIP_LIB") or os.path.join(_HERE, "libcenterpose_hip.so")
 
 _lib = None
+ABI_VERSION = 3  # CP_ABI_VERSION of include/centerpose_hip.h this binding was written against
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -39,6 +40,9 @@ def lib():
     L = ctypes.CDLL(LIB_PATH)
     _sig(L.cp_version, c_char_p)
     _sig(L.cp_last_error, c_char_p)
+    _sig(L.cp_abi_version, c_int)
+    _sig(L.cp_num_kernel_variants, c_int)
+    _sig(L.cp_num_roles, c_int)
     _sig(L.cp_dcnv2_workspace_bytes, c_size_t, c_int, c_int, c_int, c_int, c_int)
     _sig(L.cp_dcnv2_forward, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
          *([c_int] * 14), c_void_p, c_size_t)
@@ -80,6 +84,9 @@ def lib():
     _sig(L.cp_pnp_from_post_workspace_bytes, c_size_t, c_int, c_int)
     _sig(L.cp_pnp_from_post, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t)
     _sig(L.cp_pnp_solve, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t)
+    if L.cp_abi_version() != ABI_VERSION:
+        raise RuntimeError("centerpose_amd: %s has ABI version %d, this binding was written for %d (rebuild the library)"
+                           % (LIB_PATH, L.cp_abi_version(), ABI_VERSION))
     _lib = L
     return L
 
@@ -91,7 +98,8 @@ def exported_symbols():
             "cp_model_forward", "cp_model_forward_tap", "cp_conv2d_workspace_bytes", "cp_conv2d_nhwc",
             "cp_decode_workspace_bytes", "cp_decode", "cp_pnp_workspace_bytes", "cp_pnp_solve", "cp_model_profile", "cp_model_profile_read",
             "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug", "cp_preprocess", "cp_postprocess_workspace_bytes", "cp_postprocess", "cp_render_gaussians",
-            "cp_model_profile_roles", "cp_role_name", "cp_pnp_from_post_workspace_bytes", "cp_pnp_from_post", "cp_resize_u8"]
+            "cp_model_profile_roles", "cp_role_name", "cp_pnp_from_post_workspace_bytes", "cp_pnp_from_post", "cp_resize_u8",
+            "cp_abi_version", "cp_num_kernel_variants", "cp_num_roles"]
 
 
 def _check(rc, what):
@@ -120,7 +128,16 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh
     input, weight, bias, offset, mask = map(_dev, (input, weight, bias, offset, mask))
     B, C, H, W = input.shape
     Co = weight.shape[0]
-    out = torch.empty(B, Co, H, W, device=input.device, dtype=torch.float32)
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1  # dcn_v2_cuda.cu:75-76
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    if Ho < 1 or Wo < 1:
+        raise RuntimeError("dcn_v2_forward: empty output")
+    for name, t, shape in (("weight", weight, (Co, C, kh, kw)), ("bias", bias, (Co,)),
+                           ("offset", offset, (B, deformable_group * 2 * kh * kw, Ho, Wo)),
+                           ("mask", mask, (B, deformable_group * kh * kw, Ho, Wo))):
+        if tuple(t.shape) != shape:  # the reference's AT_ASSERTM shape checks (dcn_v2_cuda.cu:60-66)
+            raise RuntimeError("dcn_v2_forward: %s has shape %s, expected %s" % (name, tuple(t.shape), shape))
+    out = torch.empty(B, Co, Ho, Wo, device=input.device, dtype=torch.float32)
     nbytes = L.cp_dcnv2_workspace_bytes(B, C, H, W, Co)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=input.device)
     rc = L.cp_dcnv2_forward(_stream(), _ptr(input), _ptr(weight), _ptr(bias), _ptr(offset), _ptr(mask), _ptr(out),
@@ -410,7 +427,7 @@ class HipModel(object):
 
     def profile_read(self):
         """-> {kernel name: dict(launches, ms, flops, bytes)} accumulated since the last read."""
-        nv = 36  # CP_NUM_KERNEL_VARIANTS (include/centerpose_hip.h)
+        nv = lib().cp_num_kernel_variants()  # sized by the library, not by a copy of CP_NUM_KERNEL_VARIANTS
         buf = (ctypes.c_double * (nv * 4))()
         _check(lib().cp_model_profile_read(self._h, buf, nv), "cp_model_profile_read")
         out = OrderedDict()
@@ -422,7 +439,7 @@ class HipModel(object):
 
     def profile_roles(self):
         """-> {role: dict(launches, ms, flops, bytes)} of the launches drained by the last profile_read()."""
-        nr = 9  # CP_NUM_ROLES
+        nr = lib().cp_num_roles()
         buf = (ctypes.c_double * (nr * 4))()
         _check(lib().cp_model_profile_roles(self._h, buf, nr), "cp_model_profile_roles")
         out = OrderedDict()

@@ -32,8 +32,15 @@ typedef struct cp_model cp_model;
 #define CP_ERR_ALLOC (-3)
 #define CP_ERR_STATE (-4)
 
-/* Library / device info.  cp_version() returns a static string. */
+/* Library / device info.  cp_version() returns a static string.
+ * CP_ABI_VERSION counts incompatible changes of this header; cp_abi_version() returns the value the library was built
+ * with, so a caller compiled against another revision can refuse to run instead of passing arguments with a stale
+ * meaning.  History: 1 = round-1 header; 2 = cp_preprocess takes the FORWARD 2x3 affine as double[6] and inverts it
+ * itself (round 1: the inverse as float[6]); 3 = cp_dcnv2_forward accepts every shape of the reference op (generic
+ * kernel), cp_num_kernel_variants() / cp_num_roles() size the profile buffers. */
+#define CP_ABI_VERSION 3
 const char* cp_version(void);
+int cp_abi_version(void);
 const char* cp_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -43,9 +50,15 @@ const char* cp_last_error(void);
  * Same tensor layouts as the reference (all contiguous NCHW float32):
  *   input [B,C,H,W], weight [Co,C,kh,kw], bias [Co], offset [B,dg*2*kh*kw,Ho,Wo] ((dh,dw)
  *   interleaved per tap), mask [B,dg*kh*kw,Ho,Wo], output [B,Co,Ho,Wo].
- * Supported (what CenterPose uses, pose_dla_dcn.py:384): kh=kw=3, stride 1, pad 1, dilation 1,
- * deformable_group 1, C % 16 == 0.  Anything else returns CP_ERR_INVALID.
- * `workspace` must hold cp_dcnv2_workspace_bytes(...) bytes (NHWC staging + packed weights).
+ * Ho = (H + 2*ph - (dh*(kh-1)+1)) / sh + 1 (Wo likewise), as dcn_v2_cuda.cu:75-76.
+ * Every shape the reference op accepts is accepted (C % deformable_group == 0).  Two paths, same results:
+ *   - what CenterPose uses (pose_dla_dcn.py:384: kh=kw=3, stride 1, pad 1, dilation 1, deformable_group 1,
+ *     C % 16 == 0, Co > 32): the fused gather + matrix-core kernels (dcn16p.hip / dcn16.hip / igemm.hip);
+ *   - anything else (the reference's own self-checks: DCNv2/testcpu.py:32-67 with 2 channels, :169-180 with
+ *     deformable_group 2; other kernel sizes / strides / dilations): a generic float32 kernel (dcn_generic.hip),
+ *     correct but not tuned.
+ * `workspace` must hold cp_dcnv2_workspace_bytes(...) bytes (NHWC staging + packed weights; the generic path does not
+ * touch it).
  * ------------------------------------------------------------------------------------------ */
 size_t cp_dcnv2_workspace_bytes(int B, int C, int H, int W, int Co);
 int cp_dcnv2_forward(cp_stream_t stream, const float* input, const float* weight, const float* bias,
@@ -125,6 +138,7 @@ int cp_model_set_precision(cp_model* m, int precision);
  * algorithmic FLOPs (2*M*Cout*KH*KW*Cin), total algorithmic bytes (input + output + weights
  * [+ offsets/mask] [+ residual], float32)} per kernel variant v in [0, CP_NUM_KERNEL_VARIANTS). */
 #define CP_NUM_KERNEL_VARIANTS 36
+int cp_num_kernel_variants(void); /* the value the LIBRARY was built with: size cp_model_profile_read's buffer from it */
 int cp_model_profile(cp_model* m, int enable);
 int cp_model_profile_read(cp_model* m, double* out, int num_variants);
 const char* cp_kernel_variant_name(int v);
@@ -141,6 +155,7 @@ const char* cp_kernel_variant_name(int v);
 #define CP_ROLE_LOWC 7        /* stem / level0 / level1 direct kernels (f16x3 mode) */
 #define CP_ROLE_DECODE 8      /* cp_model_detect's decode launch (both kernels) */
 #define CP_NUM_ROLES 9
+int cp_num_roles(void);
 int cp_model_profile_roles(cp_model* m, double* out, int num_roles);
 const char* cp_role_name(int role);
 
@@ -238,7 +253,9 @@ int cp_render_gaussians(cp_stream_t stream, const double* recs, int N, float* ou
  *   -> `cv2.solvePnPGeneric(SOLVEPNP_ITERATIVE | SOLVEPNP_EPNP)` + `cv2.projectPoints`
  *   (utils/pnp/cuboid_pnp_shell.py:11-24, utils/pnp/cuboid_pnp_solver.py:141-239,
  *   detectors/base_detector.py:547-654).
- *   pts   [N, npts, 2] float32 image points, npts = 8 (rep_mode 0/3/4: `kps`) or 16 (rep_mode 1:
+ *   pts   [N, npts, 2] float32 image points (the reference hands cv2 float64 values, cuboid_pnp_solver.py:153; the
+ *         float32 boundary perturbs a coordinate of a few hundred pixels by <= 3e-5 px, far inside the 1 degree / 1 %
+ *         pose tolerance; all arithmetic after the load is float64), npts = 8 (rep_mode 0/3/4: `kps`) or 16 (rep_mode 1:
  *         displacement/heat-map pairs interleaved per vertex, base_detector.py:558-566); a point
  *         with x or y < -5000 is invalid (cuboid_pnp_solver.py:145)
  *   scale [N, 3] float32 relative cuboid size (divided by its y component inside, shell :12)
@@ -265,6 +282,9 @@ int cp_pnp_solve(cp_stream_t stream, const float* pts, const float* scale, const
  *   post / count: outputs of cp_postprocess ([B,K,CP_POST_STRIDE] float64, [B] int32).
  *   rep_mode: 0 / 3 / 4 -> 8 points from `kps`; 1 -> 16 points, (kps_displacement_mean, kps_heatmap_mean) per vertex.
  *   cam: DEVICE float64 [B,4] (fx, fy, cx, cy) per image.
+ *   The assembly casts the float64 record fields to cp_pnp_solve's float32 `pts` / `scale` inputs (same rounding as the
+ *   host path, which builds float32 arrays from the same float64 values): row (b,k) is bit-identical to cp_pnp_solve on
+ *   points assembled on the host by the reference rule (tests/test_gpu_pose_chain.py).
  *   out: DEVICE float64 [B,K,CP_PNP_STRIDE]; row (b,k) as cp_pnp_solve for k < count[b], status -1 beyond.
  * No host synchronisation and no host-visible count: the whole chain backbone -> decode -> post-process -> PnP is a
  * fixed launch sequence. */

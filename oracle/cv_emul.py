@@ -66,15 +66,18 @@ def warp_affine_u8(img, M, dsize):
 
 
 def _resize_axis(dst, src):
-    scale = src / float(dst)
-    f = (np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5
+    """Coefficients of one axis in OpenCV's order of operations (resize.cpp, INTER_LINEAR): scale = 1. / (dst / src) in
+    double, fx = (float)((d + 0.5) * scale - 0.5) rounded to float BEFORE cvFloor, fx -= sx in float, border clamps,
+    then cvRound(coef * 2048).  PARITY UNPINNED (cv2 absent): restated from the published source, not run against it."""
+    scale = 1.0 / (float(dst) / float(src))
+    f = ((np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
     s = np.floor(f).astype(np.int64)
-    f = (f - s).astype(np.float32)
+    f = (f - s.astype(np.float32)).astype(np.float32)
     lo = s < 0
     f[lo], s[lo] = 0, 0
     hi = s >= src - 1
     f[hi], s[hi] = 0, src - 1
-    a0 = np.rint((1.0 - f).astype(np.float32) * np.float32(2048)).astype(np.int64)
+    a0 = np.rint((np.float32(1.0) - f).astype(np.float32) * np.float32(2048)).astype(np.int64)
     a1 = np.rint(f * np.float32(2048)).astype(np.int64)
     return s, np.minimum(s + 1, src - 1), a0, a1
 

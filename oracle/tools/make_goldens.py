@@ -10,6 +10,8 @@ and the HIP path are both checked against them.
                             (cfg: dla, dlav1, dla_track, dlav1_track, hourglass)
   dcn_ref.npz               reference CPU im2col + GEMM on a random-offset case + the reference's
                             own known-answer test (DCNv2/testcpu.py:32-67, check_zero_offset)
+  dcn_generic_ref.npz       the same reference binary on DCN_GENERIC_SHAPES (deformable groups, strides,
+                            dilations, other kernel sizes)
   decode_<cfg>.npz          reference ``object_pose_decode`` (Inference=True) on seeded heads:
                             as imported under torch>=1.2 ("bool"), and with torch<=1.1 comparison
                             semantics emulated at run time on the unmodified function ("uint8")
@@ -89,6 +91,31 @@ def dcn_case(seed=5, B=2, C=16, Co=64, H=12, W=10):
     off = torch.randn(B, 18, H, W, generator=g) * 2.0
     mask = torch.rand(B, 9, H, W, generator=g)
     return x, w, b, off, mask
+
+
+# (B, C, Co, H, W, kh, kw, sh, sw, ph, pw, dh, dw, dg): shapes of `_ext.dcn_v2_forward` beyond CenterPose's own use
+DCN_GENERIC_SHAPES = [
+    (2, 2, 2, 4, 4, 3, 3, 1, 1, 1, 1, 1, 1, 1),         # the reference KAT's shape (testcpu.py:17-20) with random offsets
+    (1, 6, 5, 9, 11, 3, 3, 1, 1, 1, 1, 1, 1, 3),        # three deformable groups, odd sizes
+    (2, 8, 70, 13, 10, 5, 3, 2, 1, 2, 1, 1, 1, 2),      # 5x3 kernel, stride (2,1), more than 64 output channels
+    (1, 12, 33, 16, 16, 3, 3, 2, 2, 2, 2, 2, 2, 4),     # dilation 2, stride 2
+    (1, 4, 3, 7, 7, 1, 1, 1, 1, 0, 0, 1, 1, 1),         # 1x1 kernel, no padding
+    (1, 32, 64, 8, 8, 3, 3, 1, 1, 1, 1, 1, 1, 2),       # fast-path channel counts but deformable_group 2 (example_dconv)
+]
+
+
+def dcn_generic_case(i):
+    """Seeded tensors of DCN_GENERIC_SHAPES[i] -> (x, w, b, offset, mask, args)."""
+    B, C, Co, H, W, kh, kw, sh, sw, ph, pw, dh, dw, dg = DCN_GENERIC_SHAPES[i]
+    g = torch.Generator().manual_seed(C * 100 + Co)
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Co, C, kh, kw, generator=g) / (C * kh * kw) ** 0.5
+    b = torch.randn(Co, generator=g)
+    off = torch.randn(B, dg * 2 * kh * kw, Ho, Wo, generator=g) * 2.0
+    mask = torch.rand(B, dg * kh * kw, Ho, Wo, generator=g)
+    return x, w, b, off, mask, (kh, kw, sh, sw, ph, pw, dh, dw, dg)
 
 
 class HostOpt:
@@ -314,6 +341,13 @@ def main():
     assert float((yi * 2 - xi).abs().max()) < 1e-10, "reference KAT failed?!"
     np.savez_compressed(os.path.join(GOLD, "dcn_ref.npz"), y=y.numpy(), kat_in=xi.numpy(), kat_out=yi.numpy())
     print("dcn", tuple(y.shape))
+    # generic shapes (deformable groups, strides, dilations, kernel sizes): the reference's compiled CPU im2col + GEMM
+    gen = {}
+    for i in range(len(DCN_GENERIC_SHAPES)):
+        gx, gw, gb, goff, gmask, gargs = dcn_generic_case(i)
+        gen["y%d" % i] = odcn.dcn_v2_forward(gx, gw, gb, goff, gmask, *gargs, kind="reference").numpy()
+    np.savez_compressed(os.path.join(GOLD, "dcn_generic_ref.npz"), **gen)
+    print("dcn generic", len(gen))
 
     for tr, sem, B in ((False, "bool", 2), (False, "uint8", 2), (True, "uint8", 1)):
         d = odec.synth_heads(B, seed=317, tracking=tr)

@@ -56,7 +56,8 @@ def test_igemm_conv_vs_torch(device, B, H, W, Cin, Cout, k, s, p, act, res):
 
 def test_dcn_reference_known_answer_and_golden(device):
     gold = np.load(os.path.join(GOLD, "dcn_ref.npz"))
-    # the reference's own KAT (DCNv2/testcpu.py:32-67) needs C % 16 == 0 here: identity weights on 16 channels
+    # the reference's KAT pattern (DCNv2/testcpu.py:32-67) on the fast path's channel counts: identity weights on 16 channels
+    # (the KAT's own 2-channel shape runs below, test_dcn_reference_selfchecks_run_unmodified_through_ext)
     x = torch.randn(2, 16, 4, 4, generator=torch.Generator().manual_seed(1))
     w = torch.zeros(64, 16, 3, 3)
     for c in range(16):
@@ -86,12 +87,86 @@ def test_dcn_vs_oracle(device, B, C, Co, H, W, std):
     torch.testing.assert_close(out, ref, rtol=0, atol=2e-5 * float(ref.abs().max()))
 
 
-def test_dcn_rejects_unsupported(device):
-    x = torch.zeros(1, 16, 4, 4, device=device)
-    with pytest.raises(RuntimeError):
-        hip.dcn_v2_forward(x, torch.zeros(64, 16, 3, 3, device=device), torch.zeros(64, device=device),
-                           torch.zeros(1, 36, 4, 4, device=device), torch.zeros(1, 18, 4, 4, device=device),
-                           3, 3, 1, 1, 1, 1, 1, 1, 2)  # deformable_group 2
+def test_dcn_reference_selfchecks_run_unmodified_through_ext(device):
+    """The reference's own DCNv2 self-checks through the `_ext` shim with their ORIGINAL shapes: `check_zero_offset`
+    (DCNv2/testcpu.py:17-67: N, inC, outC, inH, inW = 2, 2, 2, 4, 4, identity weights, zero offsets, mask 0.5 ->
+    `(input - 2 * output).abs().max() < 1e-10`) and `example_dconv` (:169-180: DCN(64, 64, 3x3, deformable_groups=2)
+    on [2, 64, 128, 128]) -- neither fits the CenterPose-only fast path (C % 16 / dg 1); the generic kernel takes them."""
+    from centerpose_amd.lib.models.networks.DCNv2.dcn_v2 import DCN, DCNv2
+
+    g = torch.Generator().manual_seed(0)
+    N, inC, outC, inH, inW, dg = 2, 2, 2, 4, 4, 1
+    dcn = DCNv2(inC, outC, (3, 3), stride=1, padding=1, dilation=1, deformable_groups=dg).to(device)
+    with torch.no_grad():   # conv_identify (testcpu.py:23-30)
+        dcn.weight.zero_()
+        dcn.bias.zero_()
+        for c in range(inC):
+            dcn.weight[c, c, 1, 1] = 1.0
+    x = torch.randn(N, inC, inH, inW, generator=g)
+    offset = torch.zeros(N, dg * 18, inH, inW)          # zeroed conv_offset (weights and bias 0)
+    mask = torch.sigmoid(torch.zeros(N, dg * 9, inH, inW))
+    out = dcn(x.to(device), offset.to(device), mask.to(device)).cpu()
+    assert float((x - out * 2).abs().max()) < 1e-10
+    # example_dconv: offsets / masks come from DCN's own conv_offset_mask (given non-zero weights here so that the
+    # deformable groups really differ), reference = the oracle on the same offsets
+    dcn2 = DCN(64, 64, kernel_size=(3, 3), stride=1, padding=1, deformable_groups=2)
+    with torch.no_grad():
+        dcn2.conv_offset_mask.weight.copy_(torch.randn(dcn2.conv_offset_mask.weight.shape, generator=g) * 0.05)
+        dcn2.conv_offset_mask.bias.copy_(torch.randn(54, generator=g) * 0.5)
+        dcn2.bias.copy_(torch.randn(64, generator=g))
+    x = torch.randn(2, 64, 128, 128, generator=g)
+    with torch.no_grad():
+        om = dcn2.conv_offset_mask(x)
+        o1, o2, m = torch.chunk(om, 3, dim=1)
+        off, m = torch.cat((o1, o2), dim=1), torch.sigmoid(m)
+        ref = odcn.dcn_v2_forward(x, dcn2.weight, dcn2.bias, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 2)
+        out = dcn2.to(device)(x.to(device)).cpu()
+    assert out.shape == (2, 64, 128, 128)
+    torch.testing.assert_close(out, ref, rtol=0, atol=3e-5 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("i", range(len(mg.DCN_GENERIC_SHAPES)))
+def test_dcn_generic_shapes_vs_reference_golden(device, i):
+    """Everything `_ext.dcn_v2_forward` accepts beyond CenterPose's own use (dcn_v2.h:9-23) against outputs of the
+    reference's compiled CPU source (tests/golden/dcn_generic_ref.npz) and the oracle port."""
+    gold = np.load(os.path.join(GOLD, "dcn_generic_ref.npz"))["y%d" % i]
+    x, w, b, off, mask, args = mg.dcn_generic_case(i)
+    ref = odcn.dcn_v2_forward(x, w, b, off, mask, *args)
+    out = hip.dcn_v2_forward(*(t.to(device) for t in (x, w, b, off, mask)), *args).cpu()
+    assert out.shape == ref.shape == gold.shape
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    torch.testing.assert_close(out, ref, rtol=0, atol=tol)
+    np.testing.assert_allclose(out.numpy(), gold, rtol=0, atol=tol)
+
+
+def test_dcn_generic_and_fast_path_agree(device):
+    """The same CenterPose-shaped layer through both kernels (cp_set_debug 8388608 forces the generic one)."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 64, 32, 32, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(64, generator=g)
+    off = torch.randn(2, 18, 32, 32, generator=g) * 2.0
+    mask = torch.rand(2, 9, 32, 32, generator=g)
+    t = [v.to(device) for v in (x, w, b, off, mask)]
+    fast = hip.dcn_v2_forward(*t, 3, 3, 1, 1, 1, 1, 1, 1, 1).cpu()
+    hip.lib().cp_set_debug(8388608)
+    try:
+        slow = hip.dcn_v2_forward(*t, 3, 3, 1, 1, 1, 1, 1, 1, 1).cpu()
+    finally:
+        hip.lib().cp_set_debug(0)
+    torch.testing.assert_close(fast, slow, rtol=0, atol=2e-5 * float(slow.abs().max()))
+
+
+def test_dcn_rejects_inconsistent_arguments(device):
+    x = torch.zeros(1, 6, 4, 4, device=device)
+    with pytest.raises(RuntimeError):   # C not divisible by deformable_group
+        hip.dcn_v2_forward(x, torch.zeros(4, 6, 3, 3, device=device), torch.zeros(4, device=device),
+                           torch.zeros(1, 72, 4, 4, device=device), torch.zeros(1, 36, 4, 4, device=device),
+                           3, 3, 1, 1, 1, 1, 1, 1, 4)
+    with pytest.raises(RuntimeError):   # offset tensor of the wrong group count (dcn_v2_cuda.cu:60-66)
+        hip.dcn_v2_forward(x, torch.zeros(4, 6, 3, 3, device=device), torch.zeros(4, device=device),
+                           torch.zeros(1, 18, 4, 4, device=device), torch.zeros(1, 18, 4, 4, device=device),
+                           3, 3, 1, 1, 1, 1, 1, 1, 2)
 
 
 @pytest.fixture(params=["f32", "f16x3"])

@@ -96,6 +96,22 @@ def test_dcn_im2col_port_bit_exact_vs_reference_binary():
     assert torch.equal(a, r)
 
 
+@pytest.mark.parametrize("i", range(len(mg.DCN_GENERIC_SHAPES)))
+def test_dcn_generic_shapes_port_vs_reference(i):
+    """deformable groups / strides / dilations / other kernel sizes: the C port against the golden written by the
+    reference's compiled CPU source (tests/golden/dcn_generic_ref.npz) and, where oracle/_ref exists, bit for bit
+    against that binary's im2col."""
+    gold = np.load(os.path.join(GOLD, "dcn_generic_ref.npz"))
+    x, w, b, off, mask, args = mg.dcn_generic_case(i)
+    y = odcn.dcn_v2_forward(x, w, b, off, mask, *args, kind="port")
+    np.testing.assert_allclose(y.numpy(), gold["y%d" % i], rtol=0, atol=2e-6)
+    if odcn.have_reference():
+        kh, kw, sh, sw, ph, pw, dh, dw, dg = args
+        a, _, _ = odcn.im2col(x, off, mask, kh, kw, ph, pw, sh, sw, dh, dw, dg, kind="port")
+        r, _, _ = odcn.im2col(x, off, mask, kh, kw, ph, pw, sh, sw, dh, dw, dg, kind="reference")
+        assert torch.equal(a, r)
+
+
 def _decode_oracle(d, tracking, sem, rep_mode=1):
     return odec.object_pose_decode(
         d["hm"], d["hps"], wh=d["wh"], kps_displacement_std=d.get("hps_uncertainty"), obj_scale=d["scale"],
