@@ -1,32 +1,40 @@
 #!/usr/bin/env python
-"""bench.py — throughput of the CenterPose inference hot path on MI355X.
+"""bench.py -- throughput of the CenterPose inference hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on): dlav1_34 at
-512x512, batch 32 per GPU, synthetic random frames, seeded random-init weights of that architecture
--> backbone forward (DLA-34 + DCNv2 up-sampling + ConvGRU + GroupNorm heads) -> sigmoid ->
-heat-map decode (NMS, top-100, gathers, keypoint association) on device.  `--workload full` runs
-configs[2] instead (dla_34, batch 64, backbone + decode + batched PnP).
-One "step" = one batch through that chain, inputs resident in HBM before the timed region.
-Images shard by batch across ranks (weak scaling, no data-path collective: the chain is per-image).
+N > 1: the driver launches this file under `python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment); when it is started directly with --gpus N > 1 and no
+WORLD_SIZE, it re-executes itself under torch.distributed.run on 127.0.0.1, so `python bench.py --gpus 8` alone is
+enough.  One rank per GPU over RCCL (backend "nccl"); images shard by batch (weak scaling), and for N > 1 every step ends
+with one all-gather of the detection records over xGMI (BASELINE configs[3]); `n_gpus` is the world size that actually
+ran and `rccl_ranks` is read back from the process group after a real all-gather.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
-  roofline      dominant kernel: algorithmic FLOPs of its launches inside the timed region / their
-                HIP-event durations vs the dense matrix peak of gfx950 (MI355X_MICROARCH.md), plus the
-                figures BASELINE.json's north_star names: roofline.dcn (DCNv2 + offset convolutions
-                against SURVEY 8(d)'s 95.36 MB/img and the 8 TB/s HBM peak), roofline.conv1x1 (MFMA
-                rate of the 1x1 convolutions), roofline.decode (microseconds and GB/s against 0.66 MB/img)
-  configs2      BASELINE configs[2] (dla_34, batch 64, backbone + decode + batched PnP) timed in the
-                same run at N=1, with its own dcn / conv1x1 / decode figures
-  cpu_baseline  the oracle (CPU restatement of the reference graph, oracle/) timed on this host's
-                cores on a bounded sample of the same workload: 1 warm-up image excluded, median over
-                the timed images; "fair" (OpenMP im2col + torch CPU convolutions, all cores) is `value`,
-                "faithful" (the reference's scalar single-thread im2col, as shipped) rides beside it
+Headline workload (top-level line) = BASELINE.json configs[2], the largest single-GPU configuration and the only one
+with the whole north-star chain: dla_34 at 512x512, batch 64 per GPU, synthetic Objectron-shaped frames, seeded
+random-init weights -> backbone (DLA-34 + DCNv2 up-sampling + fused heads) -> sigmoid -> heat-map decode ->
+post-process + soft-NMS -> PnP-input assembly -> batched PnP, everything on the device, no host synchronisation inside
+a step.  One "step" = one batch through that chain, inputs resident in HBM before the timed region.
+
+Extra objects on the ONE JSON line rank 0 prints:
+  roofline      dominant kernel of the timed region: algorithmic FLOPs of its launches / their HIP-event durations
+                (events recorded on the launch stream) vs the dense matrix peak of gfx950, plus the figures
+                BASELINE.json's north_star names: roofline.dcn (DCNv2 + offset convolutions vs SURVEY 8(d)'s
+                95.36 MB/img and the 8 TB/s HBM peak), roofline.conv1x1 (MFMA rate of the 1x1 convolutions),
+                roofline.decode, roofline.pnp
+  legs          (N = 1) short driver-timed runs of the other configurations in the same process: configs1 (BASELINE
+                configs[1]: dlav1_34, batch 32, backbone + decode, with its own roofline), exact_f32 (the headline
+                workload on the exact-f32 MFMA kernels), hourglass / track / track_gru (BASELINE configs[4] in both
+                readings), track_e2e (B concurrent videos through the whole CenterPoseTrack loop
+                incl. the host tracker: host fraction of a step)
+  cpu_baseline  the reference's CPU path for the same workload timed on this host's cores (BASELINE.md section 3:
+                3 warm-ups, >= 10 timed images, median): `value` = the reference as shipped (its own scalar
+                single-thread deformable im2col, oracle/_ref, + torch CPU convolutions), `fair` = the OpenMP port
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,18 +44,29 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from centerpose_amd import distributed as cpd  # noqa: E402
-from centerpose_amd import hip, synth  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, dense f32 matrix
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense f16/bf16 matrix
 PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md, HBM3E
 DCN_MB_PER_IMG = 95.36  # sum over the 16 DCNv2 layers of (Cin + 27 + Cout) * HW * 4 + weights, 512x512
-DCN_GFLOP_PER_IMG = 14.19  # contraction of the 16 DCNv2 layers; + 4.65 for the conv_offset_mask convolutions
 DECODE_MB_PER_IMG = 0.66  # one read of hm + hm_hp, gathers, 47 KB of records
 GFLOP_PER_IMG = {"dlav1_34": 106.85, "dla_34": 85.11, "dla_34_track": 109.68,
                  "dlav1_34_track": 138.7, "hourglass": 603.7}  # BASELINE.md section 2, SURVEY 8(a) M9 / 8(f) N4
-# hourglass: 739.0 GFLOP/img for the reference module minus the 135.3 of the first stack's seven heads, which do not feed
-# model(x)[-1] and are not computed
+# hourglass: 739.2 GFLOP/img for the reference module minus the 135.3 of the first stack's seven heads, which do not
+# feed model(x)[-1] (object_pose.py:135) and are not computed
+DEFAULT_BATCH = {"full": 64, "decode": 32, "track": 16, "track_gru": 16, "hourglass": 8, "track_e2e": 16}
+WORKLOAD_TEXT = {
+    "full": "BASELINE configs[2]: dla_34 512x512 batch=%d/GPU, Objectron-shaped synthetic frames, seeded random-init weights, "
+            "backbone + sigmoid + heat-map decode + post-process/soft-NMS + batched PnP, all on device",
+    "decode": "BASELINE configs[1]: dlav1_34 512x512 batch=%d/GPU, synthetic random frames, backbone + sigmoid + heat-map decode",
+    "track": "dla_34 512x512 batch=%d/GPU, two-frame CenterPoseTrack inputs, Gaussian-moment decode + all-gather of records",
+    "track_gru": "BASELINE configs[4] as the reference can run it (SURVEY 8(f) N4 ii): dlav1_34 512x512 batch=%d/GPU, two-frame "
+                 "inputs + ConvGRU heads, Gaussian-moment decode + all-gather of records",
+    "hourglass": "BASELINE configs[4] as the reference defines it (N4 i): 2-stack hourglass 512x512 batch=%d/GPU, single frame, "
+                 "backbone + decode",
+    "track_e2e": "dla_34 512x512, %d concurrent videos, whole CenterPoseTrack loop per frame (render of the previous tracks, "
+                 "two-frame network, decode, post-process, PnP, Gaussian fusion, Tracker.step on the host)",
+}
 
 
 def parse():
@@ -55,29 +74,42 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="decode", choices=["decode", "full", "track", "track_gru", "hourglass"],
-                    help="decode: configs[1] (default); full: configs[2] dla_34 + PnP; track: dla_34 two-frame "
-                         "CenterPoseTrack inputs + Gaussian-moment decode + RCCL all-gather of detection records; "
-                         "track_gru: the same on dlav1_34 (two-frame input + ConvGRU heads = BASELINE configs[4] as "
-                         "the reference can actually run it, SURVEY 8(f) N4 option ii); hourglass: the 2-stack hourglass "
-                         "backbone, single frame, + decode (configs[4] as the reference DEFINES it, N4 option i)")
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 / 64)")
+    ap.add_argument("--workload", default="full", choices=sorted(WORKLOAD_TEXT),
+                    help="full (default): BASELINE configs[2]; decode: configs[1]; the others: see the `legs` of the default run")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the configuration's)")
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
                     help="f32: exact float32 MFMA; f16x3: split-binary16 MFMA (float32-class accuracy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-configs2", action="store_true", help="skip the BASELINE configs[2] leg of the default run")
+    ap.add_argument("--no-legs", action="store_true", help="skip the nested legs of the default run")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--serial-pnp", action="store_true",
                     help="full: run the PnP solve on the network's stream (A/B against the side-stream default)")
     ap.add_argument("--dbg", type=int, default=0, help="cp_set_debug flags (kernel A/B switches, tuning only)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing rehearsal without a device: stub pipeline, real process group / barriers / all-gather "
+                         "(tests/test_bench_cpu.py runs it with CP_BENCH_BACKEND=gloo, world size 2)")
     return ap.parse_args()
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py <same argv>`."""
+    port = int(os.environ.get("CP_BENCH_PORT", 29500 + os.getpid() % 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
+    return subprocess.call(cmd, env=env)
 
 
 class Pipeline(object):
     """frames -> heads -> detections [-> poses], all on device."""
 
-    def __init__(self, workload, batch, device, seed, precision="f32", serial_pnp=False):
+    def __init__(self, workload, batch, device, seed, precision="f32", serial_pnp=False, gather=False):
+        from centerpose_amd import hip, synth
+
+        self.hip = hip
         self.serial_pnp = serial_pnp
+        self.gather = gather
         self.workload = workload
         self.arch = "dlav1_34" if workload in ("decode", "track_gru") else "hourglass" if workload == "hourglass" else "dla_34"
         self.track = workload in ("track", "track_gru")
@@ -88,6 +120,7 @@ class Pipeline(object):
         self.model = hip.HipModel(self.arch, self.heads, sd, tracking_task=self.track, precision=precision)
         self.extra = {}
         self._stages = {}
+        self.last = None
         if self.track:  # previous frame + rendered previous heat-maps (base_detector.py:150-388)
             g = synth._gen(seed, "pre")
             self.extra = dict(
@@ -100,24 +133,28 @@ class Pipeline(object):
         self.cam = torch.tensor([663.0287679036459, 663.0287679036459, 300.2775065104167, 395.00066121419275],
                                 dtype=torch.float64, device=device).repeat(batch, 1).contiguous()  # demo.py:143-144
         # 512x512 frames, fix_res: c = (256, 256), s = 512 (base_detector.py:110-114) -> inverse affine grid -> image
-        from centerpose_amd.lib.utils.image import get_affine_transform
         import numpy as np
+
+        from centerpose_amd.lib.utils.image import get_affine_transform
+
         m = np.zeros((batch, 8))
         m[:, :6] = get_affine_transform(np.array([256.0, 256.0], np.float32), 512.0, 0, (128, 128), inv=1).reshape(-1)
         m[:, 6] = 512.0 / 128
         self.meta = torch.from_numpy(m).to(device)
 
     def step(self, x=None, graph=False):
+        hip = self.hip
         if x is None:
             x, extra = self.x, self.extra
         else:
             extra = {k: v[: x.shape[0]] for k, v in self.extra.items()}
         if self.workload in ("decode", "hourglass"):
             # backbone + sigmoid + decode in one library call (hipGraph replay when graph=True)
-            return self.model.detect(x, K=100, rep_mode=1, fit_gaussian=False, balance=2.0, graph=graph)[1]
+            det = self.model.detect(x, K=100, rep_mode=1, fit_gaussian=False, balance=2.0, graph=graph)[1]
+            return cpd.allgather_detections(det) if self.gather else det
         if self.workload == "full":
             det = self.model.detect(x, K=100, rep_mode=1, fit_gaussian=False, balance=2.0, graph=graph)[1]
-        elif self.track:
+        else:
             z = self.model(x, sigmoid_hm=True, **extra)
             det = hip.decode_raw(z["hm"], z["hps"], z["wh"], z["hm_hp"], z["hps_uncertainty"], z["scale"],
                                  z["scale_uncertainty"], z["reg"], z["hp_offset"], z["tracking"], z["tracking_hp"],
@@ -131,75 +168,44 @@ class Pipeline(object):
         n = det.shape[0]
         if self.serial_pnp:
             post, cnt = hip.postprocess(det, self.meta[:n], 0.3, nms=True)
-            return det, hip.pnp_from_post(post, cnt, self.cam[:n], rep_mode=1)
-        stage = self._stages.get(n)
-        if stage is None:
-            stage = self._stages[n] = hip.PoseStage(n, det.shape[1], self.device, depth=2)
-        post, cnt, poses, done = stage.submit(det, self.meta[:n], self.cam[:n], 0.3, nms=True, rep_mode=1)
+            poses = hip.pnp_from_post(post, cnt, self.cam[:n], rep_mode=1)
+        else:
+            stage = self._stages.get(n)
+            if stage is None:
+                stage = self._stages[n] = hip.PoseStage(n, det.shape[1], self.device, depth=2)
+            post, cnt, poses, done = stage.submit(det, self.meta[:n], self.cam[:n], 0.3, nms=True, rep_mode=1)
+        self.last = (cnt, poses)
+        if self.gather:  # BASELINE configs[3]: every rank sees every image's detections
+            return cpd.allgather_detections(det), poses
         return det, poses
 
-
-def cpu_baseline(workload, arch, budget_s=40.0, n_fair=10, n_faithful=3):
-    """Oracle (CPU port of the reference graph) on a bounded sample of the same workload: the first
-    image is a warm-up and is not counted, `value` is 1 / median seconds per image."""
-    if workload in ("track", "track_gru", "hourglass"):
-        return None
-    import statistics
-
-    from oracle import backbone as ob
-    from oracle import dcn as odcn
-    from oracle import decode as odec
-
-    heads = synth.HEADS_POSE
-    sd = synth.make_state_dict(arch, heads, False)
-    cores = torch.get_num_threads()
-
-    def one(i, kind):
-        x = synth.frames(1, seed=1000 + i)
-        t1 = time.perf_counter()
-        z = ob.dlaseg_forward(sd, x, heads, arch=arch.split("_")[0], dcn_kind=kind)
-        hm = torch.sigmoid(z["hm"]).numpy()
-        hm_hp = torch.sigmoid(z["hm_hp"]).numpy()
-        odec.object_pose_decode(hm, z["hps"].numpy(), wh=z["wh"].numpy(), obj_scale=z["scale"].numpy(),
-                                reg=z["reg"].numpy(), hm_hp=hm_hp, hp_offset=z["hp_offset"].numpy(), K=100,
-                                rep_mode=1)
-        return time.perf_counter() - t1
-
-    def leg(kind, n_max, n_min, budget):
-        one(0, kind)  # warm-up: page-in, thread pools, im2col scratch
-        ts, t0 = [], time.perf_counter()
-        while len(ts) < n_max and (len(ts) < n_min or time.perf_counter() - t0 < budget):
-            ts.append(one(1 + len(ts), kind))
-        return ts
-
-    fair = leg("port", n_fair, 5, budget_s)
-    med = statistics.median(fair)
-    out = {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-           "sample": "%d images of the same workload after 1 warm-up image (oracle: %s forward with OpenMP im2col + "
-                     "torch CPU convolutions on %d threads, numpy decode), median %.3f s/img, min %.3f, max %.3f" % (
-                         len(fair), arch, cores, med, min(fair), max(fair))}
-    # faithful: the reference's CPU path as shipped -- scalar single-thread im2col (oracle/_ref, built from the
-    # reference's own source where that tree exists; otherwise this repo's C port pinned to one OpenMP thread)
-    kind = "reference" if odcn.have_reference() else "port"
-    if kind == "port":
-        try:
-            import ctypes
-
-            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
-        except OSError:
-            kind = None
-    if kind:
-        ff = leg(kind, n_faithful, 2, budget_s / 2)
-        fm = statistics.median(ff)
-        out["faithful"] = {"value": round(1.0 / fm, 4), "unit": "images/sec", "kind": kind,
-                           "sample": "%d images after 1 warm-up, scalar single-thread deformable im2col (%s) + torch CPU "
-                                     "convolutions, median %.3f s/img" % (
-                                         len(ff), "the reference's own dcn_v2_im2col_cpu.cpp" if kind == "reference"
-                                         else "C port, 1 OpenMP thread", fm)}
-    return out
+    def pnp_stats(self):
+        """(ms per solve on its stream, detections solved in the last batch) for roofline.pnp."""
+        st = self._stages.get(self.batch)
+        ms = st.take_solve_ms() if st is not None else None
+        n = None
+        if self.last is not None:
+            torch.cuda.synchronize()
+            n = int(self.last[0].sum().item())
+        return ms, n
 
 
-def timed_region(pipe, steps, warmup, barrier):
+class DryPipeline(object):
+    """--dry-run: no device, no library; fixed-size records tagged with the rank so the gather can be checked."""
+
+    def __init__(self, batch, rank):
+        self.batch, self.rank = batch, rank
+        self.arch, self.track, self.workload = "dla_34", False, "full"
+        self.det = torch.full((batch, 100, 118), float(rank), dtype=torch.float32)
+        self.gathered = None
+
+    def step(self, x=None, graph=False):
+        time.sleep(0.002)
+        self.gathered = cpd.allgather_detections(self.det)
+        return self.gathered
+
+
+def timed_region(pipe, steps, warmup, barrier, profile=True):
     """W untimed steps, then exactly `steps` timed ones between barriers; per-launch HIP events on every 4th step."""
     for _ in range(warmup):
         pipe.step()
@@ -208,12 +214,15 @@ def timed_region(pipe, steps, warmup, barrier):
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
-        on = i % every == 0
-        pipe.model.profile(on)
-        sampled += int(on)
+        if profile:
+            on = i % every == 0
+            pipe.model.profile(on)
+            sampled += int(on)
         pipe.step()
     barrier()
     dt = time.perf_counter() - t0
+    if not profile:
+        return dt, {}, {}, 0
     pipe.model.profile(False)
     prof = pipe.model.profile_read()
     roles = pipe.model.profile_roles()
@@ -236,17 +245,17 @@ def north_star_figures(roles, sampled, batch, precision):
                                       sampled / (t * 1e-3) / 1e12, 1),
                       "main_only_tflops": round(roles["dcn"]["flops"] / sampled / (t_main * 1e-3) / 1e12, 1)}
     peak = PEAK_F16_MFMA_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
-    for key, names in (("conv1x1", ("conv1x1", "head_final")),):
-        ms = sum(per(n) for n in names)
-        if ms > 0:
-            fl = sum(roles[n]["flops"] for n in names if n in roles) / sampled
-            by = sum(roles[n]["bytes"] for n in names if n in roles) / sampled
-            tf = fl / (ms * 1e-3) / 1e12
-            out[key] = {"bound": "mfma", "ms_per_step": round(ms, 3), "tflops": round(tf, 1), "peak_tflops": peak,
-                        "mfma_utilisation": round(tf / peak, 4),
-                        "issued_utilisation": round((3 if precision == "f16x3" else 1) * tf / peak, 4),
-                        "algorithmic_gbps": round(by / 1e6 / ms, 1),
-                        "launches_per_step": sum(roles[n]["launches"] for n in names if n in roles) // sampled}
+    names = ("conv1x1", "head_final")
+    ms = sum(per(n) for n in names)
+    if ms > 0:
+        fl = sum(roles[n]["flops"] for n in names if n in roles) / sampled
+        by = sum(roles[n]["bytes"] for n in names if n in roles) / sampled
+        tf = fl / (ms * 1e-3) / 1e12
+        out["conv1x1"] = {"bound": "mfma", "ms_per_step": round(ms, 3), "tflops": round(tf, 1), "peak_tflops": peak,
+                          "mfma_utilisation": round(tf / peak, 4),
+                          "issued_utilisation": round((3 if precision == "f16x3" else 1) * tf / peak, 4),
+                          "algorithmic_gbps": round(by / 1e6 / ms, 1),
+                          "launches_per_step": sum(roles[n]["launches"] for n in names if n in roles) // sampled}
     if "decode" in roles:
         us = per("decode") * 1e3
         out["decode"] = {"bound": "hbm", "us_per_step": round(us, 1), "algorithmic_mb_per_img": DECODE_MB_PER_IMG,
@@ -256,159 +265,370 @@ def north_star_figures(roles, sampled, batch, precision):
     return out
 
 
+def roofline_object(prof, roles, sampled, batch, precision):
+    """`roofline` of the dominant kernel (largest share of HIP-event time inside the timed region)."""
+    if not prof:
+        return None
+    name, r = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+    total_ms = sum(v["ms"] for v in prof.values())
+    is16 = "f16x3" in name
+    peak = PEAK_F16_MFMA_TFLOPS if is16 else PEAK_F32_MFMA_TFLOPS
+    roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "note": ("algorithmic FLOPs; each is executed as 3 binary16 MFMA products (hi*hi + hi*lo + lo*hi), so "
+                     "the matrix pipe does 3x this work: issued rate %.0f TFLOP/s = %.3f of the f16 peak" % (
+                         3 * achieved, 3 * achieved / peak)) if is16 else "exact float32 MFMA",
+            "launches_per_step": r["launches"] // sampled,
+            "timed_steps_sampled": sampled,
+            "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
+            "flops_per_launch": r["flops"] / r["launches"],
+            "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
+            "share_of_conv_time": round(r["ms"] / total_ms, 4),
+            "all_conv_kernels": {k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                     "ms_per_step": round(v["ms"] / sampled, 3),
+                                     "launches_per_step": v["launches"] // sampled}
+                                 for k, v in prof.items()},
+            "conv_ms_per_step": round(total_ms / sampled, 3)}
+    roof.update(north_star_figures(roles, sampled, batch, precision))
+    tr = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(tr):
+        with open(tr) as f:
+            t = json.load(f).get(name)
+        if t:  # HBM-side bytes per launch from the rocprofv3 PMC passes of profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
+            roof["traffic"] = t["hbm_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+    return roof
+
+
+def frame_latency(pipe, n=50):
+    """p50 per-frame latency at batch 1: frame already in HBM -> results in HBM, network replayed from a hipGraph."""
+    x1 = pipe.x[:1].contiguous()
+    for _ in range(3):
+        pipe.step(x1, graph=True)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        t1 = time.perf_counter()
+        pipe.step(x1, graph=True)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t1) * 1e3)
+    ts.sort()
+    return round(ts[len(ts) // 2], 3)
+
+
+def run_leg(workload, device, precision, steps, warmup, barrier, latency, serial_pnp=False):
+    """One nested leg of the default run: a short timed region of another configuration, same harness."""
+    batch = DEFAULT_BATCH[workload]
+    pipe = Pipeline(workload, batch, device, seed=317, precision=precision, serial_pnp=serial_pnp)
+    dt, prof, roles, sampled = timed_region(pipe, steps, warmup, barrier)
+    key = pipe.arch + ("_track" if pipe.track else "")
+    out = {"workload": WORKLOAD_TEXT[workload] % batch, "precision": precision,
+           "value": round(batch * steps / dt, 2), "unit": "images/sec", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 3),
+           "whole_step_tflops": round(batch * steps / dt * GFLOP_PER_IMG[key] / 1e3, 2),
+           "roofline": roofline_object(prof, roles, sampled, batch, precision)}
+    if latency and workload in ("full", "decode", "hourglass"):
+        out["p50_frame_ms_batch1"] = frame_latency(pipe, 30)
+    del pipe
+    torch.cuda.empty_cache()
+    return out
+
+
+def track_e2e_leg(device, precision, n_videos, frames, warmup):
+    """B concurrent videos through CenterPoseTrack's whole per-frame loop (lib/detectors/batch_tracking.py): what the
+    host-side tracker costs next to the batched device stages."""
+    import contextlib
+    import io
+    import tempfile
+
+    import numpy as np
+
+    from centerpose_amd import synth
+    from centerpose_amd.lib.detectors.batch_tracking import BatchedTracking
+    from centerpose_amd.lib.detectors.detector_factory import detector_factory
+    from centerpose_amd.lib.models.model import create_model, save_model
+    from centerpose_amd.lib.opts import opts
+    from centerpose_amd.lib.utils.image import get_affine_transform
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        o = opts().parser.parse_args(["--tracking_task", "--arch", "dla_34", "--c", "cup", "--debug", "0"])
+        o.nms, o.obj_scale, o.use_pnp = True, True, True           # src/demo.py:111-149
+        o.pre_img = o.pre_hm = o.tracking = o.pre_hm_hp = o.tracking_hp = True
+        o.track_thresh = 0.1
+        o.obj_scale_uncertainty = o.hps_uncertainty = o.kalman = o.scale_pool = True
+        o.vis_thresh = max(o.track_thresh, o.vis_thresh)
+        o.pre_thresh = max(o.track_thresh, o.pre_thresh)
+        o.new_thresh = max(o.track_thresh, o.new_thresh)
+        o.precision = precision
+        o = opts().init(opts().parse(o))
+        sd = synth.make_state_dict("dla_34", o.heads, True)
+        with tempfile.TemporaryDirectory() as td:
+            ck = os.path.join(td, "synthetic_dla_34_track.pth")
+            m = create_model(o.arch, o.heads, o.head_conv, o)
+            m.load_state_dict(sd, strict=True)
+            save_model(ck, 1, m)
+            o.load_model = ck
+            det = detector_factory[o.task](o)
+    c, s = np.array([256.0, 256.0], np.float32), 512.0
+    K = np.array([[663.0287679036459, 0, 300.2775065104167], [0, 663.0287679036459, 395.00066121419275], [0, 0, 1]])
+    meta = {"c": c, "s": s, "height": 512, "width": 512, "out_height": 128, "out_width": 128, "inp_height": 512,
+            "inp_width": 512, "trans_input": get_affine_transform(c, s, 0, [512, 512]),
+            "trans_output": get_affine_transform(c, s, 0, [128, 128]), "camera_matrix": K}
+    vids = [torch.cat([synth.frames(min(8, n_videos - i), seed=4000 + 100 * f + i) for i in range(0, n_videos, 8)]).to(device)
+            for f in range(4)]  # four distinct frames per video, cycled
+    bt = BatchedTracking(det, n_videos)
+    n_tracks = 0
+    with contextlib.redirect_stdout(io.StringIO()):
+        for f in range(warmup + frames):
+            if f == warmup:
+                torch.cuda.synchronize()
+                bt.times = {k: 0 if k == "steps" else 0.0 for k in bt.times}
+                t0 = time.perf_counter()
+            outs = bt.step(vids[f % 4], [dict(meta, id=f) for _ in range(n_videos)])
+            n_tracks = sum(len(x["results"]) for x in outs)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = bt.times
+    tot = t["host_records"] + t["device"] + t["host_tracks"]
+    out = {"workload": WORKLOAD_TEXT["track_e2e"] % n_videos, "precision": precision,
+           "value": round(n_videos * frames / dt, 2), "unit": "frames/sec (all videos)", "steps": frames, "warmup": warmup,
+           "ms_per_step": round(dt / frames * 1e3, 3),
+           "ms_device_stages": round(t["device"] / frames * 1e3, 3),
+           "ms_host_records": round(t["host_records"] / frames * 1e3, 3),
+           "ms_host_tracker": round(t["host_tracks"] / frames * 1e3, 3),
+           "host_fraction": round((t["host_records"] + t["host_tracks"]) / tot, 4),
+           "tracks_alive_last_frame": n_tracks,
+           "note": "host = Gaussian-record building from the tracks, detection dicts, Gaussian fusion, pnp_shell packaging, "
+                   "Tracker.step (32-state Kalman filter per track, scale pool, one cp_pnp_solve round trip per track for "
+                   "the filtered vertices); device = render + two-frame network + decode + post-process + PnP incl. the "
+                   "copy of the results to the host"}
+    del bt, det
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline(workload, arch, budget_s=45.0, n_timed=10, n_warm=3):
+    """The reference's CPU path on a bounded sample of the same workload (3 warm-ups, >= 10 timed
+    images, median).  Both legs run the oracle's restatement of the reference graph (torch CPU convolutions on all
+    cores) + numpy decode (+ for configs[2] the host post-process and the float64 PnP restatement per detection); they
+    differ in the deformable im2col: `value` = the reference's own scalar single-thread source as shipped
+    (oracle/_ref, kind "reference"; this repo's C port pinned to one thread where that binary is absent), `fair` = the C
+    port with OpenMP over all cores."""
+    if workload not in ("full", "decode"):
+        return None
+    import statistics
+
+    import numpy as np
+
+    from centerpose_amd import synth
+    from oracle import backbone as ob
+    from oracle import dcn as odcn
+    from oracle import decode as odec
+    from oracle import pnp as opnp
+
+    heads = synth.HEADS_POSE
+    sd = synth.make_state_dict(arch, heads, False)
+    cores = torch.get_num_threads()
+    Kmat = np.array([[663.0287679036459, 0, 300.2775065104167], [0, 663.0287679036459, 395.00066121419275], [0, 0, 1]])
+    n_pnp = []
+
+    def one(i, kind):
+        x = synth.frames(1, seed=1000 + i)
+        t1 = time.perf_counter()
+        z = ob.dlaseg_forward(sd, x, heads, arch=arch.split("_")[0], dcn_kind=kind)
+        hm = torch.sigmoid(z["hm"]).numpy()
+        hm_hp = torch.sigmoid(z["hm_hp"]).numpy()
+        d = odec.object_pose_decode(hm, z["hps"].numpy(), wh=z["wh"].numpy(), obj_scale=z["scale"].numpy(),
+                                    reg=z["reg"].numpy(), hm_hp=hm_hp, hp_offset=z["hp_offset"].numpy(), K=100,
+                                    rep_mode=1)
+        if workload == "full":  # the PnP of every detection above vis_thresh (x4: 128-grid -> 512 image, fix_res)
+            keep = np.nonzero(d["scores"][0, :, 0] > 0.3)[0]
+            for k in keep:
+                pts = np.hstack((d["kps_displacement_mean"][0, k].reshape(8, 2), d["kps_heatmap_mean"][0, k].reshape(8, 2)))
+                pts = np.where(pts < -5000, pts, pts * 4.0).reshape(-1, 2)
+                opnp.solve_cuboid_pnp(pts, d["obj_scale"][0, k].astype(np.float64), Kmat)
+            n_pnp.append(len(keep))
+        return time.perf_counter() - t1
+
+    def leg(kind, budget):
+        for w in range(n_warm):  # warm-ups: page-in, thread pools, im2col scratch
+            one(w, kind)
+        ts, t0 = [], time.perf_counter()
+        while len(ts) < n_timed or (time.perf_counter() - t0 < budget and len(ts) < 2 * n_timed):
+            ts.append(one(n_warm + len(ts), kind))
+            if time.perf_counter() - t0 > 4 * budget:
+                break  # stated budget: a slow host stops after 4x the budget even below n_timed images
+        ts.sort()
+        return ts
+
+    def describe(ts, what):
+        med = statistics.median(ts)
+        return med, ("%d timed images after %d warm-ups, %s; median %.3f s/img (p50), p95 %.3f, min %.3f" % (
+            len(ts), n_warm, what, med, ts[min(len(ts) - 1, int(0.95 * len(ts)))], ts[0]))
+
+    kind = "reference" if odcn.have_reference() else "port"
+    omp = None
+    if kind == "port":
+        try:
+            import ctypes
+
+            omp = ctypes.CDLL("libgomp.so.1")
+            omp.omp_set_num_threads(1)
+        except OSError:
+            omp = None
+    shipped = leg(kind, budget_s)
+    med, text = describe(shipped, "scalar single-thread deformable im2col (%s) + torch CPU convolutions on %d threads + numpy "
+                                  "decode%s" % ("the reference's own dcn_v2_im2col_cpu.cpp, oracle/_ref" if kind == "reference"
+                                                else "this repo's C port pinned to 1 thread", cores,
+                                                " + float64 PnP restatement" if workload == "full" else ""))
+    out = {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": cores, "kind": kind, "sample": text,
+           "protocol": "BASELINE.md section 3: %d warm-ups, >= %d timed images (budget %.0f s), median" % (n_warm, n_timed, budget_s)}
+    if omp is not None:
+        omp.omp_set_num_threads(cores)
+    fair = leg("port", budget_s / 2)
+    fmed, ftext = describe(fair, "OpenMP port of the im2col on all cores + the same torch CPU convolutions / decode")
+    out["fair"] = {"value": round(1.0 / fmed, 4), "unit": "images/sec", "kind": "port", "cores": cores, "sample": ftext}
+    if n_pnp:
+        out["pnp_detections_per_image"] = round(sum(n_pnp) / len(n_pnp), 2)
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
-    # one GPU per rank; ($CP_BENCH_BACKEND=gloo with fewer GPUs than ranks is a plumbing rehearsal on a 1-GPU box)
+    dry = args.dry_run
     backend = os.environ.get("CP_BENCH_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
-    if world > ndev and backend == "nccl":
-        raise SystemExit("bench.py: %d ranks but %d visible GPUs (RCCL needs one GPU per rank)" % (world, ndev))
-    local = local % ndev
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    if not dry and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    device = None
+    if not dry:
+        # one GPU per rank; ($CP_BENCH_BACKEND=gloo with fewer GPUs than ranks is a plumbing rehearsal on a 1-GPU box)
+        ndev = torch.cuda.device_count()
+        if world > ndev and backend == "nccl":
+            raise SystemExit("bench.py: %d ranks but %d visible GPUs (RCCL needs one GPU per rank)" % (world, ndev))
+        local = local % ndev
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         cpd.init_from_env(backend)
-    if args.dbg:
+    if rank == 0 and args.gpus != world:
+        print("bench.py: --gpus %d but the launcher started %d rank(s); n_gpus reports %d" % (args.gpus, world, world),
+              file=sys.stderr)
+    if args.dbg and not dry:
+        from centerpose_amd import hip
+
         hip.lib().cp_set_debug(args.dbg)
-    batch = args.batch or {"decode": 32, "full": 64, "track": 16, "track_gru": 16, "hourglass": 8}[args.workload]
-    pipe = Pipeline(args.workload, batch, device, seed=317 + 1000 * rank, precision=args.precision,
-                    serial_pnp=args.serial_pnp)
+    batch = args.batch or DEFAULT_BATCH[args.workload]
 
     def barrier():
         if dist is not None:
-            if backend == "nccl":
+            if backend == "nccl" and not dry:
                 dist.barrier(device_ids=[local])
             else:
                 dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
-    side = torch.cuda.Stream(device=device)  # a non-default stream (hipGraph capture needs one)
-    torch.cuda.set_stream(side)
-    dt, prof, roles, sampled = timed_region(pipe, args.steps, args.warmup, barrier)
+    if args.workload == "track_e2e":  # host-in-the-loop measurement, single GPU
+        if world != 1:
+            raise SystemExit("track_e2e is a single-process measurement")
+        leg = track_e2e_leg(device, args.precision, batch, max(args.steps, 4), max(args.warmup, 2))
+        leg.update({"metric": "frames/sec over %d concurrent videos (CenterPoseTrack loop incl. host tracker)" % batch,
+                    "n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+                    "dtype": "f32", "config": {"workload": leg["workload"]}})
+        print(json.dumps(leg), flush=True)
+        return
+
+    if dry:
+        pipe = DryPipeline(batch, rank)
+    else:
+        pipe = Pipeline(args.workload, batch, device, seed=317 + 1000 * rank, precision=args.precision,
+                        serial_pnp=args.serial_pnp, gather=world > 1)
+        side = torch.cuda.Stream(device=device)  # a non-default stream (hipGraph capture needs one)
+        torch.cuda.set_stream(side)
+    dt, prof, roles, sampled = timed_region(pipe, args.steps, args.warmup, barrier, profile=not dry)
+    rccl_ranks = 1
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if (device is not None and backend == "nccl") else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # the collective really ran: gather one tagged record per rank and read the world size back from the group
+        tag = torch.full((1, 1, 4), float(rank), dtype=torch.float32,
+                         device=device if (device is not None and backend == "nccl") else "cpu")
+        got = cpd.allgather_detections(tag).flatten()[::4].tolist()
+        if got != [float(r) for r in range(world)]:
+            raise SystemExit("bench.py: all-gather returned %r, expected ranks 0..%d in order" % (got, world - 1))
+        rccl_ranks = dist.get_world_size()
     ms_per_step = dt / args.steps * 1e3
     value = world * batch * args.steps / dt
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (largest share of event time inside the timed region) ----
-        roof = None
-        if prof:
-            name, r = max(prof.items(), key=lambda kv: kv[1]["ms"])
-            achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
-            total_ms = sum(v["ms"] for v in prof.values())
-            is16 = "f16x3" in name
-            peak = PEAK_F16_MFMA_TFLOPS if is16 else PEAK_F32_MFMA_TFLOPS
-            roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-                    "note": ("algorithmic FLOPs; each is executed as 3 binary16 MFMA products (hi*hi + hi*lo + lo*hi), so "
-                             "the matrix pipe does 3x this work: issued rate %.0f TFLOP/s = %.3f of the f16 peak" % (
-                                 3 * achieved, 3 * achieved / peak)) if is16 else "exact float32 MFMA",
-                    "launches_per_step": r["launches"] // sampled,
-                    "timed_steps_sampled": sampled,
-                    "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
-                    "flops_per_launch": r["flops"] / r["launches"],
-                    "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
-                    "share_of_conv_time": round(r["ms"] / total_ms, 4),
-                    "all_conv_kernels": {k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                             "ms_per_step": round(v["ms"] / sampled, 3),
-                                             "launches_per_step": v["launches"] // sampled}
-                                         for k, v in prof.items()},
-                    "conv_ms_per_step": round(total_ms / sampled, 3)}
-            roof.update(north_star_figures(roles, sampled, batch, args.precision))
-            tr = os.path.join(REPO, "profiles", "pmc_traffic.json")
-            if os.path.exists(tr):
-                with open(tr) as f:
-                    t = json.load(f).get(name)
-                if t:  # HBM-side bytes per launch from the rocprofv3 PMC passes of profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
-                    roof["traffic"] = t["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+        roof = None if dry else roofline_object(prof, roles, sampled, batch, args.precision)
+        if roof is not None and args.workload == "full":
+            ms, n = pipe.pnp_stats()
+            if ms:
+                roof["pnp"] = {"bound": "latency", "ms_per_batch_on_side_stream": round(ms, 3),
+                               "detections_last_batch": n,
+                               "detections_per_s_while_solving": round(n / (ms * 1e-3), 1) if n else None,
+                               "note": "PnP-input assembly + batched solve of one batch, HIP events on hip.PoseStage's side "
+                                       "stream; runs under the next batch's network (DESIGN 3.6)"}
         lat = None
-        if not args.no_latency:
-            # per-frame latency at batch 1: frame already in HBM -> detections in HBM, replayed from a hipGraph
-            x1 = pipe.x[:1].contiguous()
-            for _ in range(3):
-                pipe.step(x1, graph=True)
-            torch.cuda.synchronize()
-            ts = []
-            for _ in range(50):
-                t1 = time.perf_counter()
-                pipe.step(x1, graph=True)
-                torch.cuda.synchronize()
-                ts.append((time.perf_counter() - t1) * 1e3)
-            ts.sort()
-            lat = round(ts[len(ts) // 2], 3)
-        cfg2 = None
-        if world == 1 and args.workload == "decode" and not args.no_configs2:
-            # BASELINE configs[2] in the same run: dla_34, batch 64, backbone + decode + batched PnP
+        if not dry and not args.no_latency and args.workload in ("full", "decode", "hourglass"):
+            pipe.gather = False  # rank 0 alone: no collective inside the batch-1 latency loop
+            lat = frame_latency(pipe)
+        legs = None
+        if not dry and world == 1 and args.workload == "full" and not args.no_legs:
+            # the other configurations, driver-timed in the same run (short legs; each has its own roofline object)
             del pipe.model
+            pipe._stages.clear()
             torch.cuda.empty_cache()
-            p2 = Pipeline("full", 64, device, seed=317, precision=args.precision, serial_pnp=args.serial_pnp)
-            k2 = max(4, min(args.steps, 12))
-            dt2, prof2, roles2, sampled2 = timed_region(p2, k2, max(1, min(args.warmup, 2)), barrier)
-            n2, r2 = max(prof2.items(), key=lambda kv: kv[1]["ms"])
-            cfg2 = {"workload": "dla_34 512x512 batch=64, Objectron-shaped synthetic frames, backbone + sigmoid + decode + "
-                                "batched PnP (BASELINE configs[2])",
-                    "pnp": ("on the network's stream" if args.serial_pnp else
-                            "hip.PoseStage: queued on a side stream, runs under the next batch's network; all solves finish "
-                            "inside the timed region"),
-                    "value": round(64 * k2 / dt2, 2), "unit": "images/sec", "steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 3),
-                    "whole_step_tflops": round(64 * k2 / dt2 * GFLOP_PER_IMG["dla_34"] / 1e3, 2),
-                    "dominant_kernel": {"kernel": n2, "tflops": round(r2["flops"] / (r2["ms"] * 1e-3) / 1e12, 1),
-                                        "avg_launch_us": round(r2["ms"] * 1e3 / r2["launches"], 2)}}
-            cfg2.update(north_star_figures(roles2, sampled2, 64, args.precision))
-            if not args.no_latency:  # per-frame latency of the whole chain at batch 1: network graph + post-process + PnP
-                x1 = p2.x[:1].contiguous()
-                for _ in range(3):
-                    p2.step(x1, graph=True)
-                torch.cuda.synchronize()
-                ts = []
-                for _ in range(50):
-                    t1 = time.perf_counter()
-                    p2.step(x1, graph=True)
-                    torch.cuda.synchronize()
-                    ts.append((time.perf_counter() - t1) * 1e3)
-                ts.sort()
-                cfg2["p50_frame_ms_batch1"] = round(ts[len(ts) // 2], 3)
-            del p2
-            torch.cuda.empty_cache()
+            legs = {}
+            k = max(4, min(args.steps, 6))
+            w = max(1, min(args.warmup, 2))
+            legs["configs1"] = run_leg("decode", device, args.precision, max(4, min(args.steps, 12)), w, barrier,
+                                       not args.no_latency)
+            legs["exact_f32"] = run_leg("full", device, "f32", 4, 1, barrier, False)
+            for name in ("hourglass", "track", "track_gru"):
+                legs[name] = run_leg(name, device, args.precision, k, w, barrier, False)
+            try:
+                legs["track_e2e"] = track_e2e_leg(device, args.precision, DEFAULT_BATCH["track_e2e"], 6, 2)
+            except Exception as e:  # the host-in-the-loop leg must not take the headline line down with it
+                legs["track_e2e"] = {"error": "%s: %s" % (type(e).__name__, e)}
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if not dry and world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.workload, pipe.arch)
-        gf = GFLOP_PER_IMG[pipe.arch + ("_track" if pipe.track else "")]
+        key = pipe.arch + ("_track" if pipe.track else "")
+        gf = GFLOP_PER_IMG[key]
+        tail = {"full": " + post-process + PnP", "decode": "", "hourglass": ""}.get(args.workload, " + detection all-gather")
         out = {
             "metric": "images/sec at 512x512 %s (backbone + heat-map decode%s)" % (
-                "2-stack hourglass" if pipe.arch == "hourglass" else "DLA-34",
-                " + PnP" if args.workload == "full" else " + detection all-gather" if pipe.track else ""),
+                "2-stack hourglass" if pipe.arch == "hourglass" else "DLA-34", tail),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "f32 via split-f16 (f16x3) MFMA, f32 accumulate",
-            "data": "synthetic",
-            "config": {"workload": "%s 512x512 batch=%d/GPU, synthetic random frames, seeded random-init weights, "
-                                   "backbone + sigmoid + heat-map decode%s" % (
-                                       pipe.arch, batch, " + batched PnP" if args.workload == "full" else
-                                       " (two-frame tracking inputs, Gaussian moments) + all-gather" if pipe.track else ""),
-                       "arch": pipe.arch, "global_batch": world * batch, "input": "512x512",
+            "data": "dry-run (stub pipeline, no device work)" if dry else "synthetic",
+            "rccl_ranks": rccl_ranks,
+            "config": {"workload": WORKLOAD_TEXT[args.workload] % batch, "global_batch": world * batch,
+                       "per_gpu_batch": batch, "input": "512x512",
                        "parallelism": "batch-shard x%d (%s)" % (
-                           world, "all-gather of detection records" if pipe.track else "no collective"),
+                           world, "all-gather of detection records over %s" % ("RCCL" if backend == "nccl" else backend)
+                           if world > 1 else "single rank, no collective"),
                        "gflop_per_image": gf,
-                       **({"gflop_note": "603.7 = BASELINE.md's 739.2 GFLOP/img for the reference module minus the 135.3 of the "
-                                         "first stack's seven heads, which do not feed model(x)[-1] (object_pose.py:135) and "
-                                         "are not computed"} if pipe.arch == "hourglass" else {})},
+                       **({"gflop_note": "603.7 = BASELINE.md's 739.2 GFLOP/img for the reference module minus the 135.3 of "
+                                         "the first stack's seven heads, which do not feed model(x)[-1] (object_pose.py:135) "
+                                         "and are not computed"} if pipe.arch == "hourglass" else {})},
             "p50_frame_ms_batch1": lat,
             "whole_step_tflops": round(value * gf / 1e3 / world, 2),
-            "roofline": roof, "configs2": cfg2, "cpu_baseline": cpu,
+            "roofline": roof, "legs": legs, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -318,8 +318,8 @@ _pnp_ws_cache = {}
 def pnp_from_post(post, count, cam, rep_mode=1, out=None, ws=None):
     """PnP of every post-processed slot on the device (cp_pnp_from_post): post [B,K,120] float64 + count [B] int32 from
     ``postprocess``, cam [B,4] float64 (fx, fy, cx, cy).  Returns [B,K,40] float64; rows k >= count[b] carry status -1.
-    No host synchronisation.  ``out`` / ``ws``: caller-owned result and workspace (default: a fresh result, one cached
-    workspace per shape -- calls on different streams must pass their own)."""
+    No host synchronisation.  ``out`` / ``ws``: caller-owned result and workspace (default: a fresh result and one
+    cached workspace per (shape, device, stream) -- launches on the same stream are ordered, so they may share it)."""
     L = lib()
     B, K = int(post.shape[0]), int(post.shape[1])
     if not (post.is_cuda and post.dtype == torch.float64 and post.is_contiguous() and count.is_cuda and cam.is_cuda):
@@ -329,9 +329,11 @@ def pnp_from_post(post, count, cam, rep_mode=1, out=None, ws=None):
         out = torch.empty(B, K, PNP_STRIDE, dtype=torch.float64, device=post.device)
     n = L.cp_pnp_from_post_workspace_bytes(B, K)
     if ws is None:
-        key = (B, K, post.device)
+        key = (B, K, post.device, torch.cuda.current_stream(post.device).cuda_stream)
         ws = _pnp_ws_cache.get(key)
         if ws is None:
+            if len(_pnp_ws_cache) >= 16:
+                _pnp_ws_cache.clear()
             ws = _pnp_ws_cache[key] = torch.empty(n, dtype=torch.uint8, device=post.device)
     if tuple(out.shape) != (B, K, PNP_STRIDE) or out.dtype != torch.float64 or ws.numel() < n:
         raise RuntimeError("pnp_from_post: out / ws do not fit this batch")
@@ -349,7 +351,9 @@ class PoseStage(object):
     rotate, and the caller's stream waits for the solve that last used a set before post-process overwrites it.
 
     submit() -> (post [B,K,120], count [B], poses [B,K,40], done): the tensors are valid once ``done`` (a
-    torch.cuda.Event) has completed -- ``done.synchronize()`` on the host or ``stream.wait_event(done)``."""
+    torch.cuda.Event) has completed -- ``done.synchronize()`` on the host or ``stream.wait_event(done)``.
+    Caller-owned inputs (``det``, ``meta``, ``cam``) are read on the side stream as well: the stage tells the caching
+    allocator (``record_stream``), so the caller may drop them right after ``submit``."""
 
     def __init__(self, B, K, device, depth=2):
         L = lib()
@@ -364,7 +368,9 @@ class PoseStage(object):
                 poses=torch.empty(B, K, PNP_STRIDE, dtype=torch.float64, device=device),
                 ws_post=torch.empty(n_post, dtype=torch.uint8, device=device),
                 ws_pnp=torch.empty(n_pnp, dtype=torch.uint8, device=device),
-                ready=torch.cuda.Event(), done=torch.cuda.Event()))
+                ready=torch.cuda.Event(), done=torch.cuda.Event(enable_timing=True),
+                begin=torch.cuda.Event(enable_timing=True)))
+        self._timed = []
 
     def submit(self, det, meta, cam, vis_thresh, nms=True, rep_mode=1):
         s = self.sets[self.i % self.depth]
@@ -375,11 +381,24 @@ class PoseStage(object):
             main.wait_event(s["done"])  # the solve that read this set `depth` batches ago
         postprocess(det, meta, vis_thresh, nms=nms, out=s["post"], cnt=s["cnt"], ws=s["ws_post"])
         s["ready"].record(main)
+        if torch.is_tensor(cam) and cam.is_cuda:
+            cam.record_stream(self.side)  # read by the solve after this call returns
         with torch.cuda.stream(self.side):
             self.side.wait_event(s["ready"])
+            s["begin"].record(self.side)
             pnp_from_post(s["post"], s["cnt"], cam, rep_mode=rep_mode, out=s["poses"], ws=s["ws_pnp"])
             s["done"].record(self.side)
+        self._timed = [(s["begin"], s["done"])]
         return s["post"], s["cnt"], s["poses"], s["done"]
+
+    def take_solve_ms(self):
+        """Milliseconds the most recent assembly + solve took on the side stream (synchronises on it); None before the
+        first submit."""
+        if not self._timed:
+            return None
+        b, d = self._timed[-1]
+        d.synchronize()
+        return b.elapsed_time(d)
 
 
 class HipModel(object):

@@ -53,29 +53,33 @@ def _resize(image, new_w, new_h):
         return np.asarray(Image.fromarray(image).resize((new_w, new_h), Image.BILINEAR))
 
 
+def _build_tracker(opt):
+    """Which track keeper the flags select (base_detector.py:53-57: ``refined_Kalman`` wins when both are set)."""
+    if opt.refined_Kalman:
+        return Tracker_baseline(opt)
+    if opt.tracking_task:
+        return Tracker(opt)
+    return None
+
+
 class BaseDetector(object):
+    """Public attributes as the reference constructor leaves them (base_detector.py:31-57): ``model`` (built, loaded,
+    moved, eval), ``mean`` / ``std`` ([1,1,3] float32), ``max_per_image``, ``num_classes``, ``scales``, ``opt`` (with
+    ``opt.device`` filled in), ``pause``, ``pre_images`` and -- for the tracking configurations -- ``tracker``."""
+
     def __init__(self, opt):
-        if opt.gpus[0] >= 0:
-            opt.device = torch.device('cuda')
-        else:
-            opt.device = torch.device('cpu')
-        print('Creating model...')
-        self.model = create_model(opt.arch, opt.heads, opt.head_conv, opt)
-        self.model = load_model(self.model, opt.load_model)
-        self.model = self.model.to(opt.device)
-        self.model.eval()
-        self.mean = np.array(opt.mean, dtype=np.float32).reshape(1, 1, 3)
-        self.std = np.array(opt.std, dtype=np.float32).reshape(1, 1, 3)
-        self.max_per_image = 100
-        self.num_classes = opt.num_classes
-        self.scales = opt.test_scales
+        opt.device = torch.device('cuda' if opt.gpus[0] >= 0 else 'cpu')
         self.opt = opt
-        self.pause = True
-        self.pre_images = None
-        if opt.tracking_task:
-            self.tracker = Tracker(opt)
-        if opt.refined_Kalman:
-            self.tracker = Tracker_baseline(opt)
+        print('Creating model...')
+        net = load_model(create_model(opt.arch, opt.heads, opt.head_conv, opt), opt.load_model)
+        self.model = net.to(opt.device)
+        self.model.eval()
+        self.mean, self.std = (np.array(v, dtype=np.float32).reshape(1, 1, 3) for v in (opt.mean, opt.std))
+        self.num_classes, self.scales = opt.num_classes, opt.test_scales
+        self.max_per_image, self.pause, self.pre_images = 100, True, None
+        tracker = _build_tracker(opt)
+        if tracker is not None:
+            self.tracker = tracker
 
     def process(self, images, pre_images=None, pre_hms=None, pre_inds=None, return_time=False):
         raise NotImplementedError
@@ -97,32 +101,30 @@ class BaseDetector(object):
         bbox[[1, 3]] = np.clip(bbox[[1, 3]], 0, height - 1)
         return bbox
 
+    def _input_geometry(self, height, width, scale):
+        """Network input size and the crop (centre c, extent s) of the three test modes (base_detector.py:103-120):
+        ``fix_short`` (short side fixed, long side rounded up to 64), ``fix_res`` (the demo's mode: input_h x input_w,
+        crop = the scaled frame's centre with the longer ORIGINAL side as extent), else keep the resolution and pad to
+        ``opt.pad + 1``.  Returns (inp_h, inp_w, c, s, scaled_h, scaled_w)."""
+        o = self.opt
+        sh, sw = int(height * scale), int(width * scale)
+        f32 = np.float32
+        if o.fix_short > 0:
+            long_side = lambda a, b: (int(a / b * o.fix_short) + 63) // 64 * 64
+            inp_h, inp_w = (o.fix_short, long_side(width, height)) if height < width else (long_side(height, width), o.fix_short)
+            return inp_h, inp_w, np.array([width / 2, height / 2], dtype=f32), np.array([width, height], dtype=f32), sh, sw
+        if o.fix_res:
+            return o.input_h, o.input_w, np.array([sw / 2., sh / 2.], dtype=f32), max(height, width) * 1.0, sh, sw
+        inp_h, inp_w = (sh | o.pad) + 1, (sw | o.pad) + 1
+        return inp_h, inp_w, np.array([sw // 2, sh // 2], dtype=f32), np.array([inp_w, inp_h], dtype=f32), sh, sw
+
     def pre_process(self, image, scale, input_meta={}):
-        """base_detector.py:91-148"""
+        """base_detector.py:91-148: resize by ``scale``, warp the crop into the network input, normalise, CHW; the meta
+        dict carries the crop and both affine maps for post-processing."""
         height, width = image.shape[0:2]
-        new_height = int(height * scale)
-        new_width = int(width * scale)
-        if self.opt.fix_short > 0:
-            if height < width:
-                inp_height = self.opt.fix_short
-                inp_width = (int(width / height * self.opt.fix_short) + 63) // 64 * 64
-            else:
-                inp_height = (int(height / width * self.opt.fix_short) + 63) // 64 * 64
-                inp_width = self.opt.fix_short
-            c = np.array([width / 2, height / 2], dtype=np.float32)
-            s = np.array([width, height], dtype=np.float32)
-        elif self.opt.fix_res:
-            inp_height, inp_width = self.opt.input_h, self.opt.input_w
-            c = np.array([new_width / 2., new_height / 2.], dtype=np.float32)
-            s = max(height, width) * 1.0
-        else:
-            inp_height = (new_height | self.opt.pad) + 1
-            inp_width = (new_width | self.opt.pad) + 1
-            c = np.array([new_width // 2, new_height // 2], dtype=np.float32)
-            s = np.array([inp_width, inp_height], dtype=np.float32)
+        inp_height, inp_width, c, s, new_height, new_width = self._input_geometry(height, width, scale)
+        out_height, out_width = inp_height // self.opt.down_ratio, inp_width // self.opt.down_ratio
         trans_input = get_affine_transform(c, s, 0, [inp_width, inp_height])
-        out_height = inp_height // self.opt.down_ratio
-        out_width = inp_width // self.opt.down_ratio
         trans_output = get_affine_transform(c, s, 0, [out_width, out_height])
         if self.opt.device.type == 'cuda' and image.dtype == np.uint8 and image.ndim == 3:
             # resize (scale != 1) + warp + normalise on the device, in OpenCV's fixed-point arithmetic (cp_resize_u8,

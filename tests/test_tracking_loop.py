@@ -171,3 +171,53 @@ def test_tracking_run_matches_reference_gpu(device, monkeypatch):
     with contextlib.redirect_stdout(io.StringIO()):
         frames = tg.run_video(det, get_affine_transform)
     _compare(frames, gold)
+
+
+@pytest.mark.gpu
+def test_batched_tracking_matches_reference_per_video(device, monkeypatch):
+    """BatchedTracking (B concurrent videos: batched render / network / decode / post-process / PnP on the device,
+    the reference's per-video Tracker on the host) must give every video exactly what the reference's ``run()`` gives
+    the single video of tests/golden/track_run.json."""
+    import types
+
+    from centerpose_amd.lib.detectors.batch_tracking import BatchedTracking
+
+    with open(GOLD) as fh:
+        gold = json.load(fh)["frames"]
+    det = _detector(monkeypatch, "0")
+    stub, B = det.model, 3
+
+    class BatchEngine(object):
+        calls = 0
+        last_pre_hm = last_pre_hm_hp = None
+
+        def forward(self, images, pre_images=None, pre_hms=None, pre_hm_hp=None, sigmoid_hm=True):
+            assert images.shape[0] == B and pre_images is not None and pre_images.shape == images.shape
+            self.last_pre_hm, self.last_pre_hm_hp = pre_hms.detach().cpu().clone(), pre_hm_hp.detach().cpu().clone()
+            h = stub.frames[self.calls]
+            self.calls += 1
+            out = {}
+            for k, v in h.items():
+                v = torch.sigmoid(v) if (sigmoid_hm and k in ("hm", "hm_hp")) else v
+                out[k] = v.repeat(B, 1, 1, 1).contiguous().to(device)
+            return out
+
+    eng = BatchEngine()
+    stub._engine = lambda: eng
+    bt = BatchedTracking(det, B)
+    frames = [[] for _ in range(B)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        for img, meta in tg.frame_inputs(get_affine_transform):
+            images = torch.from_numpy(img)[None].repeat(B, 1, 1, 1)
+            outs = bt.step(images, [copy.deepcopy(meta) for _ in range(B)])
+            for b in range(B):
+                view = types.SimpleNamespace(model=types.SimpleNamespace(
+                    last_pre_hm=eng.last_pre_hm[b:b + 1], last_pre_hm_hp=eng.last_pre_hm_hp[b:b + 1]))
+                s = tg.summarise({"results": outs[b]["results"], "boxes": outs[b]["boxes"]}, view)
+                s["keys"] = gold[len(frames[b])]["keys"]   # run()'s timing keys are not part of a batched step
+                frames[b].append(s)
+    for b in range(B):
+        _compare(frames[b], gold)
+    assert bt.times["steps"] == len(gold) and bt.times["host_tracks"] > 0
+    bt.reset()
+    assert all(t.tracks == [] for t in bt.trackers) and bt.pre_images is None
