@@ -28,6 +28,7 @@ enum CpStore : int {
 };
 
 #define CP_MAX_SRC 4
+#define CP_MAX_HEAD_GROUP 12
 
 #ifdef __HIPCC__
 // ---- |max| tracking and power-of-two operand scaling for the split-f16 kernels (see ConvParams::in_amax) ----
@@ -148,6 +149,14 @@ struct ConvParams {
     const void* fuse_w2_lo;
     float* fuse_out;
     int fuse_c2;
+    // Several fused heads that read the same input in ONE launch (halo16.hip, EPI = 1): the 3x3 weights, scale / shift, 1x1
+    // fragments and w2_inv tables of the heads are concatenated along N (CoutPad = sum of the heads' hidden widths); N
+    // tile tn belongs to head g = tn / fuse_gtiles, whose final maps have fuse_gc2[g] channels and whose slabs start at
+    // plane fuse_gbase[g] of fuse_out ([plane][M]; head g owns fuse_gtiles * fuse_gc2[g] planes, slice-major).
+    // fuse_ngroups == 0: one head, fuse_c2 channels, planes from 0 (the layout above).
+    int fuse_ngroups, fuse_gtiles;
+    int fuse_gc2[CP_MAX_HEAD_GROUP];
+    int fuse_gbase[CP_MAX_HEAD_GROUP];
     // ---- range-safe split-f16 arithmetic (f16x3 kernels) ----
     // Binary16 only has 5 exponent bits, so the hi/lo split is exact to 2^-21 only while the operand sits well inside
     // the normal range.  Both operands are therefore pre-scaled by exact powers of two: weights per output channel at
@@ -218,6 +227,14 @@ int cp_launch_conv16_fused_head(const ConvParams& p, hipStream_t stream);
 int cp_launch_pack_head_w2(const float* w1, void* hi, void* lo, float* w2_inv, int C2, int Chid, hipStream_t s);
 int cp_launch_head_reduce(const float* slabs, const float* bias, float* out_nchw, int slices, int C2, int B, int HW,
                           int sigmoid, hipStream_t s);
+// the same for a group of heads in one launch: head g reads planes base[g] .. base[g] + slices * c2[g] of `slabs`
+struct HeadReduceGroup {
+    int n, slices;
+    int c2[CP_MAX_HEAD_GROUP], base[CP_MAX_HEAD_GROUP], sigmoid[CP_MAX_HEAD_GROUP];
+    const float* bias[CP_MAX_HEAD_GROUP];
+    float* out[CP_MAX_HEAD_GROUP];
+};
+int cp_launch_head_reduce_grouped(const float* slabs, const HeadReduceGroup& g, int B, int HW, hipStream_t s);
 int cp_launch_conv16_gru(const ConvParams& p, hipStream_t stream);
 #define CP_VARIANT_FUSED_HEAD 22
 // direct low-channel convolutions of the network's first three layers in f16x3 mode (lowc.hip).

@@ -131,7 +131,7 @@ int g_default_precision = CP_PREC_F32;
 // split-K policy: launches with fewer output tiles than kSplitTiles (and >= 8 K steps) are cut into K slices until
 // about kSplitTarget workgroups exist
 constexpr int kSplitTiles = 128, kSplitTarget = 384;  // (384 / 512 measured: B=32 equal, hourglass B=1 latency +7 %)
-int g_dbg = 0;  // cp_set_debug (A/B switches for tests and tuning): 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel, 256 unfused ConvGRU step, 512 no activation |max| tracking / pre-scale, 1024 previous DCN loop, 2048 alternative DCN wave counts, 4096 / 8192 halo kernel never / everywhere, 16384 LDS-staged weights in the N=32 halo kernel, 32768 / 65536 patch-resident DCN never / everywhere, 131072 GroupNorm'd heads' 1x1 on the matrix cores, 4194304 1x1 layers on the LDS-staged loop instead of pw16.hip
+int g_dbg = 0;  // cp_set_debug (A/B switches for tests and tuning): 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel, 256 unfused ConvGRU step, 512 no activation |max| tracking / pre-scale, 1024 previous DCN loop, 2048 alternative DCN wave counts, 4096 / 8192 halo kernel never / everywhere, 16384 LDS-staged weights in the N=32 halo kernel, 32768 / 65536 patch-resident DCN never / everywhere, 131072 GroupNorm'd heads' 1x1 on the matrix cores, 4194304 1x1 layers on the LDS-staged loop instead of pw16.hip, 8388608 cp_dcnv2_forward always on the generic kernel, 16777216 fused heads one launch per head instead of one grouped launch
 
 struct DeformW {
     ConvW offset;  // conv_offset_mask (27 -> 32 padded), shift = bias
@@ -162,6 +162,19 @@ struct cp_model {
     std::map<std::string, DeformW> deforms;
     std::map<std::string, float*> ups;
     std::vector<HeadW> headw;
+    // every fused head of the model in ONE launch (they all read the same feature map): the heads' 3x3 fragments,
+    // scale / shift, 1x1 fragments and w2_inv tables concatenated along N (ConvParams::fuse_ngroups)
+    struct HeadGroup {
+        bool ok = false;
+        void* w16f_hi = nullptr;
+        void* w16f_lo = nullptr;
+        void* w2_hi = nullptr;
+        void* w2_lo = nullptr;
+        float* scale16 = nullptr;
+        float* shift = nullptr;
+        float* w2_inv = nullptr;
+        int Cin = 0, hid = 0, Kpad16 = 0;
+    } head_group;
     std::map<std::string, LowcW> lowc;  // hi / lo weight fragments of the lowc.hip layers
     ConvW gru_x, gru_h;
     void* gru_h16_hi = nullptr;  // hidden-side GRU weights re-ordered [tile][r|z|n][32] for the fused-gate kernel
@@ -447,6 +460,44 @@ struct Packer {
             }
             m->headw.push_back(hw);
         }
+        group_heads();
+    }
+
+    // concatenate the fused heads' operands for the grouped launch (all heads must be fusable and of one shape)
+    void group_heads() {
+        auto& g = m->head_group;
+        const size_t n = m->headw.size();
+        if (n < 2 || n > CP_MAX_HEAD_GROUP || status != CP_OK) return;
+        const ConvW& c = m->headw[0].c0;
+        for (const HeadW& h : m->headw)
+            if (!h.w2_hi || !h.w2_lo || !h.w2_inv || !h.c0.w16f_hi || !h.c0.w16f_lo || !h.c0.scale16 || !h.c0.shift ||
+                h.c0.Cin != c.Cin || h.c0.CoutPad != c.CoutPad || h.c0.Cout != c.CoutPad || h.c0.Kpad16 != c.Kpad16 ||
+                h.c0.KH != 3 || h.c0.KW != 3 || c.CoutPad % 128 != 0)
+                return;
+        const size_t wbytes = (size_t)c.CoutPad * c.Kpad16 * 2, w2bytes = (size_t)c.CoutPad * 32 * 2;
+        g.w16f_hi = dev_alloc(n * wbytes / 4, false);
+        g.w16f_lo = dev_alloc(n * wbytes / 4, false);
+        g.w2_hi = dev_alloc(n * w2bytes / 4, false);
+        g.w2_lo = dev_alloc(n * w2bytes / 4, false);
+        g.scale16 = dev_alloc(n * c.CoutPad, false);
+        g.shift = dev_alloc(n * c.CoutPad, false);
+        g.w2_inv = dev_alloc(n * 64, false);
+        if (!g.w16f_hi || !g.w16f_lo || !g.w2_hi || !g.w2_lo || !g.scale16 || !g.shift || !g.w2_inv) return;
+        for (size_t i = 0; i < n; ++i) {
+            const HeadW& h = m->headw[i];
+            const auto d2d = hipMemcpyDeviceToDevice;
+            hip_ok(hipMemcpy((char*)g.w16f_hi + i * wbytes, h.c0.w16f_hi, wbytes, d2d));
+            hip_ok(hipMemcpy((char*)g.w16f_lo + i * wbytes, h.c0.w16f_lo, wbytes, d2d));
+            hip_ok(hipMemcpy((char*)g.w2_hi + i * w2bytes, h.w2_hi, w2bytes, d2d));
+            hip_ok(hipMemcpy((char*)g.w2_lo + i * w2bytes, h.w2_lo, w2bytes, d2d));
+            hip_ok(hipMemcpy(g.scale16 + i * c.CoutPad, h.c0.scale16, (size_t)c.CoutPad * 4, d2d));
+            hip_ok(hipMemcpy(g.shift + i * c.CoutPad, h.c0.shift, (size_t)c.CoutPad * 4, d2d));
+            hip_ok(hipMemcpy(g.w2_inv + i * 64, h.w2_inv, 64 * 4, d2d));
+        }
+        g.Cin = c.Cin;
+        g.hid = c.CoutPad;
+        g.Kpad16 = c.Kpad16;
+        g.ok = status == CP_OK;
     }
 
     // weight fragments for the direct low-channel kernels (f16x3 mode); the folded BatchNorm comes from the ConvW
@@ -579,6 +630,7 @@ struct Packer {
             }
             m->headw.push_back(hw);
         }
+        if (!m->gru) group_heads();
     }
 };
 
@@ -714,6 +766,88 @@ struct Fwd {
             r.bytes = 4.0 * ((double)B * x.H * x.W * w.Cin + M * hw.classes + (double)w.KH * w.KW * w.Cin * w.Cout +
                              (double)w.Cout * hw.classes);
             r.M = (int)M; r.N = w.Cout; r.K = w.KH * w.KW * w.Cin; r.kh = w.KH; r.stride = 1;
+            r.e0 = m->get_event();
+            r.e1 = m->get_event();
+            (void)hipEventRecord(r.e0, s);
+            chk(launch());
+            (void)hipEventRecord(r.e1, s);
+            m->prof.push_back(r);
+        } else {
+            chk(launch());
+        }
+        return true;
+    }
+
+    // every fused head of the model in one launch + one slice reduction (cp_model::head_group); false = nothing launched
+    bool fused_heads_grouped(const Tensor& x, float* const* head_out, int sigmoid_hm) {
+        const auto& g = m->head_group;
+        const int n = (int)m->headw.size();
+        if (!g.ok || m->precision != CP_PREC_F16X3 || m->tap_name || (g_dbg & 32) || (g_dbg & 16777216) || x.C != g.Cin)
+            return false;
+        ConvParams p;
+        std::memset(&p, 0, sizeof(p));
+        p.nsrc = 1;
+        p.src[0] = x.ptr();
+        p.src_c[0] = x.C;
+        p.Cin = x.C;
+        p.B = B;
+        p.H = p.Ho = x.H;
+        p.W = p.Wo = x.W;
+        p.KH = p.KW = 3;
+        p.stride = 1;
+        p.pad = 1;
+        p.K = p.Kpad = p.Kpad16 = g.Kpad16;
+        p.Cout = p.CoutPad = n * g.hid;
+        p.scale = g.scale16;
+        p.shift = g.shift;
+        p.in_amax[0] = x.amax;
+        p.act = CP_ACT_RELU;
+        p.w16f_hi = g.w16f_hi;
+        p.w16f_lo = g.w16f_lo;
+        p.splitk = 1;
+        p.dbg = g_dbg;
+        p.fuse_w2_hi = g.w2_hi;
+        p.fuse_w2_lo = g.w2_lo;
+        p.fuse_w2_inv = g.w2_inv;
+        p.fuse_ngroups = n;
+        p.fuse_gtiles = g.hid / 128;
+        p.fuse_out = (float*)0x1000;  // placeholder for the eligibility check
+        if (!cp_halo16_fused_head_supported(p)) return false;
+        if (B * (x.H / 8) * (x.W / 16) * (p.CoutPad / 128) < kSplitTiles) return false;  // small maps: per-head split-K path
+        HeadReduceGroup rg;
+        std::memset(&rg, 0, sizeof(rg));
+        rg.n = n;
+        rg.slices = p.fuse_gtiles;
+        int planes = 0;
+        double flops = 0.0, bytes = 0.0;
+        const double M = (double)B * x.H * x.W;
+        for (int i = 0; i < n; ++i) {
+            const HeadW& hw = m->headw[i];
+            p.fuse_gc2[i] = rg.c2[i] = hw.classes;
+            p.fuse_gbase[i] = rg.base[i] = planes;
+            planes += p.fuse_gtiles * hw.classes;
+            rg.sigmoid[i] = sigmoid_hm && (hw.name == "hm" || hw.name == "hm_hp");
+            rg.bias[i] = hw.c1.shift;
+            rg.out[i] = m->dry ? nullptr : head_out[i];
+            flops += 2.0 * M * g.hid * (9.0 * g.Cin) + 2.0 * M * hw.classes * (double)g.hid;
+            bytes += 4.0 * (M * hw.classes + 9.0 * g.Cin * g.hid + (double)g.hid * hw.classes);
+        }
+        bytes += 4.0 * M * g.Cin;  // the shared input is read once
+        Tensor slabs = make(planes, x.H, x.W);
+        if (m->dry) return true;
+        p.fuse_out = slabs.ptr();
+        auto launch = [&]() -> int {
+            int rc = cp_launch_halo16_fused_head(p, s);
+            if (rc == CP_OK) rc = cp_launch_head_reduce_grouped(slabs.ptr(), rg, B, x.H * x.W, s);
+            return rc;
+        };
+        if (m->profile) {
+            cp_model::ProfRec r;
+            r.variant = CP_VARIANT_HALO_HEAD;
+            r.role = CP_ROLE_HEAD;
+            r.flops = flops;
+            r.bytes = bytes;
+            r.M = (int)M; r.N = p.CoutPad; r.K = 9 * g.Cin; r.kh = 3; r.stride = 1;
             r.e0 = m->get_event();
             r.e1 = m->get_event();
             (void)hipEventRecord(r.e0, s);
@@ -1035,6 +1169,7 @@ struct Fwd {
                 inter = hg_residual("inters.0", b, 1);
             }
         }
+        if (fused_heads_grouped(cnv, head_out, sigmoid_hm)) return;
         for (size_t i = 0; i < m->headw.size(); ++i) {
             const HeadW& hw = m->headw[i];
             const bool sg = sigmoid_hm && (hw.name == "hm" || hw.name == "hm_hp");
@@ -1210,6 +1345,7 @@ struct Fwd {
 
         // GroupNorm statistics of every head (32 groups x (sum, sumsq) doubles per image = 128 floats per image and head):
         // one block, zeroed by one memset per forward pass instead of one per head
+        if (!m->gru && fused_heads_grouped(feat, head_out, sigmoid_hm)) return;
         Tensor stats_all;
         if (m->gru) {
             stats_all = make(128 * (int)m->headw.size(), 1, 1);

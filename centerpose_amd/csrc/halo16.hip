@@ -56,8 +56,15 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar register
     const int wm = wid / WN, wn = wid % WN;
     const int tile = tile_of_block(tiles_m, tiles_n);
-    const int tn = tile % tiles_n;
+    int tn = tile % tiles_n;
     int tm = tile / tiles_n;
+    if (EPI == 1 && p.fuse_ngroups > 0) {
+        // several heads in one launch: head slowest, so that an XCD's contiguous run of tiles walks one head's weights
+        // (0.6 MB) at a time instead of cycling through all of them (> its 4 MB L2); inside a head, n fastest as above
+        const int per = tiles_m * p.fuse_gtiles, g = tile / per, rem = tile - g * per;
+        tn = g * p.fuse_gtiles + rem % p.fuse_gtiles;
+        tm = rem / p.fuse_gtiles;
+    }
     const int txs = p.W / TW, tys = p.H / TH;
     const int tx0 = (tm % txs) * TW;
     tm /= txs;
@@ -261,6 +268,10 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
     if constexpr (EPI == 1) {
         // ---- fused prediction head (the arithmetic of igemm16.hip's FUSE epilogue on this kernel's pixel order) ----
         const int M = p.B * p.H * p.W;
+        // head of this N tile (several heads in one launch: ConvParams::fuse_ngroups), its channel count and first plane
+        const int hg = p.fuse_ngroups > 0 ? tn / p.fuse_gtiles : 0;
+        const int c2 = p.fuse_ngroups > 0 ? p.fuse_gc2[hg] : p.fuse_c2;
+        const int plane0 = p.fuse_ngroups > 0 ? p.fuse_gbase[hg] + (tn - hg * p.fuse_gtiles) * c2 : tn * p.fuse_c2;
         const u32x4* w2h = reinterpret_cast<const u32x4*>(p.fuse_w2_hi) + (size_t)((tn * WN + wn) * 4) * 64 + lane_e;
         const u32x4* w2l = reinterpret_cast<const u32x4*>(p.fuse_w2_lo) + (size_t)((tn * WN + wn) * 4) * 64 + lane_e;
         h8 wh[2][2], wl[2][2];
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
         float* red = reinterpret_cast<float*>(patch_hi);  // [wm][i][r][lane]: 16 KB of the 23 KB plane
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float wi = (p.fuse_w2_inv ? p.fuse_w2_inv[F::row(r, lane_e)] : 1.f) * hinv;
+            const float wi = (p.fuse_w2_inv ? p.fuse_w2_inv[hg * 64 + F::row(r, lane_e)] : 1.f) * hinv;
             acc2[0][r] *= wi;
             acc2[1][r] *= wi;
         }
@@ -344,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
                 for (int r = 0; r < 16; ++r) {
                     const int c = F::row(r, lane_e);
                     const float v = acc2[i][r] + red[((wm * 2 + i) * 16 + r) * 64 + lane_e];
-                    if (c < p.fuse_c2) p.fuse_out[((size_t)tn * p.fuse_c2 + c) * M + m] = v;
+                    if (c < c2) p.fuse_out[((size_t)plane0 + c) * M + m] = v;
                 }
             }
         }

@@ -906,6 +906,27 @@ __global__ void head_reduce_kernel(const float* __restrict__ slabs, const float*
     }
 }
 
+// the same reduction for every head of a grouped launch (blockIdx.y = head)
+__global__ void head_reduce_grouped_kernel(const float* __restrict__ slabs, const HeadReduceGroup g, int B, int HW) {
+    const int h = blockIdx.y;
+    const int C2 = g.c2[h], slices = g.slices;
+    const float* __restrict__ sl = slabs + (size_t)g.base[h] * B * HW;
+    const float* __restrict__ bias = g.bias[h];
+    float* __restrict__ out = g.out[h];
+    const bool sigmoid = g.sigmoid[h] != 0;
+    const size_t M = (size_t)B * HW, total = M * C2;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i / M);
+        const size_t m = i - (size_t)c * M;
+        float acc = 0.f;
+        for (int z = 0; z < slices; ++z) acc += sl[((size_t)z * C2 + c) * M + m];
+        float y = acc + (bias ? bias[c] : 0.f);
+        if (sigmoid) y = 1.f / (1.f + expf(-y));
+        const size_t b = m / HW, pix = m - b * HW;
+        out[(b * C2 + c) * HW + pix] = y;
+    }
+}
+
 // pack PyTorch [Cout][Cin][taps] float32 weights into split binary16 [CoutPad][Kpad16] (k = tap*Cin + ci)
 __global__ void pack_weight16_kernel(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                      int Cout, int Cin, int taps, int Kpad16, int coff, const float* __restrict__ fwd) {
@@ -1103,6 +1124,16 @@ int cp_launch_head_reduce(const float* slabs, const float* bias, float* out_nchw
     if (g > 65536) g = 65536;
     hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, slabs, bias, out_nchw, slices, C2, B, HW,
                        sigmoid);
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}
+
+int cp_launch_head_reduce_grouped(const float* slabs, const HeadReduceGroup& g, int B, int HW, hipStream_t s) {
+    if (g.n < 1 || g.n > CP_MAX_HEAD_GROUP) return CP_ERR_INVALID;
+    int cmax = 1;
+    for (int h = 0; h < g.n; ++h) cmax = g.c2[h] > cmax ? g.c2[h] : cmax;
+    size_t gx = ((size_t)B * HW * cmax + 255) / 256;
+    if (gx > 16384) gx = 16384;
+    hipLaunchKernelGGL(head_reduce_grouped_kernel, dim3((unsigned)gx, g.n), dim3(256), 0, s, slabs, g, B, HW);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 

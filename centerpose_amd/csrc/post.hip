@@ -205,7 +205,9 @@ __global__ void pnp_assemble_kernel(const double* __restrict__ post, const int* 
             P[2 * v + 1] = live ? (float)r[31 + 2 * v] : -10000.f;
         }
     }
-    for (int d = 0; d < 3; ++d) scale[(size_t)i * 3 + d] = live ? (float)r[2 + d] : 1.f;
+    // relative size as the reference forms it (cuboid_pnp_shell.py:12: scale / scale[1]) and as the host path hands it to
+    // cp_pnp_solve: the float64 quotient of the float32-valued fields, rounded to float32
+    for (int d = 0; d < 3; ++d) scale[(size_t)i * 3 + d] = live ? (float)(r[2 + d] / r[3]) : 1.f;
     for (int d = 0; d < 4; ++d) cam[(size_t)i * 4 + d] = cam_img[(size_t)b * 4 + d];
 }
 
