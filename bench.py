@@ -377,33 +377,55 @@ def track_e2e_leg(device, precision, n_videos, frames, warmup):
             "trans_output": get_affine_transform(c, s, 0, [128, 128]), "camera_matrix": K}
     vids = [torch.cat([synth.frames(min(8, n_videos - i), seed=4000 + 100 * f + i) for i in range(0, n_videos, 8)]).to(device)
             for f in range(4)]  # four distinct frames per video, cycled
-    bt = BatchedTracking(det, n_videos)
-    n_tracks = 0
+    # Objectron-shaped load: a handful of objects per video (the dataset caps at max_objs = 10).  The random-init network
+    # scores ~55 peaks per frame above 0.1, so the thresholds are set to the score that keeps about 4 per video.
     with contextlib.redirect_stdout(io.StringIO()):
-        for f in range(warmup + frames):
-            if f == warmup:
-                torch.cuda.synchronize()
-                bt.times = {k: 0 if k == "steps" else 0.0 for k in bt.times}
-                t0 = time.perf_counter()
-            outs = bt.step(vids[f % 4], [dict(meta, id=f) for _ in range(n_videos)])
-            n_tracks = sum(len(x["results"]) for x in outs)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    t = bt.times
-    tot = t["host_records"] + t["device"] + t["host_tracks"]
+        det._skip_host_dets = True
+        det.process(vids[0], vids[0], torch.zeros(n_videos, 1, 512, 512, device=device),
+                    torch.zeros(n_videos, 8, 512, 512, device=device), None)
+        det._skip_host_dets = False
+    scores = det.raw_dets[..., 4].flatten().sort(descending=True).values
+    thr = float(scores[min(4 * n_videos, scores.numel() - 1)])
+    o.vis_thresh = o.pre_thresh = o.new_thresh = o.track_thresh = thr
+    metas = lambda f: [dict(meta, id=f) for _ in range(n_videos)]
+    res = {}
+    for mode in ("host", "device"):
+        bt = BatchedTracking(det, n_videos, device_tracker=(mode == "device"))
+        n_tracks = 0
+        with contextlib.redirect_stdout(io.StringIO()):
+            for f in range(warmup + frames):
+                if f == warmup:
+                    torch.cuda.synchronize()
+                    bt.times = {k: 0 if k == "steps" else 0.0 for k in bt.times}
+                    t0 = time.perf_counter()
+                outs = bt.step(vids[f % 4], metas(f), read=(mode == "host"))
+                if outs is not None:
+                    n_tracks = sum(len(x["results"]) for x in outs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t = bt.times
+        tot = t["host_records"] + t["device"] + t["host_tracks"]
+        res[mode] = {"frames_per_sec": round(n_videos * frames / dt, 2), "ms_per_step": round(dt / frames * 1e3, 3),
+                     "ms_device_stages": round(t["device"] / frames * 1e3, 3),
+                     "ms_host_records": round(t["host_records"] / frames * 1e3, 3),
+                     "ms_host_tracker": round(t["host_tracks"] / frames * 1e3, 3),
+                     "host_fraction": round((t["host_records"] + t["host_tracks"]) / tot, 4)}
+        if mode == "host":
+            res[mode]["tracks_alive_last_frame"] = n_tracks
+        else:
+            res[mode]["tracks_alive_last_frame"] = sum(len(a) for a in bt.dev.read())
+        del bt
     out = {"workload": WORKLOAD_TEXT["track_e2e"] % n_videos, "precision": precision,
-           "value": round(n_videos * frames / dt, 2), "unit": "frames/sec (all videos)", "steps": frames, "warmup": warmup,
-           "ms_per_step": round(dt / frames * 1e3, 3),
-           "ms_device_stages": round(t["device"] / frames * 1e3, 3),
-           "ms_host_records": round(t["host_records"] / frames * 1e3, 3),
-           "ms_host_tracker": round(t["host_tracks"] / frames * 1e3, 3),
-           "host_fraction": round((t["host_records"] + t["host_tracks"]) / tot, 4),
-           "tracks_alive_last_frame": n_tracks,
-           "note": "host = Gaussian-record building from the tracks, detection dicts, Gaussian fusion, pnp_shell packaging, "
-                   "Tracker.step (32-state Kalman filter per track, scale pool, one cp_pnp_solve round trip per track for "
-                   "the filtered vertices); device = render + two-frame network + decode + post-process + PnP incl. the "
-                   "copy of the results to the host"}
-    del bt, det
+           "value": res["device"]["frames_per_sec"], "unit": "frames/sec (all videos)", "steps": frames, "warmup": warmup,
+           "ms_per_step": res["device"]["ms_per_step"], "host_fraction": res["device"]["host_fraction"],
+           "detection_threshold": round(thr, 4),
+           "device_tracker": res["device"], "host_tracker": res["host"],
+           "note": "device_tracker: render of the previous tracks + two-frame network + decode + post-process + PnP + "
+                   "cp_track_step (fusion, association, Kalman filter, scale pool, filtered PnP, next frame's Gaussian "
+                   "records) as one launch sequence, no host work inside a step (the tracks stay in HBM); host_tracker: the "
+                   "same loop with the reference-shaped Python Tracker per video (Gaussian-record building, detection "
+                   "dicts, fusion, pnp_shell packaging, Tracker.step with one cp_pnp_solve round trip per track)"}
+    del det
     torch.cuda.empty_cache()
     return out
 

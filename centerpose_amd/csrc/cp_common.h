@@ -325,3 +325,10 @@ int cp_launch_postprocess(const float* det, int B, int K, const double* meta, do
 int cp_launch_pnp_assemble(const double* post, const int* count, int B, int K, int npts, const double* cam_img, float* pts,
                            float* scale, double* cam, hipStream_t s);
 int cp_launch_render_gaussians(const double* recs, int N, float* out, int C, int H, int W, hipStream_t s);
+
+// ---- CenterPoseTrack bookkeeping on the device (track.hip; TrackParams: track_common.h) ----
+struct TrackParams;
+size_t cp_track_state_bytes_impl(int B, int cap);
+size_t cp_track_ws_bytes_impl(int B, int K, int cap);
+int cp_launch_track_step(hipStream_t s, const TrackParams& P, const double* vmeta, const double* post, const int* count,
+                         const double* det_pnp, int B, int K, void* state, double* recs, void* ws);

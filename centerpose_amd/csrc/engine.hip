@@ -15,7 +15,9 @@
 #undef CP_ERR_STATE
 #undef CP_DET_STRIDE
 #undef CP_PNP_STRIDE
+#undef CP_TRACK_STRIDE
 #include "cp_common.h"
+#include "track_common.h"
 
 #include <cmath>
 #include <cstdio>
@@ -1905,6 +1907,40 @@ int cp_pnp_from_post(cp_stream_t stream, const double* post, const int* count, i
     if (rc != CP_OK) return fail(rc, "pnp assemble launch failed");
     rc = cp_launch_pnp((hipStream_t)stream, pts, scale, camn, (int)n, npts, out, w);
     return rc == CP_OK ? CP_OK : fail(rc, "pnp launch failed");
+}
+
+static_assert(sizeof(cp_track_params) == sizeof(TrackParams), "cp_track_params mirrors TrackParams field by field");
+
+size_t cp_track_state_bytes(int B, int cap) {
+    return (B >= 1 && cap >= 1 && cap <= CP_TRACK_CAP) ? cp_track_state_bytes_impl(B, cap) : 0;
+}
+
+size_t cp_track_workspace_bytes(int B, int K, int cap) {
+    return (B >= 1 && K >= 1 && K <= 128 && cap >= 1 && cap <= CP_TRACK_CAP) ? cp_track_ws_bytes_impl(B, K, cap) : 0;
+}
+
+int cp_track_reset(cp_stream_t stream, void* state, int B, int cap) {
+    const size_t n = cp_track_state_bytes(B, cap);
+    if (!state || n == 0) return fail(CP_ERR_INVALID, "cp_track_reset: bad argument");
+    return hipMemsetAsync(state, 0, n, (hipStream_t)stream) == hipSuccess ? CP_OK : fail(CP_ERR_LAUNCH, "memset failed");
+}
+
+int cp_track_step(cp_stream_t stream, const cp_track_params* params, const double* vmeta, const double* post, const int* count,
+                  const double* det_pnp, int B, void* state, double* render_recs, void* workspace, size_t workspace_bytes) {
+    if (!params || !vmeta || !post || !count || !state || !render_recs || !workspace || B < 1)
+        return fail(CP_ERR_INVALID, "cp_track_step: null argument");
+    TrackParams P;
+    std::memcpy(&P, params, sizeof(P));
+    if (P.K < 1 || P.K > 128 || P.cap < 1 || P.cap > CP_TRACK_CAP)
+        return fail(CP_ERR_INVALID, "cp_track_step: K must be in [1, 128] and cap in [1, CP_TRACK_CAP]");
+    if (!P.kalman && !P.scale_pool)
+        return fail(CP_ERR_INVALID, "cp_track_step: needs opt.kalman and / or opt.scale_pool (host tracker otherwise)");
+    if (P.use_pnp && !det_pnp) return fail(CP_ERR_INVALID, "cp_track_step: use_pnp needs the detections' PnP rows");
+    if (P.cat_rule < 0 || P.cat_rule > 2) return fail(CP_ERR_INVALID, "cp_track_step: cat_rule must be 0, 1 or 2");
+    if (workspace_bytes < cp_track_workspace_bytes(B, P.K, P.cap)) return fail(CP_ERR_INVALID, "workspace too small");
+    const int rc = cp_launch_track_step((hipStream_t)stream, P, vmeta, post, count, P.use_pnp ? det_pnp : nullptr, B, P.K,
+                                        state, render_recs, workspace);
+    return rc == CP_OK ? CP_OK : fail(rc, "cp_track_step: launch failed");
 }
 
 size_t cp_decode_workspace_bytes(int B, int K) { return cp_decode_ws_bytes(B, 8, K); }

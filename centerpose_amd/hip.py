@@ -15,12 +15,20 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CENTERPOSE_HIP_LIB") or os.path.join(_HERE, "libcenterpose_hip.so")
 
 _lib = None
-ABI_VERSION = 3  # CP_ABI_VERSION of include/centerpose_hip.h this binding was written against
+ABI_VERSION = 4  # CP_ABI_VERSION of include/centerpose_hip.h this binding was written against
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
 c_size_t = ctypes.c_size_t
 c_char_p = ctypes.c_char_p
+
+
+class TrackParams(ctypes.Structure):
+    """cp_track_params of include/centerpose_hip.h (field for field)."""
+    _fields_ = [(n, ctypes.c_double) for n in ("new_thresh", "pre_thresh", "R", "conf_lo", "conf_hi")] + \
+               [(n, ctypes.c_int) for n in ("max_age", "kalman", "scale_pool", "use_pnp", "hps_uncertainty", "show_axes",
+                                            "cat_rule", "render_hm_mode", "render_hmhp_mode", "pre_hm", "pre_hm_hp", "K",
+                                            "cap")]
 
 
 def _sig(fn, restype, *argtypes):
@@ -84,6 +92,11 @@ def lib():
     _sig(L.cp_pnp_from_post_workspace_bytes, c_size_t, c_int, c_int)
     _sig(L.cp_pnp_from_post, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t)
     _sig(L.cp_pnp_solve, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t)
+    _sig(L.cp_track_state_bytes, c_size_t, c_int, c_int)
+    _sig(L.cp_track_workspace_bytes, c_size_t, c_int, c_int, c_int)
+    _sig(L.cp_track_reset, c_int, c_void_p, c_void_p, c_int, c_int)
+    _sig(L.cp_track_step, c_int, c_void_p, ctypes.POINTER(TrackParams), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+         c_void_p, c_void_p, c_size_t)
     if L.cp_abi_version() != ABI_VERSION:
         raise RuntimeError("centerpose_amd: %s has ABI version %d, this binding was written for %d (rebuild the library)"
                            % (LIB_PATH, L.cp_abi_version(), ABI_VERSION))
@@ -99,7 +112,8 @@ def exported_symbols():
             "cp_decode_workspace_bytes", "cp_decode", "cp_pnp_workspace_bytes", "cp_pnp_solve", "cp_model_profile", "cp_model_profile_read",
             "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug", "cp_preprocess", "cp_postprocess_workspace_bytes", "cp_postprocess", "cp_render_gaussians",
             "cp_model_profile_roles", "cp_role_name", "cp_pnp_from_post_workspace_bytes", "cp_pnp_from_post", "cp_resize_u8",
-            "cp_abi_version", "cp_num_kernel_variants", "cp_num_roles"]
+            "cp_abi_version", "cp_num_kernel_variants", "cp_num_roles", "cp_track_state_bytes", "cp_track_workspace_bytes",
+            "cp_track_reset", "cp_track_step"]
 
 
 def _check(rc, what):
@@ -399,6 +413,136 @@ class PoseStage(object):
         b, d = self._timed[-1]
         d.synchronize()
         return b.elapsed_time(d)
+
+
+TRACK_STRIDE = 520
+TRACK_CAP = 128
+TRACK_FIELDS = OrderedDict([  # field -> (offset, width) inside a device track record (include/centerpose_hip.h)
+    ("tracking_id", (0, 1)), ("age", (1, 1)), ("active", (2, 1)), ("flags", (3, 1)), ("post", (4, 120)),
+    ("kps_fusion_mean", (124, 16)), ("kps_fusion_std", (140, 16)), ("location", (156, 3)), ("quaternion_xyzw", (159, 4)),
+    ("projected_cuboid", (163, 16)), ("kps_pnp", (179, 18)), ("kps_3d_cam", (197, 27)), ("kps_ori", (224, 18)),
+    ("kf_x", (242, 32)), ("kf_P", (274, 128)), ("kps_mean_kf", (409, 16)), ("kps_std_kf", (425, 16)),
+    ("obj_scale_kf", (441, 3)), ("obj_scale_uncertainty_kf", (444, 3)), ("conf", (447, 8)), ("kps_pnp_kf", (455, 18)),
+    ("kps_3d_cam_kf", (473, 27)), ("kps_ori_kf", (500, 18))])
+
+
+def track_params_from_opt(opt, K=100, cap=TRACK_CAP):
+    """cp_track_params for a reference ``opt`` (opts.py:242-300); raises for what only the host tracker does."""
+    if getattr(opt, "hungarian", False):
+        raise RuntimeError("device tracker: greedy association only (opt.hungarian stays on lib/utils/tracker.py)")
+    if not getattr(opt, "tracking_task", False) or not (opt.kalman or opt.scale_pool):
+        raise RuntimeError("device tracker: tracking_task with kalman and / or scale_pool (demo.py:117-129)")
+    if getattr(opt, "gt_pre_hm_hmhp", False) or getattr(opt, "gt_pre_hm_hmhp_first", False) or getattr(opt, "empty_pre_hm", False):
+        raise RuntimeError("device tracker: ground-truth / empty previous heat-maps are host-only modes")
+    cat = {"camera": 0, "bottle": 0, "cup": 0, "book": 1, "chair": 1, "cereal_box": 1, "bike": 2, "laptop": 2, "shoe": 2}
+    lo, hi = opt.conf_border[opt.c][0], opt.conf_border[opt.c][1]
+    return TrackParams(new_thresh=opt.new_thresh, pre_thresh=opt.pre_thresh, R=opt.R, conf_lo=lo, conf_hi=hi,
+                       max_age=int(opt.max_age), kalman=int(bool(opt.kalman)), scale_pool=int(bool(opt.scale_pool)),
+                       use_pnp=int(bool(opt.use_pnp)), hps_uncertainty=int(bool(opt.hps_uncertainty)),
+                       show_axes=int(bool(opt.show_axes)), cat_rule=cat[opt.c], render_hm_mode=int(opt.render_hm_mode),
+                       render_hmhp_mode=int(opt.render_hmhp_mode), pre_hm=int(bool(opt.pre_hm)),
+                       pre_hm_hp=int(bool(opt.pre_hm_hp)), K=int(K), cap=int(cap))
+
+
+def track_vmeta(metas):
+    """[B,16] float64 rows of cp_track_step from the ``meta`` dicts of ``pre_process`` (+ 'camera_matrix')."""
+    import numpy as np
+
+    v = np.zeros((len(metas), 16))
+    for b, m in enumerate(metas):
+        v[b, 0:6] = np.asarray(m["trans_input"], np.float64).reshape(-1)
+        v[b, 6:10] = [m["width"], m["height"], m["inp_width"], m["inp_height"]]
+        if "camera_matrix" in m:
+            K = np.asarray(m["camera_matrix"], np.float64)
+            v[b, 10:14] = [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]
+    return v
+
+
+class DeviceTracker(object):
+    """CenterPoseTrack's per-video track tables on the device (cp_track_*): ``step`` consumes the outputs of
+    ``postprocess`` / ``pnp_from_post`` of a frame of B videos, ``render`` draws the next frame's pre_hm / pre_hm_hp from
+    the tracks, ``read`` copies the current lists to the host.  Nothing synchronises except ``read``."""
+
+    def __init__(self, B, params, vmeta, device, inp_h, inp_w):
+        L = lib()
+        self.B, self.P, self.device = int(B), params, device
+        self.K, self.cap = int(params.K), int(params.cap)
+        self.inp_h, self.inp_w = int(inp_h), int(inp_w)
+        self.vmeta = torch.as_tensor(vmeta, dtype=torch.float64).reshape(self.B, 16).contiguous().to(device)
+        n_state, n_ws = L.cp_track_state_bytes(self.B, self.cap), L.cp_track_workspace_bytes(self.B, self.K, self.cap)
+        if n_state == 0 or n_ws == 0:
+            raise RuntimeError("DeviceTracker: unsupported B / K / cap")
+        self.state = torch.empty(n_state, dtype=torch.uint8, device=device)
+        self.ws = torch.empty(n_ws, dtype=torch.uint8, device=device)
+        self.recs = torch.empty(self.B, self.cap, 9, 5, dtype=torch.float64, device=device)
+        self.planes = torch.empty(9 * self.B, self.inp_h, self.inp_w, dtype=torch.float32, device=device)
+        self.hdr_bytes = ((4 + 4 * self.B) * 4 + 255) // 256 * 256
+        self.reset()
+
+    def reset(self):
+        _check(lib().cp_track_reset(_stream(), _ptr(self.state), self.B, self.cap), "cp_track_reset")
+        self.recs[..., 0] = -1.0  # nothing to draw before the first frame
+        self.recs[..., 1:] = 0.0
+
+    def step(self, post, count, det_pnp=None):
+        if not (post.is_cuda and post.dtype == torch.float64 and post.is_contiguous() and tuple(post.shape) ==
+                (self.B, self.K, POST_STRIDE) and count.is_cuda and count.dtype == torch.int32):
+            raise RuntimeError("DeviceTracker.step: post [B,K,120] float64 / count [B] int32 device tensors expected")
+        if det_pnp is not None and not (det_pnp.is_cuda and det_pnp.dtype == torch.float64 and det_pnp.is_contiguous() and
+                                        tuple(det_pnp.shape) == (self.B, self.K, PNP_STRIDE)):
+            raise RuntimeError("DeviceTracker.step: det_pnp must be the [B,K,40] float64 output of pnp_from_post")
+        _check(lib().cp_track_step(_stream(), ctypes.byref(self.P), _ptr(self.vmeta), _ptr(post), _ptr(count), _ptr(det_pnp),
+                                   self.B, _ptr(self.state), _ptr(self.recs), _ptr(self.ws), self.ws.numel()), "cp_track_step")
+
+    def render(self):
+        """-> (pre_hm [B,1,H,W], pre_hm_hp [B,8,H,W]) drawn from the current tracks (views of one plane buffer)."""
+        B, H, W = self.B, self.inp_h, self.inp_w
+        _check(lib().cp_render_gaussians(_stream(), _ptr(self.recs), B * self.cap * 9, _ptr(self.planes), 9 * B, H, W, 1),
+               "cp_render_gaussians")
+        return self.planes[:B].view(B, 1, H, W), self.planes[B:].view(B, 8, H, W)
+
+    def read(self):
+        """Host copy of the current lists: a list of B float64 arrays [n_b, 520] (layout: TRACK_FIELDS)."""
+        import numpy as np
+
+        raw = self.state.cpu().numpy()
+        hdr = raw[: (4 + 4 * self.B) * 4].view(np.int32)
+        tr = raw[self.hdr_bytes:].view(np.float64).reshape(2, self.B, self.cap, TRACK_STRIDE)
+        out = []
+        for b in range(self.B):
+            n, overflow = int(hdr[4 + 4 * b]), int(hdr[4 + 4 * b + 2])
+            if overflow:
+                raise RuntimeError("DeviceTracker: video %d needed more than %d tracks" % (b, self.cap))
+            out.append(tr[int(hdr[0]), b, :n].copy())
+        return out
+
+
+def track_record_to_dict(r, opt=None):
+    """One device track record -> the reference's per-track dict (the keys `Tracker.step` leaves on a track)."""
+    import numpy as np
+
+    d = {}
+    post = r[4:124]
+    for k, (off, w) in POST_FIELDS.items():
+        v = post[off:off + w]
+        d[k] = float(v[0]) if k == "score" else int(v[0]) if k == "cls" else [v[0], v[1]] if k == "ct" else v.copy()
+    flags = int(r[3])
+    d.update(tracking_id=int(r[0]), age=int(r[1]), active=int(r[2]))
+    f = lambda k: r[TRACK_FIELDS[k][0]:TRACK_FIELDS[k][0] + TRACK_FIELDS[k][1]].copy()
+    d["kps_fusion_mean"], d["kps_fusion_std"] = f("kps_fusion_mean"), f("kps_fusion_std")
+    d["kps_mean_kf"], d["kps_std_kf"] = f("kps_mean_kf").reshape(8, 2), list(f("kps_std_kf"))
+    d["obj_scale_kf"], d["obj_scale_uncertainty_kf"] = f("obj_scale_kf"), f("obj_scale_uncertainty_kf")
+    if flags & 1:
+        d["location"], d["quaternion_xyzw"] = list(f("location")), f("quaternion_xyzw")
+        d["projected_cuboid"] = f("projected_cuboid").reshape(8, 2)
+        d["kps_pnp"], d["kps_3d_cam"] = f("kps_pnp").reshape(9, 2), f("kps_3d_cam").reshape(9, 3)
+    if flags & 8:
+        d["kps_ori"] = f("kps_ori").reshape(9, 2)
+    if flags & 2:
+        d["kps_pnp_kf"], d["kps_3d_cam_kf"] = f("kps_pnp_kf").reshape(9, 2), f("kps_3d_cam_kf").reshape(9, 3)
+        d["kps_ori_kf"] = f("kps_ori_kf").reshape(9, 2)
+    d["in_boxes"] = bool(flags & 4)
+    return d
 
 
 class HipModel(object):

@@ -9,6 +9,11 @@ detectors/base_detector.py:390-772).  One ``step`` is the reference's per-frame 
 Per-video state (``Tracker``, previous frame) is exactly the reference's; only the device stages are batched.  The
 wall-clock split between the host stages and the device stages is kept in ``times`` (bench.py --workload track_e2e
 reports the host fraction of a step: SURVEY 8(f) N2's open question).
+
+``device_tracker=True`` moves the host stages to the device as well (cp_track_step, centerpose_amd/csrc/track.hip):
+the track tables of all videos live in HBM, a frame is a fixed launch sequence render -> network -> decode ->
+post-process -> PnP -> track update -> filtered PnP -> records of the next render, and the host only reads the tracks
+when asked to (``step(..., read=True)``).
 """
 import time
 
@@ -20,8 +25,10 @@ from ..utils.tracker import Tracker, Tracker_baseline
 
 
 class BatchedTracking(object):
-    def __init__(self, detector, n_videos):
+    def __init__(self, detector, n_videos, device_tracker=False):
         opt = detector.opt
+        self.device_tracker = bool(device_tracker)
+        self.dev = None
         if not (opt.tracking_task or opt.refined_Kalman):
             raise ValueError("BatchedTracking needs opt.tracking_task or opt.refined_Kalman")
         if opt.device.type != 'cuda':
@@ -37,6 +44,8 @@ class BatchedTracking(object):
     def reset(self):
         for t in self.trackers:
             t.reset()
+        if self.dev is not None:
+            self.dev.reset()
         self.pre_images = None
         self.frames = 0
 
@@ -45,13 +54,58 @@ class BatchedTracking(object):
 
         return _hip.render_gaussians(np.array(recs, np.float64).reshape(-1, 5), C, ih, iw, self.det.opt.device)
 
-    def step(self, images, metas):
+    def _step_device(self, images, metas, read):
+        """The whole frame on the device (cp_track_step); the host builds nothing unless ``read``."""
+        from centerpose_amd import hip as _hip
+
+        det, opt, B = self.det, self.det.opt, self.n
+        t0 = time.time()
+        images = images.to(opt.device)
+        if self.dev is None:
+            if any('pre_dets' in m for m in metas):
+                raise RuntimeError("device tracker: seeding from meta['pre_dets'] is a host-tracker feature")
+            self.dev = _hip.DeviceTracker(B, _hip.track_params_from_opt(opt, K=opt.K), _hip.track_vmeta(metas), opt.device,
+                                          metas[0]['inp_height'], metas[0]['inp_width'])
+        if self.pre_images is None:
+            self.pre_images = images
+        pre_hm = pre_hm_hp = None
+        if opt.pre_hm or opt.pre_hm_hp:
+            hm, hp = self.dev.render()
+            pre_hm = hm if opt.pre_hm else None
+            pre_hm_hp = hp if opt.pre_hm_hp else None
+        det._skip_host_dets = True
+        try:
+            det.process(images, self.pre_images, pre_hm, pre_hm_hp, None)
+        finally:
+            det._skip_host_dets = False
+        rec, cnt, poses = det.post_pnp_device(metas)
+        self.dev.step(rec, cnt, poses)
+        self.pre_images = images
+        self.frames += 1
+        outs = None
+        if read:
+            outs = []
+            for arr in self.dev.read():
+                tracks = [_hip.track_record_to_dict(r) for r in arr]
+                boxes = [(t['kps_pnp_kf'], t['kps_3d_cam_kf'], t['obj_scale'], t['kps_ori_kf'], t) for t in tracks
+                         if t['in_boxes']]
+                outs.append({'results': tracks, 'boxes': boxes})
+        elif opt.device.type == 'cuda':
+            torch.cuda.synchronize()
+        self.times['device'] += time.time() - t0
+        self.times['steps'] += 1
+        return outs
+
+    def step(self, images, metas, read=True):
         """images [B,3,H,W] pre-processed frames (frame t of each video), metas: B meta dicts as ``pre_process`` builds
-        them (+ 'camera_matrix', 'id').  Returns a list of B dicts {'results': tracks, 'boxes': boxes}."""
+        them (+ 'camera_matrix', 'id').  Returns a list of B dicts {'results': tracks, 'boxes': boxes} (``read=False``
+        with the device tracker: None, the tracks stay in HBM)."""
         det, opt = self.det, self.det.opt
         B = self.n
         if images.shape[0] != B or len(metas) != B:
             raise ValueError("expected one frame and one meta per video")
+        if self.device_tracker:
+            return self._step_device(images, metas, read)
         t0 = time.time()
         images = images.to(opt.device)
         first = self.pre_images is None

@@ -120,9 +120,9 @@ class ObjectPoseDetector(BaseDetector):
             results = results[keep]
         return results
 
-    def post_process_merge_device(self, metas):
-        """post_process + merge_outputs of every image of the last ``process`` call in one device launch
-        (cp_postprocess); returns a list of per-image numpy arrays of detection dicts like ``merge_outputs``."""
+    def post_pnp_device(self, metas):
+        """cp_postprocess (+ cp_pnp_from_post) of the last ``process`` call, results left on the device:
+        (records [B,K,120] float64, counts [B] int32, poses [B,K,40] float64 or None)."""
         from centerpose_amd import hip as _hip
         from ..utils.image import get_affine_transform
 
@@ -140,8 +140,17 @@ class ObjectPoseDetector(BaseDetector):
             cams = np.array([[np.asarray(m['camera_matrix'], np.float64)[0, 0], np.asarray(m['camera_matrix'], np.float64)[1, 1],
                               np.asarray(m['camera_matrix'], np.float64)[0, 2], np.asarray(m['camera_matrix'], np.float64)[1, 2]]
                              for m in metas])
-            # enqueued behind the post-process: the single device->host copy below then carries both results
+            # enqueued behind the post-process: a single device->host copy can then carry both results
             self.pnp_dev = _hip.pnp_from_post(rec, cnt, torch.from_numpy(cams).to(rec.device), self.opt.rep_mode)
+        return rec, cnt, self.pnp_dev
+
+    def post_process_merge_device(self, metas):
+        """post_process + merge_outputs of every image of the last ``process`` call in one device launch
+        (cp_postprocess); returns a list of per-image numpy arrays of detection dicts like ``merge_outputs``."""
+        from centerpose_amd import hip as _hip
+
+        B = len(metas)
+        rec, cnt, _ = self.post_pnp_device(metas)
         rec = rec.cpu().numpy()
         cnt = cnt.cpu().numpy()
         f32_fields = ('obj_scale', 'obj_scale_uncertainty', 'kps_displacement_std', 'tracking', 'tracking_hp',

@@ -37,8 +37,8 @@ typedef struct cp_model cp_model;
  * with, so a caller compiled against another revision can refuse to run instead of passing arguments with a stale
  * meaning.  History: 1 = round-1 header; 2 = cp_preprocess takes the FORWARD 2x3 affine as double[6] and inverts it
  * itself (round 1: the inverse as float[6]); 3 = cp_dcnv2_forward accepts every shape of the reference op (generic
- * kernel), cp_num_kernel_variants() / cp_num_roles() size the profile buffers. */
-#define CP_ABI_VERSION 3
+ * kernel), cp_num_kernel_variants() / cp_num_roles() size the profile buffers; 4 = cp_track_* added. */
+#define CP_ABI_VERSION 4
 const char* cp_version(void);
 int cp_abi_version(void);
 const char* cp_last_error(void);
@@ -291,6 +291,52 @@ int cp_pnp_solve(cp_stream_t stream, const float* pts, const float* scale, const
 size_t cp_pnp_from_post_workspace_bytes(int B, int K);
 int cp_pnp_from_post(cp_stream_t stream, const double* post, const int* count, int B, int K, int rep_mode,
                      const double* cam, double* out, void* workspace, size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * CenterPoseTrack bookkeeping for B concurrent videos, on the device -- replaces, per frame, the host-side Python of
+ *   `BaseDetector.run` between `merge_outputs` and the next frame's inputs (detectors/base_detector.py:501-544 Gaussian
+ *   fusion, :547-654 `boxes`, :660-665 `self.tracker.step`, :150-388 which Gaussians `_get_additional_inputs` draws;
+ *   utils/tracker.py:112-302 `Tracker.step`: greedy association, 32-state Kalman filter per track, scale pool, filtered
+ *   PnP; utils/pnp/cuboid_pnp_shell.py:26-91 packaging and visibility rejects).
+ * Supported configuration = the demo's (src/demo.py:117-129): `tracking_task` with `kalman` and / or `scale_pool`,
+ * greedy association (`hungarian` off), no ground-truth seeding; anything else stays on the host mirror
+ * (centerpose_amd/lib/utils/tracker.py).  Per video the state holds at most `cap` (<= CP_TRACK_CAP) tracks.
+ *
+ *   params        HOST struct (opt fields; cat_rule: 0 camera / bottle / cup, 1 book / chair / cereal_box, 2 bike / laptop /
+ *                 shoe -- the visibility reject of cuboid_pnp_shell.py:70-84; K = slots per image of post / det_pnp)
+ *   vmeta         DEVICE float64 [B,16] per video: trans_input 2x3 row-major | width height inp_width inp_height |
+ *                 fx fy cx cy | 2 pad  (the `meta` of base_detector.py:142-147)
+ *   post, count   outputs of cp_postprocess ([B,K,CP_POST_STRIDE] float64, [B] int32)
+ *   det_pnp       DEVICE float64 [B,K,CP_PNP_STRIDE] from cp_pnp_from_post, or NULL when params->use_pnp == 0
+ *   state         DEVICE, cp_track_state_bytes(B, cap) bytes, zeroed by cp_track_reset:
+ *                   int32 hdr[4 + 4 B]: hdr[0] = which half holds the current lists; per video b at hdr[4 + 4 b]:
+ *                   n tracks, last id given out, overflow flag (a frame needed more than cap tracks: results invalid),
+ *                   scratch;  then (256-byte aligned) float64 tracks[2][B][cap][CP_TRACK_STRIDE]
+ *                 track record (doubles): 0 tracking_id | 1 age | 2 active | 3 flags (bit 0 location / quaternion /
+ *                   projected_cuboid / kps_3d_cam / kps_pnp valid, 1 kps_pnp_kf / kps_3d_cam_kf / kps_ori_kf valid, 2 in
+ *                   this frame's `boxes`, 3 kps_ori valid, 4 filter state valid) | 4 the CP_POST_STRIDE detection fields |
+ *                   124 kps_fusion_mean[16] | 140 kps_fusion_std[16] | 156 location[3] | 159 quaternion_xyzw[4] |
+ *                   163 projected_cuboid[16] | 179 kps_pnp[18] | 197 kps_3d_cam[27] | 224 kps_ori[18] | 242 kf.x[32] |
+ *                   274 kf.P as 8 blocks of 4x4 | 402 scale-pool sums[7] | 409 kps_mean_kf[16] | 425 kps_std_kf[16] |
+ *                   441 obj_scale_kf[3] | 444 obj_scale_uncertainty_kf[3] | 447 vertex confidences[8] | 455 kps_pnp_kf[18] |
+ *                   473 kps_3d_cam_kf[27] | 500 kps_ori_kf[18]
+ *   render_recs   DEVICE float64 [B,cap,9,5]: next frame's Gaussians as (plane, x, y, radius, k) records for
+ *                 cp_render_gaussians(recs, B*cap*9, out, C = 9 B, ...): plane b = pre_hm of video b, plane B + 8 b + j =
+ *                 pre_hm_hp[j] of video b; plane -1 = nothing to draw
+ * No host synchronisation; five kernel launches + the batched PnP of the filtered vertices.
+ * ------------------------------------------------------------------------------------------ */
+#define CP_TRACK_STRIDE 520
+#define CP_TRACK_CAP 128
+typedef struct cp_track_params {
+    double new_thresh, pre_thresh, R, conf_lo, conf_hi;
+    int max_age, kalman, scale_pool, use_pnp, hps_uncertainty, show_axes, cat_rule, render_hm_mode, render_hmhp_mode, pre_hm,
+        pre_hm_hp, K, cap;
+} cp_track_params;
+size_t cp_track_state_bytes(int B, int cap);
+size_t cp_track_workspace_bytes(int B, int K, int cap);
+int cp_track_reset(cp_stream_t stream, void* state, int B, int cap);
+int cp_track_step(cp_stream_t stream, const cp_track_params* params, const double* vmeta, const double* post, const int* count,
+                  const double* det_pnp, int B, void* state, double* render_recs, void* workspace, size_t workspace_bytes);
 
 #ifdef __cplusplus
 }

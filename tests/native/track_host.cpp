@@ -1,0 +1,45 @@
+// TEST HARNESS (not product code): the scalar functions of centerpose_amd/csrc/track_common.h compiled for the host with
+// g++, so that the device tracker's logic can be compared with the reference-pinned Python tracker on a machine without a
+// GPU (tests/test_track_logic_cpu.py).  The product runs the same functions inside track.hip's kernels.
+#include "../../centerpose_amd/csrc/track_common.h"
+
+#include <vector>
+
+extern "C" {
+
+int cp_track_host_stride(void) { return CP_TRACK_STRIDE; }
+int cp_track_host_params_bytes(void) { return (int)sizeof(TrackParams); }
+
+// stages 1-3 of one frame of one video.  post [count][120], pnp_rows [count][40] or null, prev [*np][STRIDE] ->
+// next [cap][STRIDE] (returns its length, -1 on overflow), pts [cap][16] float, scale [cap][3] float
+int cp_track_host_update(const TrackParams* P, const double* vm, const double* post, int count, const double* pnp_rows,
+                         const double* prev, int np, int* id_count, double* next, float* pts, float* scale) {
+    std::vector<double> dets((size_t)(count > 0 ? count : 1) * CP_TRACK_STRIDE);
+    std::vector<int> use(count > 0 ? count : 1), idx(count > 0 ? count : 1);
+    std::vector<unsigned char> taken(np > 0 ? np : 1);
+    int any = 0;
+    for (int k = 0; k < count; ++k) {
+        use[k] = trk_prepare_det(*P, vm, post + (size_t)k * 120, pnp_rows ? pnp_rows + (size_t)k * 40 : nullptr,
+                                 dets.data() + (size_t)k * CP_TRACK_STRIDE);
+        any |= use[k];
+    }
+    if (!any)
+        for (int k = 0; k < count; ++k) use[k] = 1;
+    std::vector<int> plan((size_t)3 * (P->cap > 0 ? P->cap : 1));
+    const int n = trk_associate(*P, dets.data(), use.data(), count, prev, np, plan.data(), id_count, idx.data(), taken.data());
+    for (int t = 0; t < n; ++t)
+        trk_materialise(plan.data() + 3 * t, dets.data(), prev, next + (size_t)t * CP_TRACK_STRIDE, 0, CP_TRACK_STRIDE);
+    for (int t = 0; t < n; ++t)
+        trk_track_stage(*P, next + (size_t)t * CP_TRACK_STRIDE, prev, pts + (size_t)t * 16, scale + (size_t)t * 3);
+    return n;
+}
+
+// stage 5: tracks [n][STRIDE] (in place), pnp_rows [n][40] or null, recs [n][9][5]
+void cp_track_host_finish(const TrackParams* P, const double* vm, double* tracks, int n, const double* pnp_rows, int hm_plane,
+                          int hp_plane0, double* recs) {
+    for (int t = 0; t < n; ++t)
+        trk_finish_stage(*P, vm, tracks + (size_t)t * CP_TRACK_STRIDE, pnp_rows ? pnp_rows + (size_t)t * 40 : nullptr,
+                         hm_plane, hp_plane0, recs + (size_t)t * 45);
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+"""The device tracker's logic on the CPU: centerpose_amd/csrc/track_common.h (the scalar functions track.hip's kernels
+run) compiled for the host by tests/native/track_host.cpp and compared, frame by frame, with
+
+* tests/golden/tracker_ref.json -- the REFERENCE's own Tracker.step on a seeded video (greedy association, Kalman
+  read-out, scale pool, coasting, new ids);
+* the reference-pinned Python loop of this repo (lib/detectors/base_detector.py + lib/utils/tracker.py, themselves
+  pinned to the reference's run() by tests/golden/track_run.json) on the CenterPoseTrack video, with PnP: every track
+  field, the `boxes` selection and the Gaussians drawn into the next frame's pre_hm / pre_hm_hp.
+"""
+import contextlib
+import copy
+import ctypes
+import io
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from centerpose_amd import hip
+from centerpose_amd.lib.utils.image import get_affine_transform
+from oracle.tools import make_goldens as mg
+from oracle.tools import track_golden as tg
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+GOLD = os.path.join(REPO, "tests", "golden")
+STRIDE = 520
+TR = dict(ID=0, AGE=1, ACTIVE=2, FLAGS=3, POST=4, FUS_MEAN=124, FUS_STD=140, LOC=156, QUAT=159, PROJ=163, KPS_PNP=179,
+          KPS_3D=197, KPS_ORI=224, KF_X=242, KF_P=274, MEAN_KF=409, STD_KF=425, SCALE_KF=441, SCALE_UNC_KF=444, CONF=447,
+          KPS_PNP_KF=455, KPS_3D_KF=473, KPS_ORI_KF=500)
+
+
+Params = hip.TrackParams   # cp_track_params of include/centerpose_hip.h (same layout as track_common.h's TrackParams)
+
+
+@pytest.fixture(scope="module")
+def host():
+    out = os.path.join(REPO, "tests", "_build", "libcp_track_host.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-ffp-contract=off", os.path.join(REPO, "tests", "native", "track_host.cpp"),
+                    "-o", out], check=True)
+    L = ctypes.CDLL(out)
+    assert L.cp_track_host_stride() == STRIDE
+    assert L.cp_track_host_params_bytes() == ctypes.sizeof(Params)
+    L.cp_track_host_update.restype = ctypes.c_int
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class HostTracker(object):
+    """One video's track table driven through the harness, the PnP in between supplied by `solve(pts, scale) -> rows`."""
+
+    def __init__(self, L, params, vm, solve=None, cap=128):
+        self.L, self.P, self.vm, self.solve, self.cap = L, params, np.ascontiguousarray(vm, np.float64), solve, cap
+        self.P.cap = cap
+        self.prev = np.zeros((cap, STRIDE))
+        self.np_, self.id_count = 0, ctypes.c_int(0)
+
+    def step(self, post, det_rows=None):
+        post = np.ascontiguousarray(post, np.float64).reshape(-1, 120)
+        nxt = np.zeros((self.cap, STRIDE))
+        pts = np.zeros((self.cap, 16), np.float32)
+        sc = np.zeros((self.cap, 3), np.float32)
+        rows = None if det_rows is None else np.ascontiguousarray(det_rows, np.float64)
+        n = self.L.cp_track_host_update(ctypes.byref(self.P), _ptr(self.vm), _ptr(post), len(post), _ptr(rows),
+                                        _ptr(self.prev), self.np_, ctypes.byref(self.id_count), _ptr(nxt), _ptr(pts), _ptr(sc))
+        assert n >= 0
+        kf_rows = None
+        if self.solve is not None and n:
+            kf_rows = np.ascontiguousarray(self.solve(pts[:n].reshape(n, 8, 2), sc[:n]), np.float64)
+        recs = np.zeros((max(n, 1), 9, 5))
+        self.L.cp_track_host_finish(ctypes.byref(self.P), _ptr(self.vm), _ptr(nxt), n, _ptr(kf_rows), 0, 1, _ptr(recs))
+        self.prev, self.np_ = nxt, n
+        return nxt[:n], recs[:n]
+
+
+def _post_from_dict(d, fusion_as_displacement=False):
+    r = np.zeros(120)
+    for k, (off, w) in hip.POST_FIELDS.items():
+        if k in d:
+            r[off:off + w] = np.asarray(d[k], np.float64).reshape(-1)
+    if fusion_as_displacement:  # hand-made detections that only carry the fused estimate: heat-map side "missing"
+        r[64:80] = np.asarray(d["kps_fusion_mean"], np.float64)
+        r[8:24] = np.asarray(d["kps_fusion_std"], np.float64)
+        r[80:96] = -1.0
+    return r
+
+
+def test_tracker_logic_matches_reference_golden(host):
+    with open(os.path.join(GOLD, "tracker_ref.json")) as f:
+        gold = json.load(f)["greedy"]
+    o = mg.TrackOpt(False)
+    P = Params(new_thresh=o.new_thresh, pre_thresh=0.3, R=o.R, conf_lo=3, conf_hi=9, max_age=o.max_age, kalman=1,
+               scale_pool=1, use_pnp=0, hps_uncertainty=1, show_axes=0, cat_rule=0, render_hm_mode=1, render_hmhp_mode=2,
+               pre_hm=1, pre_hm_hp=1, K=100)
+    vm = np.zeros(16)
+    vm[[0, 4]] = 1.0
+    vm[6:10] = 512
+    ht = HostTracker(host, P, vm)
+    for f, dets in enumerate(mg.tracker_frames()):
+        post = np.stack([_post_from_dict(d, True) for d in dets])
+        tracks, _ = ht.step(post)
+        assert len(tracks) == len(gold[f]), f
+        for t, g in zip(tracks, gold[f]):
+            assert (int(t[0]), int(t[1]), int(t[2])) == (g["tracking_id"], g["age"], g["active"]), f
+            np.testing.assert_allclose(t[4 + 28:4 + 30], g["ct"], rtol=1e-12)
+            np.testing.assert_allclose(t[TR["MEAN_KF"]:TR["MEAN_KF"] + 16], g["kps_mean_kf"], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(t[TR["STD_KF"]:TR["STD_KF"] + 16], g["kps_std_kf"], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(t[TR["SCALE_KF"]:TR["SCALE_KF"] + 3], g["obj_scale_kf"], rtol=1e-6)
+            np.testing.assert_allclose(t[TR["SCALE_UNC_KF"]:TR["SCALE_UNC_KF"] + 3], g["obj_scale_uncertainty_kf"], rtol=1e-6)
+    ids = [t[0] for t in tracks]
+    assert len(set(ids)) == len(ids)
+
+
+def _vm(meta):
+    v = np.zeros(16)
+    v[0:6] = np.asarray(meta["trans_input"], np.float64).reshape(-1)
+    v[6:10] = [meta["width"], meta["height"], meta["inp_width"], meta["inp_height"]]
+    K = np.asarray(meta["camera_matrix"], np.float64)
+    v[10:14] = [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]
+    return v
+
+
+def test_tracker_logic_matches_python_loop_with_pnp(host, monkeypatch):
+    """The CenterPoseTrack video of tests/golden/track_run.json through the Python loop (pinned to the reference's
+    run()) and, side by side, through the harness: every frame's detections (captured at `Tracker.step`) -> stages 1-5."""
+    from tests import test_tracking_loop as ttl
+    from centerpose_amd.lib.detectors import base_detector as bd
+    from centerpose_amd.lib.utils.pnp import cuboid_pnp_solver as cps
+
+    det = ttl._detector(monkeypatch, "-1")
+    det.process = ttl._cpu_process(det)
+    monkeypatch.setattr(cps, "solve_pnp_batch", ttl._oracle_pnp_rows)
+    monkeypatch.setattr(bd, "solve_pnp_batch", ttl._oracle_pnp_rows)
+    o = det.opt
+    frames_in = tg.frame_inputs(get_affine_transform)
+    meta0 = frames_in[0][1]
+    Kmat = np.asarray(meta0["camera_matrix"], np.float64)
+
+    def solve(pts, scales):
+        return ttl._oracle_pnp_rows([p for p in pts], [s for s in scales], Kmat)
+
+    P = Params(new_thresh=o.new_thresh, pre_thresh=o.pre_thresh, R=o.R, conf_lo=o.conf_border[o.c][0],
+               conf_hi=o.conf_border[o.c][1], max_age=o.max_age, kalman=int(o.kalman), scale_pool=int(o.scale_pool),
+               use_pnp=int(o.use_pnp), hps_uncertainty=int(o.hps_uncertainty), show_axes=int(o.show_axes), cat_rule=0,
+               render_hm_mode=o.render_hm_mode, render_hmhp_mode=o.render_hmhp_mode, pre_hm=int(o.pre_hm),
+               pre_hm_hp=int(o.pre_hm_hp), K=100)
+    ht = HostTracker(host, P, _vm(meta0), solve)
+    captured = {}
+    real_step = det.tracker.step
+
+    def spy(results, boxes=[]):
+        captured["results"] = copy.deepcopy(list(results))
+        return real_step(results, boxes)
+
+    det.tracker.step = spy
+    n_checked = 0
+    prev_recs = None
+    with contextlib.redirect_stdout(io.StringIO()):
+        for f, (img, meta) in enumerate(frames_in):
+            if prev_recs is not None:
+                # the Gaussians the Python loop is about to draw from its tracks == the harness's records of last frame
+                hm, hp, _ = det._track_records(det.tracker.tracks, dict(meta, id=f), True, True)
+                mine_hm = [tuple(r[0]) for r in prev_recs if r[0, 0] >= 0]
+                mine_hp = [tuple(q) for r in prev_recs for q in r[1:] if q[0] >= 0]
+                assert len(hm) == len(mine_hm) and len(hp) == len(mine_hp), (f, len(hp), len(mine_hp))
+                for a, b in zip(hm, mine_hm):
+                    np.testing.assert_allclose(np.array(a, float), np.array(b), rtol=1e-9)
+                for a, b in zip(hp, mine_hp):
+                    assert int(a[0]) == int(b[0]) - 1 and (a[1], a[2], a[3]) == (b[1], b[2], b[3])
+                    np.testing.assert_allclose(float(a[4]), b[4], rtol=1e-6)
+            ret = det.run(img, meta_inp=copy.deepcopy(meta), preprocessed_flag=True)
+            res = captured["results"]
+            post = np.stack([_post_from_dict(d) for d in res]) if len(res) else np.zeros((0, 120))
+            pts = [det._pnp_points(d) for d in res]
+            scales = [np.asarray(d["obj_scale"], np.float64) / d["obj_scale"][1] for d in res]
+            rows = ttl._oracle_pnp_rows(pts, scales, Kmat) if len(res) else None
+            tracks, recs = ht.step(post, rows)
+            prev_recs = recs
+            assert len(tracks) == len(ret["results"]), f
+            n_box = 0
+            for t, g in zip(tracks, ret["results"]):
+                assert (int(t[0]), int(t[1]), int(t[2])) == (g["tracking_id"], g["age"], g["active"]), f
+                flags = int(t[3])
+                n_box += (flags >> 2) & 1
+                chk = [("MEAN_KF", "kps_mean_kf", 16), ("STD_KF", "kps_std_kf", 16), ("SCALE_KF", "obj_scale_kf", 3),
+                       ("SCALE_UNC_KF", "obj_scale_uncertainty_kf", 3), ("FUS_MEAN", "kps_fusion_mean", 16),
+                       ("FUS_STD", "kps_fusion_std", 16)]
+                if "kps_pnp_kf" in g:
+                    assert flags & 2
+                    chk += [("KPS_PNP_KF", "kps_pnp_kf", 18), ("KPS_3D_KF", "kps_3d_cam_kf", 27), ("KPS_ORI_KF", "kps_ori_kf", 18)]
+                else:
+                    assert not flags & 2
+                if "location" in g:
+                    chk += [("LOC", "location", 3), ("QUAT", "quaternion_xyzw", 4), ("KPS_PNP", "kps_pnp", 18),
+                            ("KPS_3D", "kps_3d_cam", 27)]
+                for name, key, n in chk:
+                    np.testing.assert_allclose(t[TR[name]:TR[name] + n], np.asarray(g[key], np.float64).reshape(-1),
+                                               rtol=1e-6, atol=1e-6, err_msg="frame %d %s" % (f, key))
+                n_checked += 1
+            assert n_box == len(ret["boxes"]), f
+    assert n_checked >= 8

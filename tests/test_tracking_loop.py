@@ -174,10 +174,13 @@ def test_tracking_run_matches_reference_gpu(device, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_batched_tracking_matches_reference_per_video(device, monkeypatch):
-    """BatchedTracking (B concurrent videos: batched render / network / decode / post-process / PnP on the device,
-    the reference's per-video Tracker on the host) must give every video exactly what the reference's ``run()`` gives
-    the single video of tests/golden/track_run.json."""
+@pytest.mark.parametrize("device_tracker", [False, True])
+def test_batched_tracking_matches_reference_per_video(device, monkeypatch, device_tracker):
+    """BatchedTracking (B concurrent videos: batched render / network / decode / post-process / PnP on the device; the
+    per-video track bookkeeping either by the reference-shaped Python Tracker on the host or by cp_track_step on the
+    device) must give every video exactly what the reference's ``run()`` gives the single video of
+    tests/golden/track_run.json: tracks, filter read-outs, filtered poses, `boxes`, and the previous-frame heat-maps the
+    network is fed."""
     import types
 
     from centerpose_amd.lib.detectors.batch_tracking import BatchedTracking
@@ -204,7 +207,7 @@ def test_batched_tracking_matches_reference_per_video(device, monkeypatch):
 
     eng = BatchEngine()
     stub._engine = lambda: eng
-    bt = BatchedTracking(det, B)
+    bt = BatchedTracking(det, B, device_tracker=device_tracker)
     frames = [[] for _ in range(B)]
     with contextlib.redirect_stdout(io.StringIO()):
         for img, meta in tg.frame_inputs(get_affine_transform):
@@ -218,6 +221,59 @@ def test_batched_tracking_matches_reference_per_video(device, monkeypatch):
                 frames[b].append(s)
     for b in range(B):
         _compare(frames[b], gold)
-    assert bt.times["steps"] == len(gold) and bt.times["host_tracks"] > 0
+    assert bt.times["steps"] == len(gold) and (device_tracker or bt.times["host_tracks"] > 0)
     bt.reset()
     assert all(t.tracks == [] for t in bt.trackers) and bt.pre_images is None
+    if device_tracker:
+        assert all(len(a) == 0 for a in bt.dev.read())
+
+
+@pytest.mark.gpu
+def test_device_tracker_matches_reference_tracker_golden(device):
+    """cp_track_step alone (no PnP) on the seeded detections of tests/golden/tracker_ref.json -- the REFERENCE's own
+    Tracker.step: ids, ages, coasting, Kalman read-out and scale pool, for three videos that start one frame apart."""
+    from oracle.tools import make_goldens as mg
+
+    with open(os.path.join(os.path.dirname(GOLD), "tracker_ref.json")) as fh:
+        gold = json.load(fh)["greedy"]
+    o = mg.TrackOpt(False)
+    B, K = 3, 100
+    P = hip.TrackParams(new_thresh=o.new_thresh, pre_thresh=0.3, R=o.R, conf_lo=3, conf_hi=9, max_age=o.max_age, kalman=1,
+                        scale_pool=1, use_pnp=0, hps_uncertainty=1, show_axes=0, cat_rule=0, render_hm_mode=1,
+                        render_hmhp_mode=2, pre_hm=1, pre_hm_hp=1, K=K, cap=hip.TRACK_CAP)
+    vm = np.zeros((B, 16))
+    vm[:, [0, 4]] = 1.0
+    vm[:, 6:10] = 512
+    dt = hip.DeviceTracker(B, P, vm, device, 512, 512)
+    frames = mg.tracker_frames()
+
+    def post_of(dets):
+        post = np.zeros((K, hip.POST_STRIDE))
+        for i, d in enumerate(dets):
+            for k, (off, w) in hip.POST_FIELDS.items():
+                if k in d:
+                    post[i, off:off + w] = np.asarray(d[k], np.float64).reshape(-1)
+            post[i, 64:80] = np.asarray(d["kps_fusion_mean"], np.float64)   # only the fused estimate is given:
+            post[i, 8:24] = np.asarray(d["kps_fusion_std"], np.float64)     # heat-map side "missing"
+            post[i, 80:96] = -1.0
+        return post, len(dets)
+
+    for f in range(len(frames) + B - 1):
+        posts, cnts = [], []
+        for b in range(B):   # video b lags b frames behind and idles (no detections) outside the sequence
+            p, n = post_of(frames[f - b]) if 0 <= f - b < len(frames) else (np.zeros((K, hip.POST_STRIDE)), 0)
+            posts.append(p)
+            cnts.append(n)
+        dt.step(torch.from_numpy(np.stack(posts)).to(device), torch.tensor(cnts, dtype=torch.int32, device=device))
+        lists = dt.read()
+        for b in range(B):
+            if not 0 <= f - b < len(frames):
+                continue
+            g = gold[f - b]
+            assert len(lists[b]) == len(g), (f, b)
+            for t, gt in zip(lists[b], g):
+                assert (int(t[0]), int(t[1]), int(t[2])) == (gt["tracking_id"], gt["age"], gt["active"]), (f, b)
+                np.testing.assert_allclose(t[409:425], gt["kps_mean_kf"], rtol=1e-9, atol=1e-9)
+                np.testing.assert_allclose(t[425:441], gt["kps_std_kf"], rtol=1e-9, atol=1e-9)
+                np.testing.assert_allclose(t[441:444], gt["obj_scale_kf"], rtol=1e-6)
+                np.testing.assert_allclose(t[444:447], gt["obj_scale_uncertainty_kf"], rtol=1e-6)
