@@ -217,7 +217,7 @@ def test_run_batch_at_bench_batch_matches_run_by_value(device, tmp_path):
         # well-posed ones by value (identical inputs give identical poses: test_pnp_from_post_assembly_by_value)
         assert len(single["boxes"]) == len(outs[b]["boxes"])
         sane = [i for i, bx in enumerate(single["boxes"]) if float(np.abs(bx[1]).max()) < 1e3]
-        _boxes_equal([single["boxes"][i] for i in sane], [outs[b]["boxes"][i] for i in sane], 2e-3)
+        _boxes_equal([single["boxes"][i] for i in sane], [outs[b]["boxes"][i] for i in sane], 2e-2)  # ~1 degree
         n_box += len(sane)
         n_res += len(single["results"])
     assert n_res >= B // 4, "the synthetic network must produce detections for this test to mean anything (%d)" % n_res
