@@ -78,7 +78,10 @@ __device__ __forceinline__ f32x2 pk_fma_b(f32x2 w, f32x2 v, f32x2 c) {
     return d;
 }
 
-template <int NT>
+// ABL: timing ablations for tuning (cp_set_debug bits 25..29, tools/dcn_bench.py --dbg; results are wrong when set):
+//   1 << 25 no gather reads (registers reused), 1 << 26 no blend / split arithmetic, 1 << 27 no MFMAs,
+//   1 << 28 no weight-fragment loads, 1 << 29 no staging loads / stores (the patch keeps its zeros)
+template <int NT, bool ABL = false>
 __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lrow = lane >> 5, lcol = lane & 31;
+    const int abl = ABL ? __builtin_amdgcn_readfirstlane(p.dbg >> 25) : 0;
     const int tile = tile_of_block(tiles_m, tiles_n);
     const int tn = tile % tiles_n;
     int tm = tile / tiles_n;
@@ -204,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     // step u of chunk ch = (tap u / 2, 16-channel half u % 2): K step g = tap * (Cin / 16) + 2 ch + (u % 2)
     u32x4 wbh[3][NT], wbl[3][NT];  // register set u % 3 (18 steps per chunk keep the rotation consistent)
     auto issue_b = [&](int set, int g) {
+        if (ABL && (abl & 8)) return;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             wbh[set][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wh, (int)b_voff[j], g * 1024, 0);
@@ -222,6 +227,13 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     auto mma_step = [&](const float4 (&r)[4][2], const f32x2 (&w)[2], const u32x4 (&bh)[NT], const u32x4 (&bl)[NT]) {
         // fma(w4, v4, fma(w3, v3, fma(w2, v2, w1 * v1))) per channel (dcn16.hip's order), two per v_pk_fma_f32
         uint32_t hi[4], lo[4];
+        if (ABL && (abl & 2)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hi[q] = __float_as_uint(r[0][q >> 1].x) ^ __float_as_uint(r[3][q >> 1].y);
+                lo[q] = __float_as_uint(r[1][q >> 1].z) ^ __float_as_uint(r[2][q >> 1].w);
+            }
+        } else
 #pragma unroll
         for (int hq = 0; hq < 2; ++hq) {
             const float4 v1 = r[0][hq], v2 = r[1][hq], v3 = r[2][hq], v4 = r[3][hq];
@@ -238,6 +250,11 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
         }
         const u32x4 ahv = {hi[0], hi[1], hi[2], hi[3]}, alv = {lo[0], lo[1], lo[2], lo[3]};
         const h8 ah = *reinterpret_cast<const h8*>(&ahv), al = *reinterpret_cast<const h8*>(&alv);
+        if (ABL && (abl & 4)) {  // keep the operands alive without the matrix pipe
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[0][j][0] += __uint_as_float(ahv.x ^ alv.y ^ bh[j].x ^ bl[j].y);
+            return;
+        }
         // same term order as igemm16.hip (lo*hi, hi*lo, hi*hi)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -259,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
         const int st_base = ((b * p.H + ty0) * p.W + six) * cb + (tid & 7) * 16;  // row ty0 (always inside the image)
         const int st_lds = spx * PSTR + (tid & 7) * 16;                            // + PW * PSTR per row
         auto gather = [&](float4 (&r)[4][2], int a) {  // a: addr[tap] + 64 (K step % 2)
+            if (ABL && (abl & 1)) return;
             const unsigned char* ap = patch + a;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -273,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
         issue_b(2, 1 * gpt + 0);
         for (int ch = 0; ch < nch; ++ch) {
             if (ch > 0) __syncthreads();  // every wave is done with the previous chunk's patch
-            {
+            if (!(ABL && (abl & 16))) {
                 const int csoff = ch * (CKC * 4);
                 int sb = st_base;
                 asm volatile("" : "+v"(sb));  // per chunk: keeps the 14 row offsets from being hoisted into 14 registers
@@ -321,6 +339,12 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
             }
             __syncthreads();
             float4 raw[2][4][2];
+            if (ABL) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) raw[i][c][0] = raw[i][c][1] = make_float4(1.f, 2.f, 3.f, 4.f);
+            }
             gather(raw[0], addr[0]);
 #pragma unroll
             for (int u = 0; u < NSTEP; ++u) {
@@ -411,7 +435,10 @@ template <int NT>
 int launch_dcn16p(const ConvParams& p, hipStream_t stream) {
     constexpr int BN = 32 * NT;
     const int tiles_m = p.B * (p.H / TH) * (p.W / TW), tiles_n = p.CoutPad / BN;
-    hipLaunchKernelGGL((dcn16p_kernel<NT>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m, tiles_n);
+    if (p.dbg >> 25)
+        hipLaunchKernelGGL((dcn16p_kernel<NT, true>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL((dcn16p_kernel<NT>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m, tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
