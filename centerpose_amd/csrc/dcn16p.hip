@@ -37,6 +37,20 @@
 
 #include "patch16_common.h"
 
+#ifndef CP_DCN_EXP
+#define CP_DCN_EXP 0
+#endif
+#if CP_DCN_EXP & 8
+// tuning build 8: shader-clock stamps of one wave of one mid-launch block at its phase boundaries (tools/dcn_timeline.py)
+__device__ unsigned long long g_dcn_clk[64];
+#define DCN_STAMP(i) do { if (blockIdx.x == 4001 && threadIdx.x == 0) g_dcn_clk[i] = clock64(); } while (0)
+extern "C" int cp_debug_read_dcn_clk(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dcn_clk), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#else
+#define DCN_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int TH = PATCH_TH, TW = PATCH_TW, HALO = 3;
@@ -92,8 +106,25 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     __shared__ int exc_count;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    DCN_STAMP(0);
+#if CP_DCN_EXP & 64
+    // (tuning build 64: the second block of every CU starts half a block lifetime late, so that one block's memory phases
+    // fall into the other's K loop instead of both doing the same thing at the same time)
+#if CP_DCN_EXP & 512
+    if (blockIdx.x < 512) {  // 16 start phases spread over ~ one block lifetime
+        const int k = ((blockIdx.x >> 3) * 7 + (blockIdx.x & 7) * 3) & 15;
+        for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(48);
+    }
+#else
+    if (blockIdx.x < 512 && ((blockIdx.x >> 8) & 1)) {
+#pragma unroll
+        for (int i = 0; i < (CP_DCN_EXP >> 10); ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+#endif
     const int lrow = lane >> 5, lcol = lane & 31;
-    const int abl = ABL ? __builtin_amdgcn_readfirstlane(p.dbg >> 25) : 0;
+    const int abl = ABL ? __builtin_amdgcn_readfirstlane((int)((unsigned)p.dbg >> 25)) : 0;  // bit 5 (1 << 30): variant only;
+                                                                   // bit 6 (1 << 31): no epilogue stores
     const int tile = tile_of_block(tiles_m, tiles_n);
     const int tn = tile % tiles_n;
     int tm = tile / tiles_n;
@@ -101,22 +132,33 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     const int tx0 = (tm % txs) * TW;
     tm /= txs;
     const int ty0 = (tm % tys) * TH, b = tm / tys;
+    constexpr bool EARLY = !(CP_DCN_EXP & 32);  // (tuning build 32: the round-2 prologue, one memory round trip per stage)
     float afwd, ainv;
-    conv_in_scale(p, &afwd, &ainv);
-    // wave-uniform: keep both in scalar registers (the vector file is full)
-    afwd = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(afwd)));
-    ainv = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ainv)));
-
+    if (!EARLY) {
+        conv_in_scale(p, &afwd, &ainv);
+        // wave-uniform: keep both in scalar registers (the vector file is full)
+        afwd = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(afwd)));
+        ainv = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ainv)));
+    }
+    DCN_STAMP(1);  // after the activation-scale read
     const unsigned img_px = (unsigned)p.B * p.H * p.W;
     const __amdgpu_buffer_rsrc_t r_x = make_rsrc(p.src[0], img_px * (unsigned)p.Cin * 4u);
     const __amdgpu_buffer_rsrc_t r_om = make_rsrc(p.offmask, img_px * 128u);
     const unsigned w_bytes = (unsigned)((size_t)p.CoutPad * p.Kpad16 * 2);
     const __amdgpu_buffer_rsrc_t r_wh = make_rsrc(p.w16f_hi, w_bytes), r_wl = make_rsrc(p.w16f_lo, w_bytes);
     const int cb = p.Cin * 4, rowb = p.W * cb;
+    // staging geometry: thread -> (patch column tid / 8 (< PW: 22 of 32 busy), channel quad tid % 8), pass s = patch
+    // row s; one base offset register, the row validity is wave-uniform
+    const int spx = tid >> 3, six = tx0 - HALO + spx;
+    const bool col_ok = spx < PW && (unsigned)six < (unsigned)p.W;
+    const int st_base = ((b * p.H + ty0) * p.W + six) * cb + (tid & 7) * 16;  // row ty0 (always inside the image)
+    const int st_lds = spx * PSTR + (tid & 7) * 16;                            // + PW * PSTR per row
 
     if (tid == 0) exc_count = 0;
     // the spare pixels start as zeros: an exception sample reads its blended value with weights (1, 0, 0, 0), and the three
     // zero-weight "corners" next to it must never be NaN / Inf bit patterns left behind by an earlier kernel
+    const int ablo = ABL ? __builtin_amdgcn_readfirstlane(p.dbg & 7) : 0;  // 1 no record loads, 2 no set-up math, 4 no zeroing
+    if (!(ABL && (ablo & 4)))
     for (int i = tid; i < (NPIX_ALL - NPIX) * (PSTR / 16); i += 256)
         *reinterpret_cast<float4*>(patch + NPIX * PSTR + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
     // ---- this lane's pixel: fragment row lane % 32 of wave w -> patch rows 2 w, 2 w + 1 in the permuted order of
@@ -127,7 +169,12 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     const unsigned rec = (unsigned)((b * p.H + y) * p.W + x) * 128u;  // the pixel's offset / mask record (32 floats)
     // this lane's share of the record: taps 5 lrow .. 5 lrow + 4 (slot 4 of the upper half is a dummy, tap "9")
     float od[12], omk[5];
-    {
+    if (ABL && (ablo & 1)) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) od[i] = 0.25f * (float)((lane + i) & 3);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) omk[i] = 0.5f;
+    } else {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const float4 v = buf_ld4(r_om, rec + (unsigned)lrow * 40u + 16u * i);
@@ -137,11 +184,43 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
         omk[0] = v.x; omk[1] = v.y; omk[2] = v.z; omk[3] = v.w;
         omk[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_om, (int)(rec + 88u + (unsigned)lrow * 20u), 0, 0));
     }
+    // EARLY: every global load of the prologue is in flight before anything waits -- the offset / mask record above, the
+    // whole first chunk of the patch (14 rows per thread; the register file is still empty here) and the activation
+    // scale (scalar loads): one exposed memory round trip instead of four in a row (scale, record, two staging rounds:
+    // 15.5 k of a block's 46.6 k clocks, profiles/r03_dcn_timeline.txt)
+    float4 sv0[EARLY ? PH : 1];
+    if (EARLY) {
+#pragma unroll
+        for (int s = 0; s < PH; ++s) {
+            const bool row_ok = (unsigned)(ty0 - HALO + s) < (unsigned)p.H;
+            sv0[s] = buf_ld4s(r_x, (row_ok && col_ok) ? (unsigned)(st_base + (s - HALO) * rowb) : OOB, 0);
+        }
+        DCN_STAMP(50);  // all prologue loads issued
+        conv_in_scale(p, &afwd, &ainv);
+        afwd = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(afwd)));
+        ainv = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ainv)));
+        DCN_STAMP(51);  // activation scale arrived (scalar loads)
+        // park the rows right away (this is the one wait of the prologue; the record arrived with them): the 56 registers
+        // are free again before the set-up below needs the file
+#pragma unroll
+        for (int s = 0; s < PH; ++s)
+            if (spx < PW) *reinterpret_cast<float4*>(patch + st_lds + s * (PW * PSTR)) = sv0[s];
+        DCN_STAMP(52);  // rows arrived and parked (this wave)
+    }
     __syncthreads();  // exc_count = 0 is visible
+    DCN_STAMP(2);  // zeroing done, record loads issued, first barrier passed
 
     // ---- bilinear set-up (dcn_v2_im2col_cuda.cu:25-54, 150-187): 5 tap slots per lane, then both halves swap ----
     uint32_t sq[5], sw[5][4];  // patch pixel of corner (h_lo, w_lo); corner weights x mask x activation pre-scale
     const float fy0 = (float)(y - 1), fx0 = (float)(x - 1);
+    if (ABL && (ablo & 2)) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            sq[j] = (uint32_t)((2 * wid + 3) * PW + 3 + (lcol & 15) + j);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sw[j][c] = __float_as_uint(od[2 * j] + omk[j]);
+        }
+    } else
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         // tap 5 lrow + j = (kh, kw): lower half (0,0) (0,1) (0,2) (1,0) (1,1); upper half (1,2) (2,0) (2,1) (2,2) (-)
@@ -196,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
         }
     }
     __syncthreads();
+    DCN_STAMP(3);  // records arrived, set-up done, second barrier passed
     const int nexc_all = __builtin_amdgcn_readfirstlane(exc_count);  // scalar: the mode branches below stay uniform
     const bool slow = nexc_all > ECAP;                               // block-uniform
     const int nexc = nexc_all < ECAP ? nexc_all : ECAP;
@@ -237,6 +317,19 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
 #pragma unroll
         for (int hq = 0; hq < 2; ++hq) {
             const float4 v1 = r[0][hq], v2 = r[1][hq], v3 = r[2][hq], v4 = r[3][hq];
+#if !(CP_DCN_EXP & 256)
+            // plain v_fma_f32: same products in the same order as the packed forms below (tuning build 256), which measured 4 % slower
+            // -- packed float32 VALU beside MFMAs is an anti-lever on this part (MI355X_MICROARCH.md, instruction table)
+            const float w1 = w[0].x, w2 = w[0].y, w3 = w[1].x, w4 = w[1].y;
+            const float o0 = fmaf(w4, v4.x, fmaf(w3, v3.x, fmaf(w2, v2.x, w1 * v1.x)));
+            const float o1 = fmaf(w4, v4.y, fmaf(w3, v3.y, fmaf(w2, v2.y, w1 * v1.y)));
+            const float o2 = fmaf(w4, v4.z, fmaf(w3, v3.z, fmaf(w2, v2.z, w1 * v1.z)));
+            const float o3 = fmaf(w4, v4.w, fmaf(w3, v3.w, fmaf(w2, v2.w, w1 * v1.w)));
+            const Split2 t0 = split2(o0, o1), t1 = split2(o2, o3);
+            hi[2 * hq] = t0.hi; hi[2 * hq + 1] = t1.hi;
+            lo[2 * hq] = t0.lo; lo[2 * hq + 1] = t1.lo;
+            continue;
+#endif
             f32x2 lo2 = pk_mul_b<0>(w[0], f32x2{v1.x, v1.y}), hi2 = pk_mul_b<0>(w[0], f32x2{v1.z, v1.w});
             lo2 = pk_fma_b<1>(w[0], f32x2{v2.x, v2.y}, lo2);
             hi2 = pk_fma_b<1>(w[0], f32x2{v2.z, v2.w}, hi2);
@@ -269,12 +362,6 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
 
     if (!slow) {
         // ================= fast mode: every sample is in LDS =================
-        // staging geometry: thread -> (patch column tid / 8 (< PW: 22 of 32 busy), channel quad tid % 8), pass s = patch
-        // row s; one base offset register, the row validity is wave-uniform
-        const int spx = tid >> 3, six = tx0 - HALO + spx;
-        const bool col_ok = spx < PW && (unsigned)six < (unsigned)p.W;
-        const int st_base = ((b * p.H + ty0) * p.W + six) * cb + (tid & 7) * 16;  // row ty0 (always inside the image)
-        const int st_lds = spx * PSTR + (tid & 7) * 16;                            // + PW * PSTR per row
         auto gather = [&](float4 (&r)[4][2], int a) {  // a: addr[tap] + 64 (K step % 2)
             if (ABL && (abl & 1)) return;
             const unsigned char* ap = patch + a;
@@ -285,12 +372,36 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
                 r[c][1] = *reinterpret_cast<const float4*>(ap + co + 16);
             }
         };
+        // exception samples: 8 threads each (one channel quad per thread), 32 samples per pass: the four corners are
+        // blended here (same FMA order as the K loop) into the sample's spare pixel; addresses are rebuilt per chunk from
+        // the block's list (LDS) -- no registers held across the K loop
+        auto stage_exceptions = [&](int csoff) {
+            for (int e = tid >> 3; e < nexc; e += 32) {
+                const int key = exc_key[e], go = exc_goff[e] + (tid & 7) * 16;
+                const float4 w = *reinterpret_cast<const float4*>(exc_w[e]);
+                const int iy = (key >> 16) - 1, ix = (key & 0xffff) - 1;
+                const bool y0 = (unsigned)iy < (unsigned)p.H, y1 = (unsigned)(iy + 1) < (unsigned)p.H;
+                const bool x0 = (unsigned)ix < (unsigned)p.W, x1 = (unsigned)(ix + 1) < (unsigned)p.W;
+                const float4 v1 = buf_ld4s(r_x, (y0 && x0) ? (unsigned)go : OOB, csoff);
+                const float4 v2 = buf_ld4s(r_x, (y0 && x1) ? (unsigned)(go + cb) : OOB, csoff);
+                const float4 v3 = buf_ld4s(r_x, (y1 && x0) ? (unsigned)(go + rowb) : OOB, csoff);
+                const float4 v4 = buf_ld4s(r_x, (y1 && x1) ? (unsigned)(go + rowb + cb) : OOB, csoff);
+                float4 o;
+                o.x = fmaf(w.w, v4.x, fmaf(w.z, v3.x, fmaf(w.y, v2.x, w.x * v1.x)));
+                o.y = fmaf(w.w, v4.y, fmaf(w.z, v3.y, fmaf(w.y, v2.y, w.x * v1.y)));
+                o.z = fmaf(w.w, v4.z, fmaf(w.z, v3.z, fmaf(w.y, v2.z, w.x * v1.z)));
+                o.w = fmaf(w.w, v4.w, fmaf(w.z, v3.w, fmaf(w.y, v2.w, w.x * v1.w)));
+                *reinterpret_cast<float4*>(patch + (NPIX + e) * PSTR + (tid & 7) * 16) = o;
+            }
+        };
         // weights of steps 0, 1, 2 in flight before the first chunk is staged
         issue_b(0, 0 * gpt + 0);
         issue_b(1, 0 * gpt + 1);
         issue_b(2, 1 * gpt + 0);
         for (int ch = 0; ch < nch; ++ch) {
+            DCN_STAMP(4 + 24 * ch);  // chunk start
             if (ch > 0) __syncthreads();  // every wave is done with the previous chunk's patch
+            DCN_STAMP(5 + 24 * ch);
             if (!(ABL && (abl & 16))) {
                 const int csoff = ch * (CKC * 4);
                 int sb = st_base;
@@ -299,7 +410,12 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
                     const bool row_ok = (unsigned)(ty0 - HALO + s) < (unsigned)p.H;
                     return (row_ok && col_ok) ? (unsigned)(sb + (s - HALO) * rowb) : OOB;
                 };
-                constexpr int H1 = PH / 2;  // two rounds of 7 rows: half the registers in flight
+                // two rounds of 7 rows: half the registers in flight (CP_DCN_EXP & 1, tuning builds: one round of 14)
+                constexpr int H1 = (CP_DCN_EXP & 1) ? PH : PH / 2;
+                if (EARLY && ch == 0) {
+                    // the rows were requested and parked at the top of the kernel: only the exception samples are left
+                    stage_exceptions(csoff);
+                } else {
                 {
                     float4 sv[H1];
 #pragma unroll
@@ -309,35 +425,18 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
                         if (spx < PW) *reinterpret_cast<float4*>(patch + st_lds + s * (PW * PSTR)) = sv[s];
                 }
                 {
-                    float4 sv[PH - H1];
+                    float4 sv[PH - H1 > 0 ? PH - H1 : 1];
 #pragma unroll
                     for (int s = H1; s < PH; ++s) sv[s - H1] = buf_ld4s(r_x, row_off(s), csoff);
-                    // exception samples: 8 threads each (one channel quad per thread), 32 samples per pass: the four corners
-                    // are blended here (same FMA order as the K loop) into the sample's spare pixel; addresses are rebuilt
-                    // per chunk from the block's list (LDS) -- no registers held across the K loop
-                    for (int e = tid >> 3; e < nexc; e += 32) {
-                        const int key = exc_key[e], go = exc_goff[e] + (tid & 7) * 16;
-                        const float4 w = *reinterpret_cast<const float4*>(exc_w[e]);
-                        const int iy = (key >> 16) - 1, ix = (key & 0xffff) - 1;
-                        const bool y0 = (unsigned)iy < (unsigned)p.H, y1 = (unsigned)(iy + 1) < (unsigned)p.H;
-                        const bool x0 = (unsigned)ix < (unsigned)p.W, x1 = (unsigned)(ix + 1) < (unsigned)p.W;
-                        const float4 v1 = buf_ld4s(r_x, (y0 && x0) ? (unsigned)go : OOB, csoff);
-                        const float4 v2 = buf_ld4s(r_x, (y0 && x1) ? (unsigned)(go + cb) : OOB, csoff);
-                        const float4 v3 = buf_ld4s(r_x, (y1 && x0) ? (unsigned)(go + rowb) : OOB, csoff);
-                        const float4 v4 = buf_ld4s(r_x, (y1 && x1) ? (unsigned)(go + rowb + cb) : OOB, csoff);
-                        float4 o;
-                        o.x = fmaf(w.w, v4.x, fmaf(w.z, v3.x, fmaf(w.y, v2.x, w.x * v1.x)));
-                        o.y = fmaf(w.w, v4.y, fmaf(w.z, v3.y, fmaf(w.y, v2.y, w.x * v1.y)));
-                        o.z = fmaf(w.w, v4.z, fmaf(w.z, v3.z, fmaf(w.y, v2.z, w.x * v1.z)));
-                        o.w = fmaf(w.w, v4.w, fmaf(w.z, v3.w, fmaf(w.y, v2.w, w.x * v1.w)));
-                        *reinterpret_cast<float4*>(patch + (NPIX + e) * PSTR + (tid & 7) * 16) = o;
-                    }
+                    stage_exceptions(csoff);
 #pragma unroll
                     for (int s = H1; s < PH; ++s)
                         if (spx < PW) *reinterpret_cast<float4*>(patch + st_lds + s * (PW * PSTR)) = sv[s - H1];
                 }
+                }
             }
             __syncthreads();
+            DCN_STAMP(6 + 24 * ch);  // chunk staged
             float4 raw[2][4][2];
             if (ABL) {
 #pragma unroll
@@ -356,8 +455,11 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
                 __builtin_amdgcn_sched_barrier(0);
                 // refill the set just consumed with step u + 3 (of this chunk or the next)
                 const int u3 = u + 3 < NSTEP ? u + 3 : u + 3 - NSTEP, ch3 = u + 3 < NSTEP ? ch : ch + 1;
+                if (!(CP_DCN_EXP & 4) || (ch == 0 && u < 3))  // (tuning build 4: weight fragments loaded once, reused)
                 if (ch3 < nch) issue_b(u % 3, (u3 >> 1) * gpt + 2 * ch3 + (u3 & 1));
                 __builtin_amdgcn_sched_barrier(0);
+                if ((CP_DCN_EXP & 2) && (u & 1)) __syncthreads();  // (tuning build 2: what a barrier per tap would cost)
+                if ((CP_DCN_EXP & 16) || u == NSTEP - 1) DCN_STAMP(7 + 24 * ch + ((CP_DCN_EXP & 16) ? u : 0));  // per step (16) / chunk done
             }
         }
     } else {
@@ -415,7 +517,18 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
             }
         }
     }
+    DCN_STAMP(60);  // K loop done
+    if (ABL && (abl & 64)) {  // keep the accumulators alive: one conditional store that never happens
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < F::NACC; ++r) sacc += acc[0][j][r];
+        if (sacc == 1.2345e-30f) p.out[0] = sacc;
+        return;
+    }
     patch_epilogue<1, NT, 4, 1, true>(p, acc, b, ty0, tx0, tn, wid, 0, lane, ainv);
+    DCN_STAMP(61);  // epilogue stores issued
 }
 
 // [CoutPad][Kpad16] binary16 -> MFMA B-operand order: fragment (n tile j of 32, K step g of 16) = 64 lanes x 16 bytes,
@@ -435,10 +548,11 @@ template <int NT>
 int launch_dcn16p(const ConvParams& p, hipStream_t stream) {
     constexpr int BN = 32 * NT;
     const int tiles_m = p.B * (p.H / TH) * (p.W / TW), tiles_n = p.CoutPad / BN;
-    if (p.dbg >> 25)
+    if ((unsigned)p.dbg >> 25)
         hipLaunchKernelGGL((dcn16p_kernel<NT, true>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m, tiles_n);
-    else
-        hipLaunchKernelGGL((dcn16p_kernel<NT>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m, tiles_n);
+    else  // (tuning build 128: 8 KB of unused dynamic LDS -> one block per CU instead of two)
+        hipLaunchKernelGGL((dcn16p_kernel<NT>), dim3(tiles_m * tiles_n), dim3(256), (CP_DCN_EXP & 128) ? 8192 : 0, stream, p,
+                           tiles_m, tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
