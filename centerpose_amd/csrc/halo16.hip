@@ -59,11 +59,20 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
     int tn = tile % tiles_n;
     int tm = tile / tiles_n;
     if (EPI == 1 && p.fuse_ngroups > 0) {
-        // several heads in one launch: head slowest, so that an XCD's contiguous run of tiles walks one head's weights
-        // (0.6 MB) at a time instead of cycling through all of them (> its 4 MB L2); inside a head, n fastest as above
-        const int per = tiles_m * p.fuse_gtiles, g = tile / per, rem = tile - g * per;
-        tn = g * p.fuse_gtiles + rem % p.fuse_gtiles;
-        tm = rem / p.fuse_gtiles;
+        // several heads in one launch.  Tile order = bands of HEAD_BAND patches; inside a band head by head, inside a head
+        // patch by patch, n fastest: an XCD's contiguous run of tiles keeps one band's input (~1.5 MB with halos) and one
+        // head's weights (0.6 MB) in its 4 MB L2, so the shared input is read from HBM once -- head-slowest over the whole
+        // map streamed it once per head (2.17 GB per launch at B = 64 against 0.42 GB algorithmic, profiles/pmc_traffic.json
+        // of the first grouped form), n-fastest over all heads cycled through 4.1 MB of weights per patch (3 % slower)
+        const int bsel = (p.dbg >> 18) & 3;  // cp_set_debug bits 18-19 (A/B): band of 8 / 128 patches / the whole map
+        const int HEAD_BAND = bsel == 0 ? 32 : bsel == 1 ? 8 : bsel == 2 ? 128 : tiles_m;
+        const int gt = p.fuse_gtiles, per_band = HEAD_BAND * tiles_n;
+        const int band = tile / per_band, m0 = band * HEAD_BAND;
+        const int bsz = min(HEAD_BAND, tiles_m - m0);  // patches in this band (the last one may be short)
+        const int rem = tile - band * per_band;
+        const int g = rem / (bsz * gt), rr = rem - g * (bsz * gt);
+        tn = g * gt + rr % gt;
+        tm = m0 + rr / gt;
     }
     const int txs = p.W / TW, tys = p.H / TH;
     const int tx0 = (tm % txs) * TW;

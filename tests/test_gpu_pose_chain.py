@@ -198,7 +198,8 @@ META = {"c": np.array([256.0, 256.0], np.float32), "s": 512.0, "out_height": 128
 
 def test_run_batch_at_bench_batch_matches_run_by_value(device, tmp_path):
     """run_batch (device post-process + cp_pnp_from_post) at B=64 on the synthetic network against run() (host
-    post-process + host-assembled points + cp_pnp_solve) image by image: results AND boxes by value."""
+    post-process + host-assembled points + cp_pnp_solve) image by image: results by value, boxes by membership and by the
+    fields the solver was given (see the comment at the comparison for why not by pose)."""
     det = _detector(tmp_path, extra=["--vis_thresh", "0.2"])
     B = 64
     x = torch.cat([synth.frames(8, seed=900 + i) for i in range(0, B, 8)])
@@ -212,16 +213,20 @@ def test_run_batch_at_bench_batch_matches_run_by_value(device, tmp_path):
                 np.testing.assert_allclose(np.asarray(r1[k], np.float64), np.asarray(r2[k], np.float64), rtol=1e-5,
                                            atol=1e-4, err_msg=k)
             assert abs(r1["score"] - r2["score"]) < 1e-4   # batch 1 and batch 64 take different kernel paths (split-K)
-        # random-weight detections include degenerate PnP problems (poses at 1e5 object heights) that amplify the 1e-5
-        # batch-1 / batch-64 difference of the network outputs without bound: those are compared by count only, the
-        # well-posed ones by value (identical inputs give identical poses: test_pnp_from_post_assembly_by_value)
+        # Random-weight detections are mostly degenerate PnP problems (poses hundreds of object heights away, flat error
+        # surfaces) that amplify the 1e-5 batch-1 / batch-64 difference of the network outputs without bound, so their
+        # POSES are not comparable across the two paths.  Here: the same detections reach the solver (inputs by value) and
+        # the same ones come back as boxes; pose values are compared where they mean something -- identical inputs
+        # (test_pnp_from_post_assembly_by_value: bit-identical rows) and well-posed scenes through both paths
+        # (test_run_batch_boxes_recover_generating_poses_at_bench_batch).
         assert len(single["boxes"]) == len(outs[b]["boxes"])
-        sane = [i for i, bx in enumerate(single["boxes"]) if float(np.abs(bx[1]).max()) < 1e3]
-        _boxes_equal([single["boxes"][i] for i in sane], [outs[b]["boxes"][i] for i in sane], 2e-2)  # ~1 degree
-        n_box += len(sane)
+        for x1, x2 in zip(single["boxes"], outs[b]["boxes"]):
+            np.testing.assert_allclose(np.asarray(x1[3], np.float64), np.asarray(x2[3], np.float64), rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(np.asarray(x1[2], np.float64), np.asarray(x2[2], np.float64), rtol=1e-5, atol=1e-4)
+            n_box += 1
         n_res += len(single["results"])
     assert n_res >= B // 4, "the synthetic network must produce detections for this test to mean anything (%d)" % n_res
-    assert n_box >= 1, "no well-posed box was compared by value"
+    assert n_box >= 1, "no box came out of either path"
 
 
 def test_run_batch_boxes_recover_generating_poses_at_bench_batch(device, tmp_path):
