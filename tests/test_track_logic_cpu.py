@@ -204,3 +204,62 @@ def test_tracker_logic_matches_python_loop_with_pnp(host, monkeypatch):
                 n_checked += 1
             assert n_box == len(ret["boxes"]), f
     assert n_checked >= 8
+
+
+def test_tracker_logic_random_scenarios_vs_python_tracker(host):
+    """Crowded random videos (objects crossing, leaving, re-entering, weak detections, same-frame births and deaths) through
+    the harness and through the reference-pinned Python ``Tracker`` (greedy, Kalman + scale pool, no PnP): identical ids,
+    ages, activity and filter read-outs in every frame -- association order, coasting up to max_age, the new-track
+    threshold and the float32 cost arithmetic included."""
+    from centerpose_amd.lib.utils.tracker import Tracker
+
+    class Opt(mg.TrackOpt):
+        max_age = 3
+        new_thresh = 0.35
+
+    for seed in (1, 2, 3):
+        rng = np.random.RandomState(seed)
+        n_obj, n_frames = 14, 25
+        base = rng.uniform(60, 450, (n_obj, 2))
+        vel = rng.uniform(-9, 9, (n_obj, 2))
+        size = rng.uniform(25, 80, n_obj)
+        o = Opt(False)
+        py = Tracker(o)
+        py.init_track({"id": 0})
+        P = Params(new_thresh=o.new_thresh, pre_thresh=0.3, R=o.R, conf_lo=3, conf_hi=9, max_age=o.max_age, kalman=1,
+                   scale_pool=1, use_pnp=0, hps_uncertainty=1, show_axes=0, cat_rule=0, render_hm_mode=1, render_hmhp_mode=2,
+                   pre_hm=1, pre_hm_hp=1, K=100)
+        vm = np.zeros(16)
+        vm[[0, 4]] = 1.0
+        vm[6:10] = 512
+        ht = HostTracker(host, P, vm)
+        for f in range(n_frames):
+            dets = []
+            for i in rng.permutation(n_obj):
+                if rng.rand() < 0.2:      # missed this frame
+                    continue
+                ct = base[i] + vel[i] * f + rng.randn(2) * 1.5
+                kps = ct[None, :] + rng.uniform(-0.5, 0.5, (8, 2)) * size[i]
+                dets.append({
+                    "score": float(rng.uniform(0.2, 0.99)), "cls": 0,
+                    "bbox": [ct[0] - size[i] / 2, ct[1] - size[i] / 2, ct[0] + size[i] / 2, ct[1] + size[i] / 2],
+                    "ct": [float(ct[0]), float(ct[1])],
+                    "tracking": (-vel[i] + rng.randn(2) * 2.0).astype(np.float32),
+                    "tracking_hp": (np.tile(-vel[i], 8) + rng.randn(16) * 0.5).astype(np.float32),
+                    "kps": kps.reshape(-1).astype(np.float32),
+                    "kps_fusion_mean": kps.reshape(-1) + rng.randn(16) * 0.3,
+                    "kps_fusion_std": rng.uniform(0.4, 6.0, 16),
+                    "obj_scale": rng.uniform(0.5, 1.5, 3).astype(np.float32),
+                    "obj_scale_uncertainty": rng.uniform(0.05, 0.3, 3).astype(np.float32)})
+            post = np.stack([_post_from_dict(d, True) for d in dets]) if dets else np.zeros((0, 120))
+            mine, _ = ht.step(post)
+            theirs, _ = py.step(copy.deepcopy(dets))
+            assert len(mine) == len(theirs), (seed, f)
+            for t, g in zip(mine, theirs):
+                assert (int(t[0]), int(t[1]), int(t[2])) == (g["tracking_id"], g["age"], g["active"]), (seed, f)
+                np.testing.assert_allclose(t[4 + 28:4 + 30], g["ct"], rtol=1e-12)
+                np.testing.assert_allclose(t[TR["MEAN_KF"]:TR["MEAN_KF"] + 16], np.asarray(g["kps_mean_kf"]).reshape(-1),
+                                           rtol=1e-8, atol=1e-8)
+                np.testing.assert_allclose(t[TR["STD_KF"]:TR["STD_KF"] + 16], g["kps_std_kf"], rtol=1e-8, atol=1e-8)
+                np.testing.assert_allclose(t[TR["SCALE_KF"]:TR["SCALE_KF"] + 3], g["obj_scale_kf"], rtol=1e-6)
+        assert py.id_count >= n_obj  # tracks were lost and re-born along the way
