@@ -263,3 +263,24 @@ def test_tracker_logic_random_scenarios_vs_python_tracker(host):
                 np.testing.assert_allclose(t[TR["STD_KF"]:TR["STD_KF"] + 16], g["kps_std_kf"], rtol=1e-8, atol=1e-8)
                 np.testing.assert_allclose(t[TR["SCALE_KF"]:TR["SCALE_KF"] + 3], g["obj_scale_kf"], rtol=1e-6)
         assert py.id_count >= n_obj  # tracks were lost and re-born along the way
+
+
+def test_tracker_logic_reports_overflow(host):
+    """More live tracks than the table holds: the association returns -1 (the device sets the video's overflow flag and
+    `DeviceTracker.read` raises) instead of dropping tracks silently."""
+    o = mg.TrackOpt(False)
+    P = Params(new_thresh=0.3, pre_thresh=0.3, R=o.R, conf_lo=3, conf_hi=9, max_age=5, kalman=1, scale_pool=1, use_pnp=0,
+               hps_uncertainty=1, show_axes=0, cat_rule=0, render_hm_mode=1, render_hmhp_mode=2, pre_hm=1, pre_hm_hp=1, K=100)
+    vm = np.zeros(16)
+    vm[[0, 4]] = 1.0
+    vm[6:10] = 512
+    dets = mg.tracker_frames()[0]
+    cap = len([d for d in dets if d["score"] > 0.3]) - 1
+    ht = HostTracker(host, P, vm, cap=cap)
+    post = np.stack([_post_from_dict(d, True) for d in dets])
+    nxt = np.zeros((cap, STRIDE))
+    pts = np.zeros((cap, 16), np.float32)
+    sc = np.zeros((cap, 3), np.float32)
+    n = host.cp_track_host_update(ctypes.byref(ht.P), _ptr(ht.vm), _ptr(post), len(post), None, _ptr(ht.prev), 0,
+                                  ctypes.byref(ht.id_count), _ptr(nxt), _ptr(pts), _ptr(sc))
+    assert n == -1
