@@ -1004,7 +1004,10 @@ static int conv16_tile_n(const ConvParams& p) {
 // (split-K).  cp_set_debug: 32768 = never, 65536 = every eligible layer (tests, A/B runs).
 static bool dcn16p_wanted(const ConvParams& p) {
     if ((p.dbg & 32768) || (p.dbg & 1024) || !cp_dcn16p_supported(p)) return false;
-    return (p.dbg & 65536) || cp_dcn16p_blocks(p) >= 256;
+    // from 64 blocks up (round 3; 256 before): at batch 1 the 128 x 128 and 64 x 64 maps are 128 / 64-block launches, and one
+    // patch-resident launch beats the split-K gather kernel + its epilogue launch (frame 1.666 -> 1.627 ms, 2.089 -> 2.044;
+    // thresholds 128 / 32 / none: 1.639 / 1.643 / 1.637)
+    return (p.dbg & 65536) || cp_dcn16p_blocks(p) >= 64;
 }
 
 static bool halo16_wanted(const ConvParams& p, int bn) {
