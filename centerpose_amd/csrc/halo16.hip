@@ -78,8 +78,10 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
     const int tx0 = (tm % txs) * TW;
     tm /= txs;
     const int ty0 = (tm % tys) * TH, b = tm / tys;
-    float afwd, ainv;
-    conv_in_scale(p, &afwd, &ainv);
+    // activation pre-scale: its 32 scalar loads are issued here and reduced only behind the first staging loads (below)
+    float afwd = 1.f, ainv = 1.f;
+    const AmaxRaw amax_raw = conv_in_scale_issue(p);
+    bool have_scale = false;
 
     const unsigned img_bytes = (unsigned)p.B * p.H * p.W * (unsigned)p.Cin * 4u;
     const __amdgpu_buffer_rsrc_t r_x = make_rsrc(p.src[0], img_bytes);
@@ -184,6 +186,10 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
                 const bool in = q < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 const unsigned off = in ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + ch * CK + c4c * 4) * 4u : OOB;
                 sv[s] = buf_ld4(r_x, off);
+            }
+            if (!have_scale) {  // once per block, with the first round of staging loads already in flight
+                conv_in_scale_finish(p, amax_raw, &afwd, &ainv);
+                have_scale = true;
             }
 #pragma unroll
             for (int s = 0; s < SR; ++s) {

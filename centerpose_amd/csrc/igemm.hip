@@ -402,8 +402,9 @@ namespace {
 __global__ void splitk_epilogue_kernel(const ConvParams p) {
     const int M = p.B * p.Ho * p.Wo, HWo = p.Ho * p.Wo;
     const size_t total = (size_t)M * p.Cout;
-    float afwd, ainv, amax = 0.f;
-    conv_in_scale(p, &afwd, &ainv);
+    float afwd = 1.f, ainv = 1.f, amax = 0.f;
+    const AmaxRaw amax_raw = conv_in_scale_issue(p);  // the 32 scalar loads go out first, their reduction waits (below)
+    bool have_scale = false;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         int m, n;
         if (p.store == CP_STORE_NHWC) { m = (int)(i / p.Cout); n = (int)(i - (size_t)m * p.Cout); }
@@ -419,8 +420,16 @@ __global__ void splitk_epilogue_kernel(const ConvParams p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc += v[j];
         }
-        float y = acc * ((p.scale ? p.scale[n] : 1.f) * ainv) + (p.shift ? p.shift[n] : 0.f);
-        if (p.res) y += p.res[(size_t)m * p.res_ld + n];
+        // the activation scale (32 scalar loads issued at the top) is reduced behind the slab loads, not in front of them: this
+        // kernel is one memory round trip long, and it runs 40-odd times per batch-1 frame
+        const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift ? p.shift[n] : 0.f;
+        const float rs = p.res ? p.res[(size_t)m * p.res_ld + n] : 0.f;
+        if (!have_scale) {
+            conv_in_scale_finish(p, amax_raw, &afwd, &ainv);
+            have_scale = true;
+        }
+        float y = acc * (sc * ainv) + sh;
+        if (p.res) y += rs;
         if (p.act == CP_ACT_RELU) y = fmaxf(y, 0.f);
         else if (p.act == CP_ACT_SIGMOID || (p.act == CP_ACT_SIGMOID_FROM && n >= p.act_from)) y = 1.f / (1.f + expf(-y));
         amax = fmaxf(amax, fabsf(y));

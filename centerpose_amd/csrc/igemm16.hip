@@ -490,8 +490,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
     int tiles_left = n;  // tiles not yet issued; past the end every load goes out of range
 
     // ---- loader pieces: A slot j / B slot j of the tile the K walk points at, then the walk step ----
-    float afwd, ainv;  // power-of-two pre-scale of the activations and its inverse (ConvParams::in_amax)
-    conv_in_scale(p, &afwd, &ainv);
+    float afwd = 1.f, ainv = 1.f;  // power-of-two pre-scale of the activations and its inverse (ConvParams::in_amax)
+    const AmaxRaw amax_raw = conv_in_scale_issue(p);  // reduced behind the first tile's loads (prologue), except GNIN
+    if (GNIN) conv_in_scale_finish(p, amax_raw, &afwd, &ainv);
     float4 gn_a4 = make_float4(1.f, 1.f, 1.f, 1.f), gn_d4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int gn_b = GNIN ? (tm * BM) / (p.Ho * p.Wo) : 0;  // the tile's image (the launcher guarantees Ho*Wo % BM == 0)
     auto issue_a = [&](float4(&ga)[A_SLOTS], int j) {
@@ -689,6 +690,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
 
     // ---- prologue: tile 0 in buffer 0, tile 1 in the register set ----
     issue_tile(ga, gbh, gbl);
+    if (!GNIN) conv_in_scale_finish(p, amax_raw, &afwd, &ainv);
     store_all(0, ga, gbh, gbl, 2);
     issue_tile(ga, gbh, gbl);
     __syncthreads();

@@ -130,6 +130,37 @@ __device__ __forceinline__ void conv_in_scale(const ConvParams& p, float* fwd, f
     cp_amax_to_scale(mx, fwd, inv);
 }
 
+// The same in two halves, so that a kernel can put its first global loads between them: the 32 scalar loads of the
+// sub-slots are ISSUED by conv_in_scale_issue and only waited for / reduced by conv_in_scale_finish (the wait sits at the
+// first use of the loaded values).  Called back to back they are conv_in_scale; with the first tile's loads in between, the
+// scale's round trip (~1 us, once per block) overlaps theirs instead of preceding it.
+struct AmaxRaw {
+    unsigned v[CP_AMAX_SUB];  // the first source's sub-slots, un-reduced (uniform: scalar registers)
+    unsigned extra;           // further sources of a virtual concat, already reduced (rare: Root nodes)
+};
+__device__ __forceinline__ AmaxRaw conv_in_scale_issue(const ConvParams& p) {
+    AmaxRaw r;
+    r.extra = 0u;
+#pragma unroll
+    for (int k = 0; k < CP_AMAX_SUB; ++k) r.v[k] = 0u;
+    if (!p.in_amax[0]) return r;
+#pragma unroll
+    for (int k = 0; k < CP_AMAX_SUB; ++k) r.v[k] = p.in_amax[0][k * CP_AMAX_STRIDE];
+    if (p.nsrc > 1 && p.in_amax[1]) r.extra = max(r.extra, cp_amax_read(p.in_amax[1]));
+    if (p.nsrc > 2 && p.in_amax[2]) r.extra = max(r.extra, cp_amax_read(p.in_amax[2]));
+    if (p.nsrc > 3 && p.in_amax[3]) r.extra = max(r.extra, cp_amax_read(p.in_amax[3]));
+    return r;
+}
+__device__ __forceinline__ void conv_in_scale_finish(const ConvParams& p, const AmaxRaw& r, float* fwd, float* inv) {
+    *fwd = 1.f;
+    *inv = 1.f;
+    if (!p.in_amax[0]) return;
+    unsigned m = r.extra;
+#pragma unroll
+    for (int k = 0; k < CP_AMAX_SUB; ++k) m = max(m, r.v[k]);
+    cp_amax_to_scale(m, fwd, inv);
+}
+
 // Epilogue of every implicit-GEMM tile: y = acc*scale[n] + shift[n] (+ residual) -> ReLU / sigmoid -> NHWC or NCHW
 // store (folded eval-mode BatchNorm, conv bias, BasicBlock residual: pose_dla_dcn.py:48-62, DeformConv.actf :380-389).
 template <int FRAG, int MT, int NT, int WM, int WN>

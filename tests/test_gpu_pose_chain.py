@@ -204,29 +204,43 @@ def test_run_batch_at_bench_batch_matches_run_by_value(device, tmp_path):
     B = 64
     x = torch.cat([synth.frames(8, seed=900 + i) for i in range(0, B, 8)])
     outs = det.run_batch(x, [dict(META) for _ in range(B)])
-    n_res = n_box = 0
+    n_res = n_box = n_lone = 0
     for b in range(B):
         single = det.run({"image": [x[b]]}, meta_inp=dict(META))  # the reference's pre-processed entry (:431-436)
         assert len(single["results"]) == len(outs[b]["results"])
-        for r1, r2 in zip(single["results"], outs[b]["results"]):
-            for k in ("bbox", "kps", "kps_displacement_mean", "kps_heatmap_mean", "obj_scale"):
+        rest = list(outs[b]["results"])
+        for r1 in single["results"]:  # paired by centre: scores closer than the path difference may swap places
+            j = int(np.argmin([np.abs(np.asarray(r2["ct"], np.float64) - np.asarray(r1["ct"], np.float64)).sum()
+                               for r2 in rest]))
+            r2 = rest.pop(j)
+            for k in ("ct", "bbox", "kps", "kps_displacement_mean", "kps_heatmap_mean", "obj_scale"):
                 np.testing.assert_allclose(np.asarray(r1[k], np.float64), np.asarray(r2[k], np.float64), rtol=1e-5,
                                            atol=1e-4, err_msg=k)
             assert abs(r1["score"] - r2["score"]) < 1e-4   # batch 1 and batch 64 take different kernel paths (split-K)
         # Random-weight detections are mostly degenerate PnP problems (poses hundreds of object heights away, flat error
         # surfaces) that amplify the 1e-5 batch-1 / batch-64 difference of the network outputs without bound, so their
-        # POSES are not comparable across the two paths.  Here: the same detections reach the solver (inputs by value) and
-        # the same ones come back as boxes; pose values are compared where they mean something -- identical inputs
-        # (test_pnp_from_post_assembly_by_value: bit-identical rows) and well-posed scenes through both paths
+        # POSES are not comparable across the two paths, and a solution that lands on the validity limit (behind the
+        # camera / reprojection gate) can come back as a box from one path only.  Here: the same detections reach the
+        # solver (inputs by value), boxes are paired by those inputs, and at most 8 % of them may be one-sided
+        # (measured 11 of 299, tools/probe/lone_boxes.py: every one a wild cuboid -- negative or 50:1 relative scales); pose
+        # values are compared where they mean something -- identical inputs (test_pnp_from_post_assembly_by_value:
+        # bit-identical rows) and well-posed scenes through both paths, where the counts must be equal
         # (test_run_batch_boxes_recover_generating_poses_at_bench_batch).
-        assert len(single["boxes"]) == len(outs[b]["boxes"])
-        for x1, x2 in zip(single["boxes"], outs[b]["boxes"]):
-            np.testing.assert_allclose(np.asarray(x1[3], np.float64), np.asarray(x2[3], np.float64), rtol=1e-5, atol=1e-5)
+        left = list(outs[b]["boxes"])
+        for x1 in single["boxes"]:
+            hit = [i for i, x2 in enumerate(left)
+                   if np.allclose(np.asarray(x1[3], np.float64), np.asarray(x2[3], np.float64), rtol=1e-5, atol=1e-5)]
+            if not hit:
+                n_lone += 1
+                continue
+            x2 = left.pop(hit[0])
             np.testing.assert_allclose(np.asarray(x1[2], np.float64), np.asarray(x2[2], np.float64), rtol=1e-5, atol=1e-4)
             n_box += 1
+        n_lone += len(left)
         n_res += len(single["results"])
     assert n_res >= B // 4, "the synthetic network must produce detections for this test to mean anything (%d)" % n_res
     assert n_box >= 1, "no box came out of either path"
+    assert n_lone <= max(2, n_box // 12), "%d of %d boxes came out of one path only" % (n_lone, n_box)
 
 
 def test_run_batch_boxes_recover_generating_poses_at_bench_batch(device, tmp_path):
