@@ -65,7 +65,7 @@ WORKLOAD_TEXT = {
     "hourglass": "BASELINE configs[4] as the reference defines it (N4 i): 2-stack hourglass 512x512 batch=%d/GPU, single frame, "
                  "backbone + decode",
     "track_e2e": "dla_34 512x512, %d concurrent videos, whole CenterPoseTrack loop per frame (render of the previous tracks, "
-                 "two-frame network, decode, post-process, PnP, Gaussian fusion, Tracker.step on the host)",
+                 "two-frame network, decode, post-process, PnP, Gaussian fusion, Tracker.step); `value` = the device tracker, the host tracker beside it",
 }
 
 

@@ -9,17 +9,17 @@ R=$PWD
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
-python bench.py 2>$O/bench_default.err | tail -1 > $O/bench_default.json
+timeout 900 python bench.py 2>$O/bench_default.err | tail -1 > $O/bench_default.json
 B="--no-cpu-baseline --no-latency --no-legs"
-CP_PROFILE_DUMP=$O/layers_default.csv python bench.py --steps 8 --warmup 2 $B 2>/dev/null | tail -1 > $O/bench_layers.json
+CP_PROFILE_DUMP=$O/layers_default.csv timeout 300 python bench.py --steps 8 --warmup 2 $B 2>/dev/null | tail -1 > $O/bench_layers.json
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --steps 10 --warmup 3 $B > $O/kt.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --steps 10 --warmup 3 $B > $O/kt.log 2>&1
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/rocprof_kernel_stats.csv
 if [ "${1:-}" != "quick" ]; then
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python $R/bench.py --workload decode --steps 10 --warmup 3 $B > $O/kt1.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python $R/bench.py --workload decode --steps 10 --warmup 3 $B > $O/kt1.log 2>&1
   cp $(find $O/kt1 -name "*kernel_stats.csv" | head -1) $O/rocprof_kernel_stats_configs1.csv
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python $R/bench.py --steps 3 --warmup 1 $B > $O/fetch.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python $R/bench.py --steps 3 --warmup 1 $B > $O/write.log 2>&1
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python $R/bench.py --steps 3 --warmup 1 $B > $O/fetch.log 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python $R/bench.py --steps 3 --warmup 1 $B > $O/write.log 2>&1
   python $R/tools/pmc_to_json.py $(find $O/fetch -name "*counter_collection.csv" | head -1) \
          $(find $O/write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json
 fi
