@@ -14,7 +14,7 @@
 //     so lanes reading neighbouring pixels at the same channel quad spread over the banks; no XOR swizzle, hence ONE
 //     address register per (lane, tap) and every corner / K step / quad is an immediate offset.
 //   * A lane gathers exactly its MFMA A-fragment (pixel = lane % 32, 8 consecutive channels = 2 quads per corner),
-//     blends in float32 (packed FMAs), splits to binary16 hi / lo in registers: the A tile never exists in LDS.
+//     blends in float32 (plain v_fma_f32: the packed form measured 4 % slower), splits to binary16 hi / lo in registers: the A tile never exists in LDS.
 //     Each wave owns 32 pixels x the whole 64-wide N tile, so nothing is gathered twice inside a block.
 //   * The weight fragments come straight from global memory / L2 in MFMA operand order (ConvParams::w16f_*: one
 //     coalesced 1 KB load per fragment, cp_launch_frag16_repack), three K steps ahead.  With neither operand staged
@@ -74,24 +74,6 @@ __device__ __forceinline__ void both_halves(uint32_t v, uint32_t* lo, uint32_t* 
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// Packed float32 multiply / FMA whose first operand is ONE dword of a register pair broadcast to both halves
-// (op_sel / op_sel_hi pick dword S for the low and the high product).  Written out because the compiler materialises
-// {w, w} pairs instead: 72 registers for the 36 bilinear weights of a lane, where 36 do.
-template <int S>
-__device__ __forceinline__ f32x2 pk_mul_b(f32x2 w, f32x2 v) {
-    f32x2 d;
-    if (S == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(w), "v"(v));
-    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(w), "v"(v));
-    return d;
-}
-template <int S>
-__device__ __forceinline__ f32x2 pk_fma_b(f32x2 w, f32x2 v, f32x2 c) {
-    f32x2 d;
-    if (S == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(w), "v"(v), "v"(c));
-    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(w), "v"(v), "v"(c));
-    return d;
-}
-
 // ABL: timing ablations for tuning (cp_set_debug bits 25..29, tools/dcn_bench.py --dbg; results are wrong when set):
 //   1 << 25 no gather reads (registers reused), 1 << 26 no blend / split arithmetic, 1 << 27 no MFMAs,
 //   1 << 28 no weight-fragment loads, 1 << 29 no staging loads / stores (the patch keeps its zeros)
@@ -107,21 +89,6 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     DCN_STAMP(0);
-#if CP_DCN_EXP & 64
-    // (tuning build 64: the second block of every CU starts half a block lifetime late, so that one block's memory phases
-    // fall into the other's K loop instead of both doing the same thing at the same time)
-#if CP_DCN_EXP & 512
-    if (blockIdx.x < 512) {  // 16 start phases spread over ~ one block lifetime
-        const int k = ((blockIdx.x >> 3) * 7 + (blockIdx.x & 7) * 3) & 15;
-        for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(48);
-    }
-#else
-    if (blockIdx.x < 512 && ((blockIdx.x >> 8) & 1)) {
-#pragma unroll
-        for (int i = 0; i < (CP_DCN_EXP >> 10); ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-#endif
     const int lrow = lane >> 5, lcol = lane & 31;
     const int abl = ABL ? __builtin_amdgcn_readfirstlane((int)((unsigned)p.dbg >> 25)) : 0;  // bit 5 (1 << 30): variant only;
                                                                    // bit 6 (1 << 31): no epilogue stores
@@ -132,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     const int tx0 = (tm % txs) * TW;
     tm /= txs;
     const int ty0 = (tm % tys) * TH, b = tm / tys;
-    constexpr bool EARLY = !(CP_DCN_EXP & 32);  // (tuning build 32: the round-2 prologue, one memory round trip per stage)
+    constexpr bool EARLY = true;  // (false: the round-2 prologue, one memory round trip per stage -- profiles/NOTES.md)
     float afwd, ainv;
     if (!EARLY) {
         conv_in_scale(p, &afwd, &ainv);
@@ -317,8 +284,7 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
 #pragma unroll
         for (int hq = 0; hq < 2; ++hq) {
             const float4 v1 = r[0][hq], v2 = r[1][hq], v3 = r[2][hq], v4 = r[3][hq];
-#if !(CP_DCN_EXP & 256)
-            // plain v_fma_f32: same products in the same order as the packed forms below (tuning build 256), which measured 4 % slower
+            // plain v_fma_f32: same products in the same order as the v_pk_fma_f32 form this replaced, which measured 4 % slower
             // -- packed float32 VALU beside MFMAs is an anti-lever on this part (MI355X_MICROARCH.md, instruction table)
             const float w1 = w[0].x, w2 = w[0].y, w3 = w[1].x, w4 = w[1].y;
             const float o0 = fmaf(w4, v4.x, fmaf(w3, v3.x, fmaf(w2, v2.x, w1 * v1.x)));
@@ -328,18 +294,6 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
             const Split2 t0 = split2(o0, o1), t1 = split2(o2, o3);
             hi[2 * hq] = t0.hi; hi[2 * hq + 1] = t1.hi;
             lo[2 * hq] = t0.lo; lo[2 * hq + 1] = t1.lo;
-            continue;
-#endif
-            f32x2 lo2 = pk_mul_b<0>(w[0], f32x2{v1.x, v1.y}), hi2 = pk_mul_b<0>(w[0], f32x2{v1.z, v1.w});
-            lo2 = pk_fma_b<1>(w[0], f32x2{v2.x, v2.y}, lo2);
-            hi2 = pk_fma_b<1>(w[0], f32x2{v2.z, v2.w}, hi2);
-            lo2 = pk_fma_b<0>(w[1], f32x2{v3.x, v3.y}, lo2);
-            hi2 = pk_fma_b<0>(w[1], f32x2{v3.z, v3.w}, hi2);
-            lo2 = pk_fma_b<1>(w[1], f32x2{v4.x, v4.y}, lo2);
-            hi2 = pk_fma_b<1>(w[1], f32x2{v4.z, v4.w}, hi2);
-            const Split2 s0 = split2(lo2.x, lo2.y), s1 = split2(hi2.x, hi2.y);
-            hi[2 * hq] = s0.hi; hi[2 * hq + 1] = s1.hi;
-            lo[2 * hq] = s0.lo; lo[2 * hq + 1] = s1.lo;
         }
         const u32x4 ahv = {hi[0], hi[1], hi[2], hi[3]}, alv = {lo[0], lo[1], lo[2], lo[3]};
         const h8 ah = *reinterpret_cast<const h8*>(&ahv), al = *reinterpret_cast<const h8*>(&alv);
@@ -410,8 +364,8 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
                     const bool row_ok = (unsigned)(ty0 - HALO + s) < (unsigned)p.H;
                     return (row_ok && col_ok) ? (unsigned)(sb + (s - HALO) * rowb) : OOB;
                 };
-                // two rounds of 7 rows: half the registers in flight (CP_DCN_EXP & 1, tuning builds: one round of 14)
-                constexpr int H1 = (CP_DCN_EXP & 1) ? PH : PH / 2;
+                // two rounds of 7 rows: half the registers in flight (one round of 14 measured the same)
+                constexpr int H1 = PH / 2;
                 if (EARLY && ch == 0) {
                     // the rows were requested and parked at the top of the kernel: only the exception samples are left
                     stage_exceptions(csoff);
@@ -455,10 +409,8 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
                 __builtin_amdgcn_sched_barrier(0);
                 // refill the set just consumed with step u + 3 (of this chunk or the next)
                 const int u3 = u + 3 < NSTEP ? u + 3 : u + 3 - NSTEP, ch3 = u + 3 < NSTEP ? ch : ch + 1;
-                if (!(CP_DCN_EXP & 4) || (ch == 0 && u < 3))  // (tuning build 4: weight fragments loaded once, reused)
                 if (ch3 < nch) issue_b(u % 3, (u3 >> 1) * gpt + 2 * ch3 + (u3 & 1));
                 __builtin_amdgcn_sched_barrier(0);
-                if ((CP_DCN_EXP & 2) && (u & 1)) __syncthreads();  // (tuning build 2: what a barrier per tap would cost)
                 if ((CP_DCN_EXP & 16) || u == NSTEP - 1) DCN_STAMP(7 + 24 * ch + ((CP_DCN_EXP & 16) ? u : 0));  // per step (16) / chunk done
             }
         }
@@ -550,9 +502,8 @@ int launch_dcn16p(const ConvParams& p, hipStream_t stream) {
     const int tiles_m = p.B * (p.H / TH) * (p.W / TW), tiles_n = p.CoutPad / BN;
     if ((unsigned)p.dbg >> 25)
         hipLaunchKernelGGL((dcn16p_kernel<NT, true>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m, tiles_n);
-    else  // (tuning build 128: 8 KB of unused dynamic LDS -> one block per CU instead of two)
-        hipLaunchKernelGGL((dcn16p_kernel<NT>), dim3(tiles_m * tiles_n), dim3(256), (CP_DCN_EXP & 128) ? 8192 : 0, stream, p,
-                           tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL((dcn16p_kernel<NT>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m, tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
