@@ -26,6 +26,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+#ifdef CP_LOWC_STAMP
+// tuning build: shader-clock stamps of wave 0 of one mid-launch block per kernel kind (tools/lowc_timeline.py)
+__device__ unsigned long long g_lowc_clk[4][16];
+#define LOWC_STAMP(i) do { if (blockIdx.x == gridDim.x / 2 + 1 && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"); \
+                                g_lowc_clk[(CIN == 4 ? 0 : S) + (NG - 1) * 3][i] = clock64(); } } while (0)
+extern "C" int cp_debug_read_lowc_clk(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lowc_clk), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#else
+#define LOWC_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 struct LowcParams {
@@ -73,6 +85,7 @@ __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
 
+    LOWC_STAMP(0);
     // ---- weights -> registers (B operand: lane = (n = lane % 16, k chunk = lane / 16)) ----
     h8 wh[KSTEPS][NF], wl[KSTEPS][NF];
     {
@@ -88,8 +101,10 @@ __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
             }
     }
 
+    LOWC_STAMP(1);  // weights arrived
     float afwd = 1.f, ainv = 1.f;
     if (p.in_amax) cp_amax_to_scale(cp_amax_read(p.in_amax), &afwd, &ainv);
+    LOWC_STAMP(2);  // activation scale arrived
     // ---- stage the input tile: float32 global -> binary16 hi / lo image in LDS, zero outside the picture ----
     // All loads of a round are issued before the first conversion (one HBM round trip per round of SR slots, not one per
     // slot: the kernels are streams of their input and output, latency is what they have to hide).
@@ -163,7 +178,9 @@ __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
             }
         }
     }
+    LOWC_STAMP(3);  // this wave's share of the tile staged
     __syncthreads();
+    LOWC_STAMP(4);  // barrier passed
 
     // ---- multiply: wave w owns x fragment (w % XF) of rows (w / XF), + 4 / XF, ... ----
     const int pl = lane & 15, q = lane >> 4;
@@ -178,6 +195,7 @@ __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
     for (int row = wid / XF; row < TH; row += 4 / XF) {
         const int oy = oy0 + row;
         if (oy >= p.Ho) break;
+        if (row == wid / XF + 4 / XF) LOWC_STAMP(5);  // first row done (MFMAs retired, stores issued and acknowledged)
         f32x4 acc[NF];
 #pragma unroll
         for (int f = 0; f < NF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -220,7 +238,9 @@ __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
             }
         }
     }
+    LOWC_STAMP(6);  // all rows done
     if (p.out_amax) cp_amax_commit(p.out_amax, amax);
+    LOWC_STAMP(7);
 }
 
 // PyTorch [COUT][cin][KS][KS] float32 -> hi / lo B fragments in the K layout described at the top of the file
