@@ -2,7 +2,8 @@
 kernels of the two halves overlap?).  usage: python tools/probe/dual_stream.py [--offset]"""
 import sys, time
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import bench
 
 dev = torch.device("cuda:0")

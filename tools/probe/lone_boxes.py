@@ -1,7 +1,8 @@
 """Diagnostic: which boxes come out of run() but not run_batch() (or the reverse) on the synthetic network."""
 import sys, tempfile, pathlib
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from tests import test_gpu_pose_chain as T
 from centerpose_amd import synth
 det = T._detector(pathlib.Path(tempfile.mkdtemp()), extra=["--vis_thresh", "0.2"])
