@@ -317,6 +317,25 @@ def frame_latency(pipe, n=50):
     return round(ts[len(ts) // 2], 3)
 
 
+def detect_latency(pipe, n=30):
+    """The same frame through the network + sigmoid + decode only (cp_model_detect from its hipGraph): what is left of
+    `frame_latency` is the post-process and the PnP walk, which on random-weight (ill-posed) detections runs its full
+    20 Levenberg-Marquardt iterations (profiles/NOTES.md)."""
+    x1 = pipe.x[:1].contiguous()
+    det = lambda: pipe.model.detect(x1, K=100, rep_mode=1, fit_gaussian=False, balance=2.0, graph=True)
+    for _ in range(3):
+        det()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        t1 = time.perf_counter()
+        det()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t1) * 1e3)
+    ts.sort()
+    return round(ts[len(ts) // 2], 3)
+
+
 def run_leg(workload, device, precision, steps, warmup, barrier, latency, serial_pnp=False):
     """One nested leg of the default run: a short timed region of another configuration, same harness."""
     batch = DEFAULT_BATCH[workload]
@@ -602,10 +621,12 @@ def main():
                                "detections_per_s_while_solving": round(n / (ms * 1e-3), 1) if n else None,
                                "note": "PnP-input assembly + batched solve of one batch, HIP events on hip.PoseStage's side "
                                        "stream; runs under the next batch's network (DESIGN 3.6)"}
-        lat = None
+        lat = lat_det = None
         if not dry and not args.no_latency and args.workload in ("full", "decode", "hourglass"):
             pipe.gather = False  # rank 0 alone: no collective inside the batch-1 latency loop
             lat = frame_latency(pipe)
+            if args.workload == "full":
+                lat_det = detect_latency(pipe)
         legs = None
         if not dry and world == 1 and args.workload == "full" and not args.no_legs:
             # the other configurations, driver-timed in the same run (short legs; each has its own roofline object)
@@ -649,6 +670,7 @@ def main():
                                          "the first stack's seven heads, which do not feed model(x)[-1] (object_pose.py:135) "
                                          "and are not computed"} if pipe.arch == "hourglass" else {})},
             "p50_frame_ms_batch1": lat,
+            **({"p50_frame_ms_batch1_network_decode": lat_det} if lat_det is not None else {}),
             "whole_step_tflops": round(value * gf / 1e3 / world, 2),
             "roofline": roof, "legs": legs, "cpu_baseline": cpu,
         }

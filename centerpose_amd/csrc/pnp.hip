@@ -33,12 +33,18 @@ constexpr double FLT_EPS = 1.1920928955078125e-07;
 
 struct Cam { double fx, fy, cx, cy; };
 
-__device__ void rodrigues(const double r[3], double R[9], double* J /*27 or null*/) {
+// cv::Rodrigues vector -> matrix (+ the 27 derivatives dR/dr when WJ).  Every loop is unrolled and the outputs are
+// references to fixed-size arrays: with a nullable pointer for J the caller's dR[27] stayed in scratch memory (a store ->
+// load round trip per Jacobian of the Levenberg-Marquardt walk).
+template <bool WJ>
+__device__ __forceinline__ void rodrigues_t(const double* r, double (&R)[9], double (&J)[27]) {
     const double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
     if (theta < DBL_EPS) {
+#pragma unroll
         for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
-        if (J) {
+        if (WJ) {
             const double j0[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
+#pragma unroll
             for (int i = 0; i < 27; ++i) J[i] = j0[i];
         }
         return;
@@ -47,18 +53,26 @@ __device__ void rodrigues(const double r[3], double R[9], double* J /*27 or null
     const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
     const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
     const double rx[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+#pragma unroll
     for (int k = 0; k < 9; ++k) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * rrt[k] + s * rx[k];
-    if (!J) return;
+    if (!WJ) return;
     const double drrt[27] = {x + x, y, z, y, 0, 0, z, 0, 0, 0, x, 0, x, y + y, z, 0, z, 0, 0, 0, x, 0, 0, y, x, y, z + z};
     const double drx[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
     const double a[3] = {x, y, z};
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
         const double ri = a[i];
         const double a0 = -s * ri, a1 = (s - 2 * c1 * it) * ri, a2 = c1 * it, a3 = (c - s * it) * ri, a4 = s * it;
+#pragma unroll
         for (int k = 0; k < 9; ++k)
             J[i * 9 + k] = a0 * ((k % 4 == 0) ? 1.0 : 0.0) + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * rx[k] +
                            a4 * drx[i * 9 + k];
     }
+}
+__device__ __forceinline__ void rodrigues(const double* r, double (&R)[9], double (&J)[27]) { rodrigues_t<true>(r, R, J); }
+__device__ __forceinline__ void rodrigues(const double* r, double (&R)[9], decltype(nullptr)) {
+    double none[27];
+    rodrigues_t<false>(r, R, none);
 }
 
 // polar factor U V^T of a 3x3 matrix with positive determinant (Newton iteration X <- (X + X^-T)/2)
@@ -179,27 +193,51 @@ __device__ void smallest_eigvec(double* A /*n (n + 1) / 2, destroyed*/, double* 
     for (int i = 0; i < n; ++i) out[i] = x[i];
 }
 
-// solve 6x6 A x = b (Gaussian elimination, partial pivoting); A, b destroyed
-__device__ void solve6(double A[36], double b[6], double x[6]) {
+// solve 6x6 A x = b (Gaussian elimination, partial pivoting); A, b destroyed.
+// Every index is a compile-time constant after unrolling: the row exchange is a predicated select over the candidate rows,
+// not an access through the run-time pivot index -- that form put A and b into scratch memory, and the dependent memory
+// round trips of one elimination were most of a Levenberg-Marquardt step (pnp_kernel on 12 ill-posed detections: 701 us
+// of a 2.45 ms batch-1 frame).  Same comparisons, same operations in the same order: the results are bit-identical.
+__device__ __forceinline__ void solve6(double (&A)[36], double (&b)[6], double (&x)[6]) {
+#pragma unroll
     for (int c = 0; c < 6; ++c) {
         int piv = c;
-        for (int r = c + 1; r < 6; ++r)
-            if (fabs(A[r * 6 + c]) > fabs(A[piv * 6 + c])) piv = r;
-        if (piv != c) {
-            for (int k = 0; k < 6; ++k) { const double t = A[c * 6 + k]; A[c * 6 + k] = A[piv * 6 + k]; A[piv * 6 + k] = t; }
-            const double t = b[c]; b[c] = b[piv]; b[piv] = t;
+        double best = fabs(A[c * 6 + c]);
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) {
+            const double a = fabs(A[r * 6 + c]);
+            if (a > best) { best = a; piv = r; }
+        }
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) {
+            const bool sw = piv == r;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const double t = A[c * 6 + k], u = A[r * 6 + k];
+                A[c * 6 + k] = sw ? u : t;
+                A[r * 6 + k] = sw ? t : u;
+            }
+            const double t = b[c], u = b[r];
+            b[c] = sw ? u : t;
+            b[r] = sw ? t : u;
         }
         const double d = A[c * 6 + c];
-        if (d == 0.0) continue;
-        for (int r = c + 1; r < 6; ++r) {
-            const double f = A[r * 6 + c] / d;
-            if (f == 0.0) continue;
-            for (int k = c; k < 6; ++k) A[r * 6 + k] -= f * A[c * 6 + k];
-            b[r] -= f * b[c];
+        if (d != 0.0) {
+#pragma unroll
+            for (int r = c + 1; r < 6; ++r) {
+                const double f = A[r * 6 + c] / d;
+                if (f != 0.0) {
+#pragma unroll
+                    for (int k = c; k < 6; ++k) A[r * 6 + k] -= f * A[c * 6 + k];
+                    b[r] -= f * b[c];
+                }
+            }
         }
     }
+#pragma unroll
     for (int r = 5; r >= 0; --r) {
         double s = b[r];
+#pragma unroll
         for (int k = r + 1; k < 6; ++k) s -= A[r * 6 + k] * x[k];
         x[r] = (A[r * 6 + r] != 0.0) ? s / A[r * 6 + r] : 0.0;
     }
@@ -361,7 +399,8 @@ __device__ __forceinline__ double gsum16(double v) {
 __device__ __forceinline__ int lm_refine16(const Problem& q, double param[6], int sub) {
     const Cam cam = q.cam;
     const bool pv = sub < q.npts && pt_valid(q, sub);
-    const double* M = q.V3[(sub < q.npts ? sub : 0) / q.per];
+    const double* Mq = q.V3[(sub < q.npts ? sub : 0) / q.per];
+    const double M[3] = {Mq[0], Mq[1], Mq[2]};  // this lane's model point, read once (the only run-time index of the walk)
     const double pu = pv ? (double)q.P[2 * sub] : 0.0, pw = pv ? (double)q.P[2 * sub + 1] : 0.0;
     double prev[6];
     int lambda_lg10 = -3, iters = 0;
@@ -396,6 +435,7 @@ __device__ __forceinline__ int lm_refine16(const Problem& q, double param[6], in
                     JtJ[b * 6 + a] = t;
                 }
             }
+#pragma unroll
             for (int k = 0; k < 6; ++k) prev[k] = param[k];
             if (iters == 0) prev_err = sqrt(e2);
             calc_j = false;
@@ -414,6 +454,7 @@ __device__ __forceinline__ int lm_refine16(const Problem& q, double param[6], in
                 lambda_lg10 = lambda_lg10 - 1 < -16 ? -16 : lambda_lg10 - 1;
                 ++iters;
                 double dn = 0, pn = 0;
+#pragma unroll
                 for (int k = 0; k < 6; ++k) { dn += (param[k] - prev[k]) * (param[k] - prev[k]); pn += prev[k] * prev[k]; }
                 const double rel = sqrt(dn) / (pn > 0 ? sqrt(pn) : 1.0);
                 if (iters >= 20 || rel < FLT_EPS) break;
@@ -425,9 +466,12 @@ __device__ __forceinline__ int lm_refine16(const Problem& q, double param[6], in
         // step(): param = prev - solve(JtJ with diag *= 1 + lambda, JtErr)
         double Aq[36], bq[6], dx[6];
         const double lam = exp(lambda_lg10 * log(10.0));
+#pragma unroll
         for (int k = 0; k < 36; ++k) Aq[k] = JtJ[k];
+#pragma unroll
         for (int k = 0; k < 6; ++k) { Aq[k * 7] *= 1.0 + lam; bq[k] = JtE[k]; }
         solve6(Aq, bq, dx);
+#pragma unroll
         for (int k = 0; k < 6; ++k) param[k] = prev[k] - dx[k];
     }
     return iters;
