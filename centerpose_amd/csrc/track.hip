@@ -36,9 +36,12 @@ __device__ __forceinline__ StateView view(void* state, int B) {
     return v;
 }
 
-__global__ void track_prepare_kernel(const TrackParams P, const double* __restrict__ vmeta, const double* __restrict__ post,
-                                     const int* __restrict__ count, const double* __restrict__ det_pnp, int B, int K,
-                                     double* __restrict__ dets, int* __restrict__ use) {
+// (launch bounds = the 64 threads these kernels are launched with: without them the compiler assumes 1024-thread blocks,
+// caps the kernels at 128 registers and spills the Kalman blocks to scratch)
+__global__ __launch_bounds__(64) void track_prepare_kernel(const TrackParams P, const double* __restrict__ vmeta,
+                                                           const double* __restrict__ post, const int* __restrict__ count,
+                                                           const double* __restrict__ det_pnp, int B, int K,
+                                                           double* __restrict__ dets, int* __restrict__ use) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * K) return;
     const int b = i / K, k = i - b * K;
@@ -84,8 +87,9 @@ __global__ __launch_bounds__(64) void track_associate_kernel(const TrackParams P
     if (lane == 0) h[3] = n;  // published as h[0] by the advance kernel's launch (same stream: ordered)
 }
 
-__global__ void track_advance_kernel(const TrackParams P, const double* __restrict__ vmeta, int B, void* state,
-                                     float* __restrict__ pts, float* __restrict__ scale, double* __restrict__ cam) {
+__global__ __launch_bounds__(64) void track_advance_kernel(const TrackParams P, const double* __restrict__ vmeta, int B,
+                                                           void* state, float* __restrict__ pts, float* __restrict__ scale,
+                                                           double* __restrict__ cam) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * P.cap) return;
     const int b = i / P.cap, t = i - b * P.cap;
@@ -102,8 +106,9 @@ __global__ void track_advance_kernel(const TrackParams P, const double* __restri
     for (int e = 0; e < 4; ++e) cam[(size_t)i * 4 + e] = vmeta[(size_t)b * CP_VMETA_STRIDE + VM_CAM + e];
 }
 
-__global__ void track_finish_kernel(const TrackParams P, const double* __restrict__ vmeta, int B, void* state,
-                                    const double* __restrict__ rows, double* __restrict__ recs) {
+__global__ __launch_bounds__(64) void track_finish_kernel(const TrackParams P, const double* __restrict__ vmeta, int B,
+                                                          void* state, const double* __restrict__ rows,
+                                                          double* __restrict__ recs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * P.cap) return;
     const int b = i / P.cap, t = i - b * P.cap;
@@ -120,7 +125,7 @@ __global__ void track_finish_kernel(const TrackParams P, const double* __restric
 }
 
 // the new list becomes the current one
-__global__ void track_flip_kernel(int B, void* state) {
+__global__ __launch_bounds__(64) void track_flip_kernel(int B, void* state) {
     int* hdr = (int*)state;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) hdr[4 + 4 * b] = hdr[4 + 4 * b + 3];
