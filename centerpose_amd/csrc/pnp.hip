@@ -128,8 +128,7 @@ __device__ void rot_to_rvec(const double R[9], double r[3]) {
 //   exact correspondences, without moving the eigenvectors), then x <- normalise(L^-T L^-1 x) until the direction stops
 //   changing.  ~300 FMAs for the factor + 160 per iteration, against ~10^5 strided global loads / stores for the cyclic
 //   Jacobi sweep this replaces (which was 90 % of the kernel's time: 4.1 ms per 6400 detections).  The convergence
-//   ratio is lambda_1 / lambda_2; the iteration cap only bites on (near-)degenerate point sets, whose pose is
-//   ill-defined anyway and is refined by the Levenberg-Marquardt stage regardless.
+//   ratio is lambda_1 / lambda_2; slow walks end with a Rayleigh-Ritz step over the last two iterates (below).
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
 template <int n>
 __device__ void smallest_eigvec(double* A /*n (n + 1) / 2, destroyed*/, double* out /*n*/) {
@@ -161,12 +160,12 @@ __device__ void smallest_eigvec(double* A /*n (n + 1) / 2, destroyed*/, double* 
     double x[n];
 #pragma unroll
     for (int i = 0; i < n; ++i) x[i] = 0.28867513459481287 * ((i & 1) ? 1.0 : 0.9) * ((i % 3 == 2) ? -1.0 : 1.0);  // generic start
-    for (int it = 0; it < 400; ++it) {
-        double y[n];
+    // one application of (A + mu I)^-1: y = L^-T L^-1 x
+    auto apply_inv = [&](const double (&xin)[n], double (&y)[n]) {
         // forward: L z = x
 #pragma unroll
         for (int i = 0; i < n; ++i) {
-            double v = x[i];
+            double v = xin[i];
 #pragma unroll
             for (int k = 0; k < i; ++k) v -= A[TRI(i, k)] * y[k];
             y[i] = v * dinv[i];
@@ -179,6 +178,21 @@ __device__ void smallest_eigvec(double* A /*n (n + 1) / 2, destroyed*/, double* 
             for (int k = i + 1; k < n; ++k) v -= A[TRI(k, i)] * y[k];
             y[i] = v * dinv[i];
         }
+    };
+    // Plain inverse iteration converges like (lambda_1 / lambda_2)^k: a handful of steps on most point sets, hundreds when
+    // the two smallest eigenvalues are close -- and a batch waits for its slowest detection (64 well-posed detections:
+    // 314 us against 60 for one, because one of them walked to the old cap of 400 steps).  After SLOW_AFTER steps the last
+    // two iterates span, to (lambda_1 / lambda_3)^k, the plane of the two slowest eigenvectors; a Rayleigh-Ritz step in
+    // that plane (2 x 2 symmetric eigenproblem of the inverse operator) separates them exactly and ends the walk.  Point
+    // sets that converge earlier leave through the same test as before, with the same result.
+    constexpr int SLOW_AFTER = 48;
+    double xp[n];  // the iterate before x
+#pragma unroll
+    for (int i = 0; i < n; ++i) xp[i] = x[i];
+    bool converged = false;
+    for (int it = 0; it < SLOW_AFTER; ++it) {
+        double y[n];
+        apply_inv(x, y);
         double nn = 0, dot = 0;
 #pragma unroll
         for (int i = 0; i < n; ++i) nn += y[i] * y[i];
@@ -186,8 +200,42 @@ __device__ void smallest_eigvec(double* A /*n (n + 1) / 2, destroyed*/, double* 
 #pragma unroll
         for (int i = 0; i < n; ++i) { y[i] *= inv; dot += y[i] * x[i]; }
 #pragma unroll
-        for (int i = 0; i < n; ++i) x[i] = y[i];
-        if (it >= 2 && 1.0 - fabs(dot) < 1e-16) break;
+        for (int i = 0; i < n; ++i) { xp[i] = x[i]; x[i] = y[i]; }
+        if (it >= 2 && 1.0 - fabs(dot) < 1e-16) { converged = true; break; }
+    }
+    if (!converged) {
+        // orthonormal basis {q1 = x, q2 = xp - (xp . x) x normalised} of span{x, xp}; H = Q^T B Q with B = (A + mu I)^-1
+        double q2[n], b1[n], b2[n];
+        double d = 0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) d += xp[i] * x[i];
+        double nn = 0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) { q2[i] = xp[i] - d * x[i]; nn += q2[i] * q2[i]; }
+        if (nn > 1e-28) {  // (else the two iterates coincide to rounding: x is the answer)
+            const double inv = 1.0 / sqrt(nn);
+#pragma unroll
+            for (int i = 0; i < n; ++i) q2[i] *= inv;
+            apply_inv(x, b1);
+            apply_inv(q2, b2);
+            double h11 = 0, h12 = 0, h22 = 0;
+#pragma unroll
+            for (int i = 0; i < n; ++i) { h11 += x[i] * b1[i]; h12 += x[i] * b2[i]; h22 += q2[i] * b2[i]; }
+            // dominant eigenvector (c, s) of [[h11, h12], [h12, h22]] (largest eigenvalue of B = smallest of A)
+            const double half = 0.5 * (h11 - h22), rad = sqrt(half * half + h12 * h12);
+            double c, sn;
+            if (half >= 0) { c = half + rad; sn = h12; } else { c = h12; sn = rad - half; }
+            const double nrm = sqrt(c * c + sn * sn);
+            if (nrm > 0) {
+                c /= nrm; sn /= nrm;
+                double m2 = 0;
+#pragma unroll
+                for (int i = 0; i < n; ++i) { x[i] = c * x[i] + sn * q2[i]; m2 += x[i] * x[i]; }
+                const double im = 1.0 / sqrt(m2);
+#pragma unroll
+                for (int i = 0; i < n; ++i) x[i] *= im;
+            }
+        }
     }
 #pragma unroll
     for (int i = 0; i < n; ++i) out[i] = x[i];
@@ -530,7 +578,8 @@ __device__ __forceinline__ void load_problem(Problem& q, const float* pts, const
 
 // pts [N][npts][2] float (npts = 8 or 16), scale [N][3] float, cam [N][4] double (fx, fy, cx, cy)
 // out [N][CP_PNP_STRIDE] double;  scratch: unused since the eigen-solver moved into registers (kept in the ABI).
-// Sixteen consecutive lanes = one detection (4 detections per wavefront); lane `sub` owns image point `sub`.
+// Sixteen consecutive lanes = one detection (4 per wavefront, or one 16-lane workgroup each: cp_launch_pnp); lane `sub`
+// owns image point `sub`.
 __global__ __launch_bounds__(64) void pnp_kernel(const float* __restrict__ pts, const float* __restrict__ scale,
                                                  const double* __restrict__ camp, int N, int npts,
                                                  double* __restrict__ out, double* __restrict__ scratch) {
@@ -1035,7 +1084,15 @@ int cp_launch_pnp(hipStream_t s, const float* pts, const float* scale, const dou
                   void* ws) {
     if (N < 1) return CP_OK;
     if (npts != 8 && npts != 16) return CP_ERR_INVALID;
-    hipLaunchKernelGGL(pnp_kernel, dim3((N * 16 + 63) / 64), dim3(64), 0, s, pts, scale, cam, N, npts, out, (double*)ws);
+    // Up to 256 problems (a batch-1 frame: K = 100 slots): one detection per wavefront (a 16-lane workgroup each) -- the
+    // Levenberg-Marquardt walks of different detections branch differently (lambda retries, iteration counts), and four
+    // ill-posed ones sharing a wavefront run one after the other (batch-1 frame of the random-weight network: 2.09 -> 2.02 ms).
+    // Larger batches keep four detections per wavefront: with well-posed detections the walks agree and a quarter of the
+    // wavefronts is the better trade (640 / 6400 detections: 314 / 583 us against 424 / 741).
+    if (N <= 256)
+        hipLaunchKernelGGL(pnp_kernel, dim3(N), dim3(16), 0, s, pts, scale, cam, N, npts, out, (double*)ws);
+    else
+        hipLaunchKernelGGL(pnp_kernel, dim3((N * 16 + 63) / 64), dim3(64), 0, s, pts, scale, cam, N, npts, out, (double*)ws);
     // detections the common-case kernel marked -2 (4-5 valid points) / -3 (planar model); a no-op otherwise
     hipLaunchKernelGGL(pnp_rare_kernel, dim3((N + RARE_LANES - 1) / RARE_LANES), dim3(64), 0, s, pts, scale, cam, N, npts,
                        out);
