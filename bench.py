@@ -27,6 +27,10 @@ Extra objects on the ONE JSON line rank 0 prints:
                 workload on the exact-f32 MFMA kernels), hourglass / track / track_gru (BASELINE configs[4] in both
                 readings), track_e2e (B concurrent videos through the whole CenterPoseTrack loop
                 incl. the host tracker: host fraction of a step)
+  p50_frame_ms_batch1 / p50_frame_ms_batch1_network_decode
+                p50 latency of one frame at batch 1 (frame resident in HBM -> results in HBM, network replayed from its
+                hipGraph): the whole chain, and its network + sigmoid + decode share (the rest is the post-process and
+                the PnP walk of that frame's detections)
   cpu_baseline  the reference's CPU path for the same workload timed on this host's cores (BASELINE.md section 3:
                 3 warm-ups, >= 10 timed images, median): `value` = the reference as shipped (its own scalar
                 single-thread deformable im2col, oracle/_ref, + torch CPU convolutions), `fair` = the OpenMP port
