@@ -765,6 +765,62 @@ def test_pnp_known_pose_and_vs_float64_oracle(device, noise, npts, drop):
         np.testing.assert_allclose(q, s2["quaternion_xyzw"], atol=1e-6)
 
 
+def _dlt_gap(pts, scale, K):
+    """lambda_1 / lambda_2 of the DLT normal matrix cv's non-planar initialisation takes its smallest eigenvector of
+    (oracle/pnp.py: dlt_init) -- the convergence ratio of the device's inverse iteration."""
+    verts = opnp.cuboid_vertices(np.asarray(scale, np.float64) / scale[1])
+    obj = np.repeat(verts, len(pts) // 8, axis=0)
+    mn = np.stack([(pts[:, 0] - K[0, 2]) / K[0, 0], (pts[:, 1] - K[1, 2]) / K[1, 1]], 1).astype(np.float64)
+    L = np.zeros((2 * len(pts), 12))
+    for i in range(len(pts)):
+        X, Y, Z = obj[i]
+        x, y = -mn[i, 0], -mn[i, 1]
+        L[2 * i] = [X, Y, Z, 1, 0, 0, 0, 0, x * X, x * Y, x * Z, x]
+        L[2 * i + 1] = [0, 0, 0, 0, X, Y, Z, 1, y * X, y * Y, y * Z, y]
+    w = np.linalg.eigvalsh(L.T @ L)
+    return w[0] / w[1]
+
+
+@pytest.mark.gpu
+def test_pnp_slowly_converging_dlt_vs_float64_oracle(device):
+    """Point sets whose two smallest DLT eigenvalues are close (ratio > 0.75: plain inverse iteration would need more than
+    the 48 steps after which pnp.hip finishes with a Rayleigh-Ritz step over its last two iterates): the pose must still be
+    the float64 restatement's, which takes the exact eigenvector (numpy eigh)."""
+    # far objects under 2 px of noise: ~4 % of these have a gap ratio above 0.75
+    rng = np.random.RandomState(4242)
+    K = np.array([[663.0287679036459, 0, 300.2775065104167], [0, 663.0287679036459, 395.00066121419275], [0, 0, 1]])
+    M = 1500
+    pts = np.zeros((M, 16, 2), np.float32)
+    scale = np.zeros((M, 3), np.float32)
+    for i in range(M):
+        sc = np.array([rng.uniform(0.3, 3), rng.uniform(0.5, 2.0), rng.uniform(0.3, 3)])
+        q = rng.randn(4)
+        R = opnp.quat_xyzw_to_matrix(q / np.linalg.norm(q))
+        t = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(20.0, 60.0)])
+        uv = opnp.project_points(opnp.cuboid_vertices(sc / sc[1]), opnp.matrix_to_rodrigues(R), t, K)
+        pts[i], scale[i] = np.repeat(uv, 2, axis=0) + rng.randn(16, 2) * 2.0, sc
+    gaps = np.array([_dlt_gap(pts[i].astype(np.float64), scale[i], K) for i in range(M)])
+    sel = np.argsort(-gaps)[:48]
+    assert gaps[sel].min() > 0.75, "the generator no longer produces slowly converging cases (%.3f)" % gaps[sel].min()
+    pts, scale = pts[sel], scale[sel]
+    N = len(sel)
+    cam = np.tile(np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]]), (N, 1))
+    out = hip.pnp_solve(torch.from_numpy(pts).to(device), torch.from_numpy(scale).to(device),
+                        torch.from_numpy(cam).to(device)).cpu().numpy()
+    n_pose = 0
+    for i in range(N):
+        s = opnp.solve_cuboid_pnp(pts[i].astype(np.float64), scale[i].astype(np.float64), K, opencv_return=True)
+        if s is None:
+            assert out[i, 0] == 2
+            continue
+        assert out[i, 0] == 1
+        assert _geodesic_deg(opnp.rodrigues_to_matrix(out[i, 1:4]), opnp.rodrigues_to_matrix(s["rvec"])) < 1e-3
+        assert np.linalg.norm(out[i, 4:7] - s["tvec"]) / np.linalg.norm(s["tvec"]) < 1e-6
+        np.testing.assert_allclose(out[i, 8:24].reshape(8, 2), s["projected_points"], atol=1e-4)
+        n_pose += 1
+    assert n_pose >= 8, "too few of the selected cases have a pose in front of the camera (%d)" % n_pose  # measured: 16 of 48
+
+
 def test_pnp_status_codes_and_rare_branches(device):
     """< 4 points -> -1; 5 valid points -> EPnP (cuboid_pnp_solver.py:162-163); one cuboid face -> the planar
     (homography) initialisation; 4 points on two vertices -> degenerate, failure (0).  Poses vs the float64 oracle."""
