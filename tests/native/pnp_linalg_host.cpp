@@ -1,0 +1,16 @@
+// Host build of centerpose_amd/csrc/pnp_linalg.h for tests/test_pnp_linalg_cpu.py (the same source the device compiles).
+#include "../../centerpose_amd/csrc/pnp_linalg.h"
+
+extern "C" {
+// packed lower triangle (n (n + 1) / 2 doubles, destroyed) -> unit eigenvector of the smallest eigenvalue
+void pnp_host_smallest_eigvec12(double* A, double* out) { smallest_eigvec<12>(A, out); }
+void pnp_host_smallest_eigvec9(double* A, double* out) { smallest_eigvec<9>(A, out); }
+// row-major 6 x 6 (destroyed), b (destroyed) -> x
+void pnp_host_solve6(double* A, double* b, double* x) {
+    double Am[36], bm[6], xm[6];
+    for (int i = 0; i < 36; ++i) Am[i] = A[i];
+    for (int i = 0; i < 6; ++i) bm[i] = b[i];
+    solve6(Am, bm, xm);
+    for (int i = 0; i < 6; ++i) x[i] = xm[i];
+}
+}

@@ -1,0 +1,140 @@
+"""The dense linear algebra of the device PnP (centerpose_amd/csrc/pnp_linalg.h: smallest eigenvector by inverse
+iteration with a Rayleigh-Ritz finish, 6 x 6 elimination with register-resident pivoting) compiled for the host by
+tests/native/pnp_linalg_host.cpp and compared with numpy on the matrices the solve meets: DLT normal matrices of posed
+cuboids (well separated, and with the two smallest eigenvalues close), rank-deficient ones, damped J^T J systems."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pnp as opnp
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def host():
+    out = os.path.join(REPO, "tests", "_build", "libcp_pnp_linalg_host.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    src = os.path.join(REPO, "tests", "native", "pnp_linalg_host.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", out])
+    lib = ctypes.CDLL(out)
+    for f in (lib.pnp_host_smallest_eigvec12, lib.pnp_host_smallest_eigvec9, lib.pnp_host_solve6):
+        f.restype = None
+    return lib
+
+
+def _packed(A):
+    n = A.shape[0]
+    return np.array([A[i, j] for i in range(n) for j in range(i + 1)], np.float64)
+
+
+def _eig(host, A):
+    n = A.shape[0]
+    p, out = _packed(A), np.zeros(n)
+    fn = host.pnp_host_smallest_eigvec12 if n == 12 else host.pnp_host_smallest_eigvec9
+    fn(p.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def _dlt_matrix(rng, z_range, noise):
+    K = np.array([[663.0287679036459, 0, 300.2775065104167], [0, 663.0287679036459, 395.00066121419275], [0, 0, 1]])
+    sc = np.array([rng.uniform(0.3, 3), rng.uniform(0.5, 2.0), rng.uniform(0.3, 3)])
+    q = rng.randn(4)
+    R = opnp.quat_xyzw_to_matrix(q / np.linalg.norm(q))
+    t = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(*z_range)])
+    obj = np.repeat(opnp.cuboid_vertices(sc / sc[1]), 2, axis=0)
+    uv = opnp.project_points(obj, opnp.matrix_to_rodrigues(R), t, K) + rng.randn(16, 2) * noise
+    mn = np.stack([(uv[:, 0] - K[0, 2]) / K[0, 0], (uv[:, 1] - K[1, 2]) / K[1, 1]], 1)
+    L = np.zeros((32, 12))
+    for i in range(16):
+        X, Y, Z = obj[i]
+        x, y = -mn[i, 0], -mn[i, 1]
+        L[2 * i] = [X, Y, Z, 1, 0, 0, 0, 0, x * X, x * Y, x * Z, x]
+        L[2 * i + 1] = [0, 0, 0, 0, X, Y, Z, 1, y * X, y * Y, y * Z, y]
+    return L.T @ L
+
+
+def _angle(a, b):
+    return np.arccos(min(1.0, abs(float(a @ b))))
+
+
+def test_smallest_eigvec_on_dlt_matrices(host):
+    """Well-posed point sets (eigen-gap ratio << 1): the iteration converges and leaves through its own test."""
+    rng = np.random.RandomState(5)
+    for _ in range(200):
+        A = _dlt_matrix(rng, (3.0, 12.0), rng.choice([0.0, 0.3, 1.0]))
+        w, V = np.linalg.eigh(A)
+        v = _eig(host, A)
+        assert abs(np.linalg.norm(v) - 1) < 1e-12
+        if w[0] / w[1] < 0.5:
+            assert _angle(v, V[:, 0]) < 1e-7, (w[:3], _angle(v, V[:, 0]))
+
+
+def test_smallest_eigvec_with_close_eigenvalues(host):
+    """lambda_1 / lambda_2 in 0.75 .. 0.97 (far objects under pixel noise: plain inverse iteration would need 100 .. 600
+    steps): the Rayleigh-Ritz finish after 48 steps must return the smallest eigenvector, not a mixture."""
+    rng = np.random.RandomState(11)
+    n_slow, worst = 0, 0.0
+    for _ in range(3000):
+        A = _dlt_matrix(rng, (20.0, 60.0), 2.0)
+        w, V = np.linalg.eigh(A)
+        r12, r13 = w[0] / w[1], w[0] / w[2]
+        if not (0.75 < r12 < 0.97) or r13 > 0.5:
+            continue
+        n_slow += 1
+        ang = _angle(_eig(host, A), V[:, 0])
+        worst = max(worst, ang)
+        # what is left after the Ritz step is the third eigenvector's share: (lambda_1 / lambda_3)^48, and the conditioning of
+        # the 2 x 2 problem (1 / (1 - r12)) on float64 round-off
+        assert ang < 1e-6 + 10 * r13 ** 48, (r12, r13, ang)
+    assert n_slow >= 20, n_slow
+
+
+def test_smallest_eigvec_synthetic_spectra(host):
+    """Prescribed spectra (random orthogonal basis): separated, two close, exactly singular (exact correspondences)."""
+    rng = np.random.RandomState(3)
+    for n in (12, 9):
+        for spec in ([1e-9] + list(np.linspace(1, 5, n - 1)), [1.0, 1.05] + list(np.linspace(3, 9, n - 2)),
+                     [0.0] + list(np.linspace(0.5, 2, n - 1)), [2.0, 2.0002] + list(np.linspace(8, 20, n - 2))):
+            Q, _ = np.linalg.qr(rng.randn(n, n))
+            A = (Q * np.array(spec)) @ Q.T
+            A = 0.5 * (A + A.T)
+            v = _eig(host, A)
+            gap = spec[0] / spec[1] if spec[1] else 0.0
+            if gap < 0.999:
+                assert _angle(v, Q[:, 0]) < (1e-7 if gap < 0.9 else 1e-4), (n, spec[:2], _angle(v, Q[:, 0]))
+            # in every case: a unit vector inside the span of the two smallest eigenvectors
+            resid = v - Q[:, :2] @ (Q[:, :2].T @ v)
+            assert np.linalg.norm(resid) < 1e-6 and abs(np.linalg.norm(v) - 1) < 1e-12
+
+
+def test_solve6_matches_numpy(host):
+    """Damped normal equations of a Levenberg-Marquardt step (J^T J with its diagonal times 1 + lambda), matrices that need
+    row exchanges, and a singular one (zero pivot -> that unknown is 0, as the device code defines it)."""
+    rng = np.random.RandomState(9)
+
+    def solve(A, b):
+        x = np.zeros(6)
+        Ac, bc = np.ascontiguousarray(A, np.float64).copy(), np.ascontiguousarray(b, np.float64).copy()
+        host.pnp_host_solve6(Ac.ctypes.data_as(ctypes.c_void_p), bc.ctypes.data_as(ctypes.c_void_p),
+                             x.ctypes.data_as(ctypes.c_void_p))
+        return x
+
+    for _ in range(300):
+        J = rng.randn(32, 6) * rng.uniform(0.1, 100, 6)
+        A = J.T @ J
+        A[np.diag_indices(6)] *= 1 + 10.0 ** rng.randint(-6, 4)
+        b = rng.randn(6)
+        np.testing.assert_allclose(solve(A, b), np.linalg.solve(A, b), rtol=1e-8, atol=1e-12)
+    for _ in range(100):  # general matrices: pivoting matters
+        A = rng.randn(6, 6)
+        A[rng.randint(6), :] *= 1e-6
+        A[0, 0] = 0.0
+        b = rng.randn(6)
+        np.testing.assert_allclose(solve(A, b), np.linalg.solve(A, b), rtol=1e-6, atol=1e-9)
+    A = np.diag([1.0, 2.0, 0.0, 4.0, 5.0, 6.0])
+    x = solve(A, np.arange(1.0, 7.0))
+    np.testing.assert_allclose(x, [1.0, 1.0, 0.0, 1.0, 1.0, 1.0])
