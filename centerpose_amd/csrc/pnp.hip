@@ -28,101 +28,9 @@
 
 namespace {
 
-constexpr double DBL_EPS = 2.220446049250313e-16;
-constexpr double FLT_EPS = 1.1920928955078125e-07;
+#include "pnp_linalg.h"  // DBL_EPS / FLT_EPS, rodrigues, polar3, rot_to_rvec, smallest_eigvec<n>, solve6 (host-testable)
 
 struct Cam { double fx, fy, cx, cy; };
-
-// cv::Rodrigues vector -> matrix (+ the 27 derivatives dR/dr when WJ).  Every loop is unrolled and the outputs are
-// references to fixed-size arrays: with a nullable pointer for J the caller's dR[27] stayed in scratch memory (a store ->
-// load round trip per Jacobian of the Levenberg-Marquardt walk).
-template <bool WJ>
-__device__ __forceinline__ void rodrigues_t(const double* r, double (&R)[9], double (&J)[27]) {
-    const double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-    if (theta < DBL_EPS) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
-        if (WJ) {
-            const double j0[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int i = 0; i < 27; ++i) J[i] = j0[i];
-        }
-        return;
-    }
-    const double c = cos(theta), s = sin(theta), c1 = 1.0 - c, it = 1.0 / theta;
-    const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
-    const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
-    const double rx[9] = {0, -z, y, z, 0, -x, -y, x, 0};
-#pragma unroll
-    for (int k = 0; k < 9; ++k) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * rrt[k] + s * rx[k];
-    if (!WJ) return;
-    const double drrt[27] = {x + x, y, z, y, 0, 0, z, 0, 0, 0, x, 0, x, y + y, z, 0, z, 0, 0, 0, x, 0, 0, y, x, y, z + z};
-    const double drx[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
-    const double a[3] = {x, y, z};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double ri = a[i];
-        const double a0 = -s * ri, a1 = (s - 2 * c1 * it) * ri, a2 = c1 * it, a3 = (c - s * it) * ri, a4 = s * it;
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-            J[i * 9 + k] = a0 * ((k % 4 == 0) ? 1.0 : 0.0) + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * rx[k] +
-                           a4 * drx[i * 9 + k];
-    }
-}
-__device__ __forceinline__ void rodrigues(const double* r, double (&R)[9], double (&J)[27]) { rodrigues_t<true>(r, R, J); }
-__device__ __forceinline__ void rodrigues(const double* r, double (&R)[9], decltype(nullptr)) {
-    double none[27];
-    rodrigues_t<false>(r, R, none);
-}
-
-// polar factor U V^T of a 3x3 matrix with positive determinant (Newton iteration X <- (X + X^-T)/2)
-__device__ void polar3(const double A[9], double R[9]) {
-    double X[9];
-    for (int i = 0; i < 9; ++i) X[i] = A[i];
-    for (int it = 0; it < 60; ++it) {
-        const double c00 = X[4] * X[8] - X[5] * X[7], c01 = X[5] * X[6] - X[3] * X[8], c02 = X[3] * X[7] - X[4] * X[6];
-        const double c10 = X[2] * X[7] - X[1] * X[8], c11 = X[0] * X[8] - X[2] * X[6], c12 = X[1] * X[6] - X[0] * X[7];
-        const double c20 = X[1] * X[5] - X[2] * X[4], c21 = X[2] * X[3] - X[0] * X[5], c22 = X[0] * X[4] - X[1] * X[3];
-        const double det = X[0] * c00 + X[1] * c01 + X[2] * c02;
-        const double id = 1.0 / det;
-        // inverse-transpose = cofactor matrix / det
-        const double T[9] = {c00 * id, c01 * id, c02 * id, c10 * id, c11 * id, c12 * id, c20 * id, c21 * id, c22 * id};
-        double diff = 0;
-        for (int i = 0; i < 9; ++i) {
-            const double n = 0.5 * (X[i] + T[i]);
-            diff += fabs(n - X[i]);
-            X[i] = n;
-        }
-        if (diff < 1e-15) break;
-    }
-    for (int i = 0; i < 9; ++i) R[i] = X[i];
-}
-
-// cv::Rodrigues matrix -> vector for an orthonormal R
-__device__ void rot_to_rvec(const double R[9], double r[3]) {
-    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
-    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
-    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
-    c = c > 1 ? 1 : (c < -1 ? -1 : c);
-    double theta = acos(c);
-    if (s < 1e-5) {
-        if (c > 0) { r[0] = r[1] = r[2] = 0; return; }
-        double t = (R[0] + 1) * 0.5;
-        rx = sqrt(t > 0 ? t : 0);
-        t = (R[4] + 1) * 0.5;
-        ry = sqrt(t > 0 ? t : 0) * (R[1] < 0 ? -1.0 : 1.0);
-        t = (R[8] + 1) * 0.5;
-        rz = sqrt(t > 0 ? t : 0) * (R[2] < 0 ? -1.0 : 1.0);
-        if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && ((R[5] > 0) != (ry * rz > 0))) rz = -rz;
-        theta /= sqrt(rx * rx + ry * ry + rz * rz);
-        r[0] = rx * theta; r[1] = ry * theta; r[2] = rz * theta;
-        return;
-    }
-    const double v = theta / (2 * s);
-    r[0] = rx * v; r[1] = ry * v; r[2] = rz * v;
-}
-
-#include "pnp_linalg.h"  // smallest_eigvec<n>, solve6 (host-testable)
 
 __device__ __forceinline__ void project1(const double R[9], const double t[3], const Cam& cam, const double M[3],
                                          double& u, double& v, double& x, double& y, double& z) {

@@ -1,5 +1,6 @@
-"""The dense linear algebra of the device PnP (centerpose_amd/csrc/pnp_linalg.h: smallest eigenvector by inverse
-iteration with a Rayleigh-Ritz finish, 6 x 6 elimination with register-resident pivoting) compiled for the host by
+"""The scalar numerics of the device PnP (centerpose_amd/csrc/pnp_linalg.h: Rodrigues' formula with derivatives, polar
+factor, matrix -> rotation vector, smallest eigenvector by inverse iteration with a Rayleigh-Ritz finish, 6 x 6
+elimination with register-resident pivoting) compiled for the host by
 tests/native/pnp_linalg_host.cpp and compared with numpy on the matrices the solve meets: DLT normal matrices of posed
 cuboids (well separated, and with the two smallest eigenvalues close), rank-deficient ones, damped J^T J systems."""
 import ctypes
@@ -21,7 +22,8 @@ def host():
     src = os.path.join(REPO, "tests", "native", "pnp_linalg_host.cpp")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", out])
     lib = ctypes.CDLL(out)
-    for f in (lib.pnp_host_smallest_eigvec12, lib.pnp_host_smallest_eigvec9, lib.pnp_host_solve6):
+    for f in (lib.pnp_host_smallest_eigvec12, lib.pnp_host_smallest_eigvec9, lib.pnp_host_solve6, lib.pnp_host_rodrigues,
+              lib.pnp_host_rodrigues_nojac, lib.pnp_host_polar3, lib.pnp_host_rot_to_rvec):
         f.restype = None
     return lib
 
@@ -138,3 +140,56 @@ def test_solve6_matches_numpy(host):
     A = np.diag([1.0, 2.0, 0.0, 4.0, 5.0, 6.0])
     x = solve(A, np.arange(1.0, 7.0))
     np.testing.assert_allclose(x, [1.0, 1.0, 0.0, 1.0, 1.0, 1.0])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def test_rodrigues_and_derivatives_match_oracle(host):
+    """cv::Rodrigues vector -> matrix and dR/dr (the Jacobian block of every Levenberg-Marquardt step): against the float64
+    restatement, against finite differences, at theta ~ 0 (the identity branch) and near pi."""
+    rng = np.random.RandomState(2)
+    vecs = [rng.randn(3) * s for s in (1e-3, 0.1, 1.0, 2.0) for _ in range(25)]
+    vecs += [np.zeros(3), np.array([1e-17, 0, 0]), np.array([np.pi - 1e-6, 0, 0]), np.array([0, 2.2, 2.2])]
+    for r in vecs:
+        r = np.ascontiguousarray(r, np.float64)
+        R, J, R2 = np.zeros(9), np.zeros(27), np.zeros(9)
+        host.pnp_host_rodrigues(_ptr(r), _ptr(R), _ptr(J))
+        host.pnp_host_rodrigues_nojac(_ptr(r), _ptr(R2))
+        Ro, Jo = opnp.rodrigues_to_matrix(r, jac=True)
+        np.testing.assert_allclose(R.reshape(3, 3), Ro, rtol=0, atol=1e-14)
+        np.testing.assert_array_equal(R, R2)
+        np.testing.assert_allclose(J.reshape(3, 9), Jo, rtol=1e-12, atol=1e-13)
+        if np.linalg.norm(r) > 1e-2:  # central differences of the oracle's matrix
+            h = 1e-6
+            for i in range(3):
+                e = np.zeros(3)
+                e[i] = h
+                fd = (opnp.rodrigues_to_matrix(r + e) - opnp.rodrigues_to_matrix(r - e)).reshape(9) / (2 * h)
+                np.testing.assert_allclose(J.reshape(3, 9)[i], fd, atol=1e-8)
+
+
+def test_polar_factor_and_rotation_vector(host):
+    """polar3 = U V^T of a matrix with positive determinant (what the DLT's 3 x 3 block is turned into); rot_to_rvec is the
+    inverse of Rodrigues' formula, including rotations by (almost) pi."""
+    rng = np.random.RandomState(4)
+    for _ in range(200):
+        q = rng.randn(4)
+        R0 = opnp.quat_xyzw_to_matrix(q / np.linalg.norm(q))
+        A = R0 @ (np.eye(3) + 0.2 * rng.randn(3, 3)) * rng.uniform(0.01, 50)
+        if np.linalg.det(A) <= 0:
+            continue
+        A = np.ascontiguousarray(A.reshape(9))
+        P = np.zeros(9)
+        host.pnp_host_polar3(_ptr(A), _ptr(P))
+        U, _, Vt = np.linalg.svd(A.reshape(3, 3))
+        np.testing.assert_allclose(P.reshape(3, 3), U @ Vt, atol=1e-10)
+    angles = list(rng.uniform(0.01, 3.1, 100)) + [np.pi - 1e-7, np.pi, 1e-9, 0.0]
+    for th in angles:
+        ax = rng.randn(3)
+        ax /= np.linalg.norm(ax)
+        R = np.ascontiguousarray(opnp.rodrigues_to_matrix(ax * th).reshape(9))
+        r = np.zeros(3)
+        host.pnp_host_rot_to_rvec(_ptr(R), _ptr(r))
+        np.testing.assert_allclose(opnp.rodrigues_to_matrix(r), R.reshape(3, 3), atol=2e-7 if th > 3.1 else 1e-9)
