@@ -180,7 +180,7 @@ int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream);
 // K steps (of 16 for the f32 kernels, 32 for f16x3) and output tiles of the launch cp_launch_conv[16] would make
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 36
+#define CP_NUM_CONV_VARIANTS 37
 #define CP_VARIANT_GRU 26
 // split-f16 ("f16x3") implicit GEMM (igemm16.hip)
 bool cp_conv16_supported(const ConvParams& p);
@@ -202,6 +202,12 @@ int cp_launch_pw16(const ConvParams& p, hipStream_t stream);
 bool cp_dcn16p_supported(const ConvParams& p);
 int cp_dcn16p_blocks(const ConvParams& p);
 int cp_launch_dcn16p(const ConvParams& p, hipStream_t stream);
+// dcn16s.hip: the same gather as a persistent kernel with the halo streamed by LDS-DMA into two 16-channel buffers
+// (launches with several (patch, N tile) items per resident workgroup)
+#define CP_VARIANT_DCN16S 36
+bool cp_dcn16s_supported(const ConvParams& p);
+int cp_dcn16s_items(const ConvParams& p);
+int cp_launch_dcn16s(const ConvParams& p, hipStream_t stream);
 int cp_launch_frag16_repack(const void* w16, void* w16f, int CoutPad, int Kpad16, hipStream_t s);
 #define CP_VARIANT_DCN16P 30
 #define CP_VARIANT_GN_FINAL 31

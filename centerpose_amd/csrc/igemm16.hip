@@ -1012,6 +1012,13 @@ static bool dcn16p_wanted(const ConvParams& p) {
     return (p.dbg & 65536) || cp_dcn16p_blocks(p) >= 64;
 }
 
+// ... and, when every resident workgroup gets several (patch, N tile) items, from the persistent streamed form of the same
+// gather (dcn16s.hip).  cp_set_debug: 1048576 = never, 2097152 = every eligible launch (tests, A/B runs).
+static bool dcn16s_wanted(const ConvParams& p) {
+    if ((p.dbg & 1048576) || !dcn16p_wanted(p) || !cp_dcn16s_supported(p)) return false;
+    return (p.dbg & 2097152) || cp_dcn16s_items(p) >= 1024;
+}
+
 static bool halo16_wanted(const ConvParams& p, int bn) {
     if ((p.dbg & 4096) || p.gn_in_a || !cp_halo16_supported(p)) return false;
     // with the weight fragments coming straight from L2 (no barrier inside a chunk) the halo kernel beats the per-tap
@@ -1058,6 +1065,7 @@ int cp_launch_conv16(const ConvParams& p, hipStream_t stream) {
             return CP_ERR_INVALID;
         // dcn16.hip: the software-pipelined gather kernel; cp_set_debug(1024) keeps the previous un-pipelined loop
         // (igemm16_kernel<DCN>) for A/B runs, 2048 selects the other wave count of the new kernel
+        if (dcn16s_wanted(p)) return cp_launch_dcn16s(p, stream);
         if (dcn16p_wanted(p)) return cp_launch_dcn16p(p, stream);
         if (!(p.dbg & 1024)) return cp_launch_dcn16(p, bn, (p.dbg & 2048) ? 1 : 0, stream);
         return bn == 128 ? launch16<2, 2, 2, 2, true, false>(p, stream) : launch16<2, 1, 2, 2, true, false>(p, stream);
@@ -1077,7 +1085,7 @@ int cp_launch_conv16(const ConvParams& p, hipStream_t stream) {
 // kernel-variant ids continue after the exact-f32 ones (cp_conv_variant): 14.. = split-f16 instantiations
 int cp_conv16_variant(const ConvParams& p) {
     const int bn = conv16_tile_n(p);
-    if (p.offmask) return dcn16p_wanted(p) ? CP_VARIANT_DCN16P : bn == 128 ? 18 : 17;
+    if (p.offmask) return dcn16s_wanted(p) ? CP_VARIANT_DCN16S : dcn16p_wanted(p) ? CP_VARIANT_DCN16P : bn == 128 ? 18 : 17;
     const int t = bn == 32 ? 0 : bn == 64 ? 1 : 2;
     if (halo16_wanted(p, bn)) return 27 + t;
     if (pw16_wanted(p)) return CP_VARIANT_PW16 + (p.CoutPad % 128 == 0 ? 1 : 0);

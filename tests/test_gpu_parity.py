@@ -311,6 +311,50 @@ def test_dcn_patch_resident_vs_oracle_and_gather_kernel(device, B, C, Co, H, W, 
     assert C == 32 or not torch.equal(out, old)   # two different kernels really ran (one 32-channel chunk: same order)
 
 
+@pytest.mark.parametrize("B,C,Co,H,W,std,grid8", [
+    (2, 32, 64, 8, 16, 0.0, False),     # one patch per image, zero offsets, image border = zero fill by the DMA
+    (2, 64, 64, 16, 16, 1.5, False),    # a few exception samples per patch
+    (2, 64, 64, 32, 32, 1.5, True),     # 16 items on 8 workgroups: item -> item hand-over (prefetched chunk 0, record, weights)
+    (1, 128, 256, 32, 32, 3.0, True),   # eight chunks, four N tiles (tn changes from item to item), patches over the capacity
+    (1, 64, 128, 16, 32, 8.0, True),    # offsets far beyond the halo and the image: buffer-load mode, mixed with fast patches
+    (1, 32, 64, 64, 64, 10.0, True),    # every patch in buffer-load mode, several per workgroup
+    (2, 64, 64, 32, 32, 2.0, True),     # the upper end of the synthetic network's offset scale
+    (3, 64, 64, 40, 48, 1.0, True),     # 45 items: uneven item counts per XCD, non-power-of-two map
+    (1, 64, 64, 128, 128, 1.5, False),  # the heaviest layer shape of the network (dla_up 64 -> 64 at 128 x 128)
+])
+def test_dcn_streamed_persistent_vs_oracle_and_gather_kernel(device, B, C, Co, H, W, std, grid8):
+    """dcn16s.hip (persistent workgroups, halo chunks and exception corners streamed by LDS-DMA into two buffers) against the
+    float64 oracle and against dcn16.hip (cp_set_debug 32768).  cp_set_debug 65536 | 2097152 selects it for launches of any size,
+    8388608 limits the grid to 8 workgroups so that small problems exercise the item-to-item hand-over."""
+    hip.set_default_precision("f16x3")
+    try:
+        g = torch.Generator().manual_seed(C + H + int(std * 10))
+        x = torch.randn(B, C, H, W, generator=g)
+        w = torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5
+        b = torch.randn(Co, generator=g)
+        off = torch.randn(B, 18, H, W, generator=g) * std
+        mask = torch.rand(B, 9, H, W, generator=g)
+        ref = odcn.dcn_v2_forward_f64(x, w, b, off, mask)
+        args = [t.to(device) for t in (x, w, b, off, mask)] + [3, 3, 1, 1, 1, 1, 1, 1, 1]
+        hip.lib().cp_set_debug(65536 | 2097152 | (8388608 if grid8 else 0))
+        try:
+            out = hip.dcn_v2_forward(*args).cpu()
+            out2 = hip.dcn_v2_forward(*args).cpu()
+        finally:
+            hip.lib().cp_set_debug(0)
+        hip.lib().cp_set_debug(32768)
+        try:
+            old = hip.dcn_v2_forward(*args).cpu()
+        finally:
+            hip.lib().cp_set_debug(0)
+    finally:
+        hip.set_default_precision("f32")
+    assert torch.equal(out, out2)   # deterministic (no atomics on the data path, no race between DMA and gather)
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert float((out - old).abs().max() / ref.abs().max()) < 2e-6
+    assert not torch.equal(out, old)   # two different kernels really ran (summation order differs)
+
+
 @pytest.fixture
 def f16x3():
     hip.set_default_precision("f16x3")
