@@ -51,6 +51,15 @@ extern "C" int cp_debug_read_dcn_clk(unsigned long long* out) {
 #define DCN_STAMP(i) do { } while (0)
 #endif
 
+#if CP_DCN_EXP & (32 | 262144)
+// tuning build 32 / 262144 (at the end of the kernel): every lane re-derives its 9 taps' set-up from a fresh copy of the record after the half-wave exchange and
+// logs disagreements (tools/probe/dcn16p_race.py --chk): [0] = count, then 8 words per entry
+__device__ unsigned g_dcn_chk[8 + 64 * 8];
+extern "C" int cp_debug_read_dcn_chk(unsigned* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dcn_chk), sizeof(unsigned) * (8 + 64 * 8)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace {
 
 constexpr int TH = PATCH_TH, TW = PATCH_TW, HALO = 3;
@@ -67,10 +76,20 @@ __device__ __forceinline__ float4 buf_ld4s(__amdgpu_buffer_rsrc_t r, unsigned vo
 }
 
 // both 32-lane halves of `v` for every lane: {lower half's value, upper half's value}
-__device__ __forceinline__ void both_halves(uint32_t v, uint32_t* lo, uint32_t* hi) {
-    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    *lo = r[0];
-    *hi = r[1];
+__device__ __forceinline__ void both_halves5(const uint32_t (&v)[5], uint32_t (&lo)[5], uint32_t (&hi)[5]) {
+    // v_permlane32_swap_b32 vdst, vsrc exchanges vdst[32..63] with vsrc[0..31]; with both operands holding v every lane ends up
+    // with {the lower half's value, the upper half's value}.  Written out with its own wait states: the compiler's sequence
+    // (v_mov tmp, x / v_permlane32_swap x, tmp / v_mov tmp, y / ...) re-writes the swap's second operand in the very next
+    // instruction, and on a wave that has its SIMD to itself (the last workgroups of a launch) the swap's own late write to
+    // that register then wins in lanes 16-31: roughly one launch in a hundred computed 16 pixels of one wave from the wrong
+    // corner addresses (profiles/NOTES.md, round 4).  Distinct registers per swap, padded on both sides.
+    uint32_t a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], b0 = v[0], b1 = v[1], b2 = v[2], b3 = v[3], b4 = v[4];
+    asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %5\n\ts_nop 1\n\tv_permlane32_swap_b32 %1, %6\n\ts_nop 1\n\t"
+                 "v_permlane32_swap_b32 %2, %7\n\ts_nop 1\n\tv_permlane32_swap_b32 %3, %8\n\ts_nop 1\n\t"
+                 "v_permlane32_swap_b32 %4, %9\n\ts_nop 4"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4));
+    lo[0] = a0; lo[1] = a1; lo[2] = a2; lo[3] = a3; lo[4] = a4;
+    hi[0] = b0; hi[1] = b1; hi[2] = b2; hi[3] = b3; hi[4] = b4;
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -86,6 +105,10 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     __shared__ int exc_goff[ECAP];  // that corner's byte offset into the input tensor (may be "before" it: see validity)
     __shared__ __attribute__((aligned(16))) float exc_w[ECAP][4];  // its four corner weights
     __shared__ int exc_count;
+#if CP_DCN_EXP & 4096
+    __shared__ int lds_ballast[12 * 1024];
+    if (p.dbg == 0x7fffffff) lds_ballast[threadIdx.x] = 1;
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     DCN_STAMP(0);
@@ -99,9 +122,13 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     const int tx0 = (tm % txs) * TW;
     tm /= txs;
     const int ty0 = (tm % tys) * TH, b = tm / tys;
-    constexpr bool EARLY = true;  // (false: the round-2 prologue, one memory round trip per stage -- profiles/NOTES.md)
+    // EARLY (tuning build 128): every prologue load -- record, first chunk, activation scale -- in flight before anything waits.
+    // OFF since round 4: it measured +-0 (the CU's fill rate bounds the prologue, profiles/NOTES.md round 3) and it is the one
+    // configuration in which about one launch in a hundred came back with 16 pixels of one wave computed from wrong bilinear
+    // set-up values (lanes 48-63 -> 16-31 of the set-up's packed-f32 arithmetic; tools/probe/dcn16p_race.py, NOTES round 4).
+    constexpr bool EARLY = (CP_DCN_EXP & 128) != 0;
     float afwd, ainv;
-    if (!EARLY) {
+    if (!EARLY || (CP_DCN_EXP & 131072)) {
         conv_in_scale(p, &afwd, &ainv);
         // wave-uniform: keep both in scalar registers (the vector file is full)
         afwd = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(afwd)));
@@ -144,6 +171,15 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     } else {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
+#if CP_DCN_EXP & 524288
+            if (i == 1) {  // the upper half's second quad spans bytes 56 .. 71 of the record: two 8-byte loads instead of one that
+                           // straddles the 64-byte boundary
+                const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(r_om, (int)(rec + (unsigned)lrow * 40u + 16u), 0, 0);
+                const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(r_om, (int)(rec + (unsigned)lrow * 40u + 24u), 0, 0);
+                od[4] = __uint_as_float(a.x); od[5] = __uint_as_float(a.y); od[6] = __uint_as_float(c.x); od[7] = __uint_as_float(c.y);
+                continue;
+            }
+#endif
             const float4 v = buf_ld4(r_om, rec + (unsigned)lrow * 40u + 16u * i);
             od[4 * i] = v.x; od[4 * i + 1] = v.y; od[4 * i + 2] = v.z; od[4 * i + 3] = v.w;
         }
@@ -163,9 +199,14 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
             sv0[s] = buf_ld4s(r_x, (row_ok && col_ok) ? (unsigned)(st_base + (s - HALO) * rowb) : OOB, 0);
         }
         DCN_STAMP(50);  // all prologue loads issued
+        if (!(CP_DCN_EXP & 131072)) {
         conv_in_scale(p, &afwd, &ainv);
         afwd = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(afwd)));
         ainv = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ainv)));
+        }
+#if CP_DCN_EXP & 16384
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
         DCN_STAMP(51);  // activation scale arrived (scalar loads)
         // park the rows right away (this is the one wait of the prologue; the record arrived with them): the 56 registers
         // are free again before the set-up below needs the file
@@ -175,6 +216,9 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
         DCN_STAMP(52);  // rows arrived and parked (this wave)
     }
     __syncthreads();  // exc_count = 0 is visible
+#if CP_DCN_EXP & 8192
+    __syncthreads();
+#endif
     DCN_STAMP(2);  // zeroing done, record loads issued, first barrier passed
 
     // ---- bilinear set-up (dcn_v2_im2col_cuda.cu:25-54, 150-187): 5 tap slots per lane, then both halves swap ----
@@ -230,17 +274,55 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     f32x2 bw[9][2];  // {w1, w2}, {w3, w4}: corner weights x mask x activation pre-scale
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        uint32_t lo, hi;
-        both_halves(sq[j], &lo, &hi);
-        addr[j] = (int)lo * PSTR + lrow * 32;
-        if (j < 4) addr[5 + j] = (int)hi * PSTR + lrow * 32;
+        const uint32_t pack[5] = {sq[j], sw[j][0], sw[j][1], sw[j][2], sw[j][3]};
+        uint32_t lo[5], hi[5];
+        both_halves5(pack, lo, hi);
+        addr[j] = (int)lo[0] * PSTR + lrow * 32;
+        if (j < 4) addr[5 + j] = (int)hi[0] * PSTR + lrow * 32;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            both_halves(sw[j][c], &lo, &hi);
-            bw[j][c >> 1][c & 1] = __uint_as_float(lo);
-            if (j < 4) bw[5 + j][c >> 1][c & 1] = __uint_as_float(hi);
+            bw[j][c >> 1][c & 1] = __uint_as_float(lo[1 + c]);
+            if (j < 4) bw[5 + j][c >> 1][c & 1] = __uint_as_float(hi[1 + c]);
         }
     }
+#if CP_DCN_EXP & 32
+    {
+        float o9[28];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const float4 v = buf_ld4(r_om, rec + 16u * i);
+            o9[4 * i] = v.x; o9[4 * i + 1] = v.y; o9[4 * i + 2] = v.z; o9[4 * i + 3] = v.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float h_im = (fy0 + (float)(t / 3)) + o9[2 * t];
+            float w_im = (fx0 + (float)(t % 3)) + o9[2 * t + 1];
+            const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W;
+            h_im = valid ? h_im : 0.f;
+            w_im = valid ? w_im : 0.f;
+            const float mk = valid ? o9[18 + t] * afwd : 0.f;
+            const float fh = floorf(h_im), fw = floorf(w_im);
+            const int h_lo = (int)fh, w_lo = (int)fw;
+            const float lh = h_im - fh, lw = w_im - fw;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const float e1 = hh * hw * mk, e2 = hh * lw * mk, e3 = lh * hw * mk, e4 = lh * lw * mk;
+            const int qy = h_lo - (ty0 - HALO), qx = w_lo - (tx0 - HALO);
+            const bool inp = (unsigned)qy <= (unsigned)(PH - 2) && (unsigned)qx <= (unsigned)(PW - 2);
+            const int ea = (inp ? qy * PW + qx : 0) * PSTR + lrow * 32;
+            bool bad;
+            if (valid && !inp) bad = !(addr[t] >= NPIX * PSTR || exc_count > ECAP);  // filed as an exception (or overflow)
+            else bad = addr[t] != ea || bw[t][0].x != e1 || bw[t][0].y != e2 || bw[t][1].x != e3 || bw[t][1].y != e4;
+            if (bad) {
+                const unsigned k = atomicAdd(&g_dcn_chk[0], 1u);
+                if (k < 64) {
+                    unsigned* o = g_dcn_chk + 8 + 8 * k;
+                    o[0] = blockIdx.x; o[1] = tid; o[2] = t; o[3] = (unsigned)addr[t]; o[4] = (unsigned)ea;
+                    o[5] = __float_as_uint(bw[t][0].x); o[6] = __float_as_uint(e1); o[7] = (unsigned)(valid ? 1 : 0) | (inp ? 2 : 0);
+                }
+            }
+        }
+    }
+#endif
     __syncthreads();
     DCN_STAMP(3);  // records arrived, set-up done, second barrier passed
     const int nexc_all = __builtin_amdgcn_readfirstlane(exc_count);  // scalar: the mode branches below stay uniform
@@ -271,7 +353,11 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     const int nch = p.Cin / CKC;
 
     // blend + split of one gathered K step, then its 3 NT MFMAs
-    auto mma_step = [&](const float4 (&r)[4][2], const f32x2 (&w)[2], const u32x4 (&bh)[NT], const u32x4 (&bl)[NT]) {
+    // `mid` runs between the blend and the MFMAs: the refill of the weight set the PREVIOUS step consumed.  It must not be issued
+    // right behind that step's MFMAs: a load that returns from L1 / L2 while the last of six back-to-back MFMAs is still reading
+    // its B operand overwrites it (seen as wrong fragment rows 16 .. 31 in the last, lonely workgroups of a launch, about one
+    // launch in 60: profiles/NOTES.md, round 4); behind the blend's ~50 VALU instructions those MFMAs have long retired.
+    auto mma_step = [&](const float4 (&r)[4][2], const f32x2 (&w)[2], const u32x4 (&bh)[NT], const u32x4 (&bl)[NT], auto&& mid) {
         // fma(w4, v4, fma(w3, v3, fma(w2, v2, w1 * v1))) per channel (dcn16.hip's order), two per v_pk_fma_f32
         uint32_t hi[4], lo[4];
         if (ABL && (abl & 2)) {
@@ -297,6 +383,12 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
         }
         const u32x4 ahv = {hi[0], hi[1], hi[2], hi[3]}, alv = {lo[0], lo[1], lo[2], lo[3]};
         const h8 ah = *reinterpret_cast<const h8*>(&ahv), al = *reinterpret_cast<const h8*>(&alv);
+        __builtin_amdgcn_sched_barrier(0);
+        mid();
+        __builtin_amdgcn_sched_barrier(0);
+#if CP_DCN_EXP & 64
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
         if (ABL && (abl & 4)) {  // keep the operands alive without the matrix pipe
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[0][j][0] += __uint_as_float(ahv.x ^ alv.y ^ bh[j].x ^ bl[j].y);
@@ -348,10 +440,9 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
                 *reinterpret_cast<float4*>(patch + (NPIX + e) * PSTR + (tid & 7) * 16) = o;
             }
         };
-        // weights of steps 0, 1, 2 in flight before the first chunk is staged
+        // weights of steps 0 and 1 in flight before the first chunk is staged (step u refills set (u + 2) % 3 with step u + 2)
         issue_b(0, 0 * gpt + 0);
         issue_b(1, 0 * gpt + 1);
-        issue_b(2, 1 * gpt + 0);
         for (int ch = 0; ch < nch; ++ch) {
             DCN_STAMP(4 + 24 * ch);  // chunk start
             if (ch > 0) __syncthreads();  // every wave is done with the previous chunk's patch
@@ -405,11 +496,14 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
                 // just above its first use -- no prefetch, a full LDS / L2 round trip exposed per step
                 if (u + 1 < NSTEP) gather(raw[(u + 1) & 1], addr[(u + 1) >> 1] + ((u + 1) & 1) * 64);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_step(raw[u & 1], bw[u >> 1], wbh[u % 3], wbl[u % 3]);
-                __builtin_amdgcn_sched_barrier(0);
-                // refill the set just consumed with step u + 3 (of this chunk or the next)
-                const int u3 = u + 3 < NSTEP ? u + 3 : u + 3 - NSTEP, ch3 = u + 3 < NSTEP ? ch : ch + 1;
-                if (ch3 < nch) issue_b(u % 3, (u3 >> 1) * gpt + 2 * ch3 + (u3 & 1));
+#if CP_DCN_EXP & 1024
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                mma_step(raw[u & 1], bw[u >> 1], wbh[u % 3], wbl[u % 3], [&]() {
+                    // the set step u - 1 consumed takes step u + 2 (of this chunk or the next)
+                    const int u2 = u + 2 < NSTEP ? u + 2 : u + 2 - NSTEP, ch2 = u + 2 < NSTEP ? ch : ch + 1;
+                    if (ch2 < nch) issue_b((u + 2) % 3, (u2 >> 1) * gpt + 2 * ch2 + (u2 & 1));
+                });
                 __builtin_amdgcn_sched_barrier(0);
                 if ((CP_DCN_EXP & 16) || u == NSTEP - 1) DCN_STAMP(7 + 24 * ch + ((CP_DCN_EXP & 16) ? u : 0));  // per step (16) / chunk done
             }
@@ -449,12 +543,11 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
             }
         }
         issue_b(0, 0);
+        issue_b(1, 1);
         for (int ch = 0; ch < nch; ++ch) {
 #pragma unroll
             for (int u = 0; u < NSTEP; ++u) {
                 const int t = u >> 1, ks = u & 1;
-                const int u1 = u + 1 < NSTEP ? u + 1 : 0, ch1 = u + 1 < NSTEP ? ch : ch + 1;
-                if (ch1 < nch) issue_b((u + 1) & 1, (u1 >> 1) * gpt + 2 * ch1 + (u1 & 1));
                 float4 r[4][2];
                 const int so = (ch * CKC + ks * 16) * 4;
                 const int base = (addr[t] & ~15) + lrow * 32;
@@ -464,7 +557,10 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
                     r[c][0] = buf_ld4s(r_x, (unsigned)gi, so);
                     r[c][1] = buf_ld4s(r_x, (unsigned)gi + 16u, so);
                 }
-                mma_step(r, bw[t], wbh[u & 1], wbl[u & 1]);
+                mma_step(r, bw[t], wbh[u % 3], wbl[u % 3], [&]() {
+                    const int u2 = u + 2 < NSTEP ? u + 2 : u + 2 - NSTEP, ch2 = u + 2 < NSTEP ? ch : ch + 1;
+                    if (ch2 < nch) issue_b((u + 2) % 3, (u2 >> 1) * gpt + 2 * ch2 + (u2 & 1));
+                });
                 __builtin_amdgcn_sched_barrier(0);  // keep the loads of later steps below: the register file is full
             }
         }
@@ -479,8 +575,54 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
         if (sacc == 1.2345e-30f) p.out[0] = sacc;
         return;
     }
+#if CP_DCN_EXP & 2048
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
     patch_epilogue<1, NT, 4, 1, true>(p, acc, b, ty0, tx0, tn, wid, 0, lane, ainv);
     DCN_STAMP(61);  // epilogue stores issued
+#if CP_DCN_EXP & 262144
+    if (!slow) {
+        float o9[28];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const float4 v = buf_ld4(r_om, rec + 16u * i);
+            o9[4 * i] = v.x; o9[4 * i + 1] = v.y; o9[4 * i + 2] = v.z; o9[4 * i + 3] = v.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float h_im = (fy0 + (float)(t / 3)) + o9[2 * t];
+            float w_im = (fx0 + (float)(t % 3)) + o9[2 * t + 1];
+            const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W;
+            h_im = valid ? h_im : 0.f;
+            w_im = valid ? w_im : 0.f;
+            const float mk = valid ? o9[18 + t] * afwd : 0.f;
+            const float fh = floorf(h_im), fw = floorf(w_im);
+            const int h_lo = (int)fh, w_lo = (int)fw;
+            const float lh = h_im - fh, lw = w_im - fw;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const float e1 = hh * hw * mk, e2 = hh * lw * mk, e3 = lh * hw * mk, e4 = lh * lw * mk;
+            const int qy = h_lo - (ty0 - HALO), qx = w_lo - (tx0 - HALO);
+            const bool inp = (unsigned)qy <= (unsigned)(PH - 2) && (unsigned)qx <= (unsigned)(PW - 2);
+            const int ea = (inp ? qy * PW + qx : 0) * PSTR + lrow * 32;
+            bool bad;
+            if (valid && !inp) bad = !(addr[t] >= NPIX * PSTR || slow);  // filed as an exception (or overflow)
+            else bad = addr[t] != ea || bw[t][0].x != e1 || bw[t][0].y != e2 || bw[t][1].x != e3 || bw[t][1].y != e4;
+            if (bad) {
+                const unsigned k = atomicAdd(&g_dcn_chk[0], 1u);
+                if (k < 64) {
+                    unsigned* o = g_dcn_chk + 8 + 8 * k;
+                    o[0] = blockIdx.x; o[1] = tid; o[2] = t; o[3] = (unsigned)addr[t]; o[4] = (unsigned)ea;
+                    o[5] = __float_as_uint(bw[t][0].x); o[6] = __float_as_uint(e1); o[7] = (unsigned)(valid ? 1 : 0) | (inp ? 2 : 0);
+                    if (lrow && t >= 5) {  // the stale values themselves: this lane's own copy of the tap's offsets
+                        o[5] = __float_as_uint(od[2 * (t - 5)]); o[6] = __float_as_uint(od[2 * (t - 5) + 1]);
+                        o[7] = 0x80000000u | (unsigned)(((b * p.H + y) * p.W + x));
+                    }
+                }
+            }
+        }
+    }
+#endif
+
 }
 
 // [CoutPad][Kpad16] binary16 -> MFMA B-operand order: fragment (n tile j of 32, K step g of 16) = 64 lanes x 16 bytes,

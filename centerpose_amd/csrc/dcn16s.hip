@@ -53,10 +53,20 @@ __device__ __forceinline__ float4 s_ld4s(__amdgpu_buffer_rsrc_t r, unsigned voff
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-__device__ __forceinline__ void s_both_halves(uint32_t v, uint32_t* lo, uint32_t* hi) {
-    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    *lo = r[0];
-    *hi = r[1];
+__device__ __forceinline__ void s_both_halves5(const uint32_t (&v)[5], uint32_t (&lo)[5], uint32_t (&hi)[5]) {
+    // v_permlane32_swap_b32 vdst, vsrc exchanges vdst[32..63] with vsrc[0..31]; with both operands holding v every lane ends up
+    // with {the lower half's value, the upper half's value}.  Written out with its own wait states: the compiler's sequence
+    // (v_mov tmp, x / v_permlane32_swap x, tmp / v_mov tmp, y / ...) re-writes the swap's second operand in the very next
+    // instruction, and on a wave that has its SIMD to itself (the last workgroups of a launch) the swap's own late write to
+    // that register then wins in lanes 16-31: roughly one launch in a hundred computed 16 pixels of one wave from the wrong
+    // corner addresses (profiles/NOTES.md, round 4).  Distinct registers per swap, padded on both sides.
+    uint32_t a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], b0 = v[0], b1 = v[1], b2 = v[2], b3 = v[3], b4 = v[4];
+    asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %5\n\ts_nop 1\n\tv_permlane32_swap_b32 %1, %6\n\ts_nop 1\n\t"
+                 "v_permlane32_swap_b32 %2, %7\n\ts_nop 1\n\tv_permlane32_swap_b32 %3, %8\n\ts_nop 1\n\t"
+                 "v_permlane32_swap_b32 %4, %9\n\ts_nop 4"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4));
+    lo[0] = a0; lo[1] = a1; lo[2] = a2; lo[3] = a3; lo[4] = a4;
+    hi[0] = b0; hi[1] = b1; hi[2] = b2; hi[3] = b3; hi[4] = b4;
 }
 
 // One LDS-DMA piece: lane l's 16 bytes at (voff + soff) of the buffer land at LDS byte lds_addr + 16 l (lanes masked off by
@@ -181,7 +191,6 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
     load_record(cur);
     issue_b(0, cur.tn, 0 * gpt);
     issue_b(1, cur.tn, 1 * gpt);
-    issue_b(2, cur.tn, 2 * gpt);
     float afwd, ainv;
     conv_in_scale(p, &afwd, &ainv);
     afwd = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(afwd)));
@@ -255,15 +264,15 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
         s_f32x2 bw[9][2];  // {w1, w2}, {w3, w4}
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            uint32_t lo, hi;
-            s_both_halves(sq[j], &lo, &hi);
-            addr[j] = (int)lo + lrow * 32;
-            if (j < 4) addr[5 + j] = (int)hi + lrow * 32;
+            const uint32_t pack[5] = {sq[j], sw[j][0], sw[j][1], sw[j][2], sw[j][3]};
+            uint32_t lo[5], hi[5];
+            s_both_halves5(pack, lo, hi);
+            addr[j] = (int)lo[0] + lrow * 32;
+            if (j < 4) addr[5 + j] = (int)hi[0] + lrow * 32;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                s_both_halves(sw[j][c], &lo, &hi);
-                bw[j][c >> 1][c & 1] = __uint_as_float(lo);
-                if (j < 4) bw[5 + j][c >> 1][c & 1] = __uint_as_float(hi);
+                bw[j][c >> 1][c & 1] = __uint_as_float(lo[1 + c]);
+                if (j < 4) bw[5 + j][c >> 1][c & 1] = __uint_as_float(hi[1 + c]);
             }
         }
         __syncthreads();  // the exception list is complete
@@ -279,8 +288,11 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
 #pragma unroll
             for (int r = 0; r < F::NACC; ++r) acc[j][r] = 0.f;
 
-        // blend + split of one gathered K step, then its 3 NT MFMAs (term order of igemm16.hip: lo*hi, hi*lo, hi*hi)
-        auto mma_step = [&](const float4 (&r)[4][2], const s_f32x2 (&w)[2], const u32x4 (&bh)[NT], const u32x4 (&bl)[NT]) {
+        // blend + split of one gathered K step, then its 3 NT MFMAs (term order of igemm16.hip: lo*hi, hi*lo, hi*hi).  `mid` runs
+        // between the two: the refill of the weight set the PREVIOUS step consumed -- never right behind that step's MFMAs, whose
+        // B operand a fast-returning load would overwrite while the matrix pipe still reads it (dcn16p.hip, mma_step).
+        auto mma_step = [&](const float4 (&r)[4][2], const s_f32x2 (&w)[2], const u32x4 (&bh)[NT], const u32x4 (&bl)[NT],
+                            auto&& mid) {
             uint32_t hi[4], lo[4];
 #pragma unroll
             for (int hq = 0; hq < 2; ++hq) {
@@ -296,6 +308,12 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
             }
             const u32x4 ahv = {hi[0], hi[1], hi[2], hi[3]}, alv = {lo[0], lo[1], lo[2], lo[3]};
             const h8 ah = *reinterpret_cast<const h8*>(&ahv), al = *reinterpret_cast<const h8*>(&alv);
+            __builtin_amdgcn_sched_barrier(0);
+            mid();
+            __builtin_amdgcn_sched_barrier(0);
+#if defined(CP_DCN_EXP) && (CP_DCN_EXP & 64)
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // tuning build: slower K steps (tools/probe/dcn16p_race.py)
+#endif
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, *reinterpret_cast<const h8*>(&bh[j]), acc[j], 0, 0, 0);
@@ -306,18 +324,18 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
             for (int j = 0; j < NT; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, *reinterpret_cast<const h8*>(&bh[j]), acc[j], 0, 0, 0);
         };
-        // the weight set just consumed by step (ch, t) is refilled with the step three ahead: of this chunk, of the next one, or
-        // of the next item's first chunk
+        // inside step (ch, t): the weight set step t - 1 consumed takes the step two ahead -- of this chunk, of the next one, or of
+        // the next item's first chunk
         auto refill = [&](int ch, int t) {
-            const int t3 = t + 3 < S_NSTEP ? t + 3 : t + 3 - S_NSTEP;
-            int ch3 = t + 3 < S_NSTEP ? ch : ch + 1;
-            int tn3 = cur.tn;
-            if (ch3 >= nch) {
+            const int t2 = t + 2 < S_NSTEP ? t + 2 : t + 2 - S_NSTEP;
+            int ch2 = t + 2 < S_NSTEP ? ch : ch + 1;
+            int tn2 = cur.tn;
+            if (ch2 >= nch) {
                 if (!has_next) return;
-                ch3 = 0;
-                tn3 = nxt.tn;
+                ch2 = 0;
+                tn2 = nxt.tn;
             }
-            issue_b(t % 3, tn3, t3 * gpt + ch3);
+            issue_b((t + 2) % 3, tn2, t2 * gpt + ch2);
         };
 
         if (!slow) {
@@ -396,15 +414,14 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
                     // the order of the three phases is pinned: gather of the next tap, blend + MFMAs of this one, weight refill
                     if (t + 1 < S_NSTEP) gather(raw[(t + 1) & 1], addr[t + 1]);
                     __builtin_amdgcn_sched_barrier(0);
-                    mma_step(raw[t & 1], bw[t], wbh[t % 3], wbl[t % 3]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    refill(ch, t);
+                    mma_step(raw[t & 1], bw[t], wbh[t % 3], wbl[t % 3], [&]() { refill(ch, t); });
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // ---- chunk boundary: this wave's DMA pieces have landed once at most the 3 x 2 NT weight loads issued after
-                //      them are outstanding; its exceptions' corners are blended into the other buffer; one barrier ----
+                // ---- chunk boundary: this wave's DMA pieces have landed once at most the 2 x 2 NT weight loads issued after
+                //      them (steps 7 and 8: the next chunk's first two steps) are outstanding; its exceptions' corners are
+                //      blended into the other buffer; one barrier ----
                 if (!last || has_next) {
-                    if (NT == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    if (NT == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 if (!last) blend_corners(PAR ^ 1);
@@ -460,9 +477,7 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
                         r[c][0] = s_ld4s(r_x, (unsigned)gi, so);
                         r[c][1] = s_ld4s(r_x, (unsigned)gi + 16u, so);
                     }
-                    mma_step(r, bw[t], wbh[t % 3], wbl[t % 3]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    refill(ch, t);
+                    mma_step(r, bw[t], wbh[t % 3], wbl[t % 3], [&]() { refill(ch, t); });
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }

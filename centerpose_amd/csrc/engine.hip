@@ -1480,6 +1480,7 @@ extern "C" {
 
 const char* cp_version(void) { return "centerpose_hip 0.3.0 (gfx950; f32 and split-f16 MFMA)"; }
 int cp_abi_version(void) { return CP_ABI_VERSION; }
+static_assert(CP_NUM_KERNEL_VARIANTS == CP_NUM_CONV_VARIANTS, "public and internal kernel-variant counts");
 int cp_num_kernel_variants(void) { return CP_NUM_KERNEL_VARIANTS; }
 int cp_num_roles(void) { return CP_NUM_ROLES; }
 const char* cp_last_error(void) { return g_err.c_str(); }

@@ -41,6 +41,14 @@ __device__ __forceinline__ uint32_t pk(float a, float b) {
 // (v_cvt_f32_f16 + v_sub_f32 per element) -- the conversion is most of the loaders' VALU work.
 __device__ __forceinline__ Split2 split2(float a, float b) {
     Split2 s;
+#if defined(CP_DCN_EXP) && (CP_DCN_EXP & 256)
+    {   // tuning build: the same split without inline assembly
+        fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+        s.hi = *reinterpret_cast<uint32_t*>(&h);
+        s.lo = pk(a - (float)h.x, b - (float)h.y);
+        return s;
+    }
+#endif
     fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
     s.hi = *reinterpret_cast<uint32_t*>(&h);
     float ra, rb;
