@@ -28,6 +28,23 @@
 
 #include "patch16_common.h"
 
+// Tuning builds (make variant ... DEFS=-DCP_DCN_EXP=n; timing only, results wrong): 1 << 20 no halo / corner DMA, 1 << 21 no
+// weight-fragment loads, 1 << 22 no epilogue stores, 1 << 23 no gather reads, 1 << 24 no MFMAs, 1 << 25 no blend arithmetic
+#ifndef CP_DCN_EXP
+#define CP_DCN_EXP 0
+#endif
+
+#if CP_DCN_EXP & 8
+// tuning build 8: shader-clock stamps of wave 0 of one mid-launch workgroup during its fourth item (tools/dcn16s_timeline.py)
+__device__ unsigned long long g_dcn16s_clk[64];
+#define S_STAMP(i) do { if (blockIdx.x == 203 && threadIdx.x == 0 && item_no == 3) g_dcn16s_clk[i] = clock64(); } while (0)
+extern "C" int cp_debug_read_dcn16s_clk(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dcn16s_clk), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#else
+#define S_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int S_TH = PATCH_TH, S_TW = PATCH_TW, S_HALO = 4;
@@ -43,7 +60,8 @@ constexpr int S_EW = S_CORN + S_ECAP * 256;                        // float4 cor
 constexpr int S_EGOFF = S_EW + S_ECAP * 16;                        // top-left corner's byte offset into the input tensor
 constexpr int S_EKEY = S_EGOFF + S_ECAP * 4;                       // (h_lo + 1) << 16 | (w_lo + 1)
 constexpr int S_ECNT = S_EKEY + S_ECAP * 4;                        // two counters (patch parity)
-constexpr int S_LDS = S_ECNT + 16;
+constexpr int S_SCSH = S_ECNT + 16;                                // epilogue constants of the item's N tile: 64 scales, 64 shifts
+constexpr int S_LDS = S_SCSH + 512;
 constexpr int S_NSTEP = 9;                                         // K steps (one tap x 16 channels) per chunk
 static_assert(S_BUFB % 16 == 0 && S_LDS <= 80 * 1024 - 128, "two workgroups per CU");
 static_assert((S_ROWB / 16) % 16 == 1, "row pitch = 1 bank group mod 16");
@@ -74,6 +92,7 @@ __device__ __forceinline__ void s_both_halves5(const uint32_t (&v)[5], uint32_t 
 // s_waitcnt vmcnt, visibility to other waves = a barrier after that.  s_nop 4: the operands may come straight from
 // v_readfirstlane / v_cmp (VALU-written SGPRs read by VMEM); s_nop 0: M0 written by SALU, read by the DMA.
 __device__ __forceinline__ void s_dma16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned lds_addr) {
+    if (CP_DCN_EXP & (1 << 20)) return;
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :
                  : "s"(lds_addr), "v"(voff), "s"(r), "s"(soff)
@@ -176,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
     //      register sets, K step s of an item uses set s % 3 (9 steps per chunk keep the rotation aligned) ----
     u32x4 wbh[3][NT], wbl[3][NT];
     auto issue_b = [&](int set, int tn, int g) {
+        if ((CP_DCN_EXP & (1 << 21)) && g >= 0) return;
         const unsigned b_lane = (unsigned)(lane * 16);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -185,8 +205,23 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
         }
     };
 
+    if (CP_DCN_EXP & (1 << 21)) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wbh[k][j] = wbl[k][j] = u32x4{0x3c003c00u + (unsigned)lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    }
+    // the epilogue's per-channel scale / shift of N tile tn, once per workgroup (again only if a later item has another tn)
+    auto write_scsh = [&](int tn) {
+        if (tid < 32 * NT) {
+            const int n = tn * (32 * NT) + tid;
+            reinterpret_cast<float*>(smem + S_SCSH)[tid] = (p.scale && n < p.Cout) ? p.scale[n] : 1.f;
+            reinterpret_cast<float*>(smem + S_SCSH)[32 * NT + tid] = (p.shift && n < p.Cout) ? p.shift[n] : 0.f;
+        }
+    };
     // =============================== prologue (once per workgroup) ===============================
     SItem cur = s_item(it, tiles_n, txs, tys);
+    write_scsh(cur.tn);
     issue_halo(cur, 0, 0);
     load_record(cur);
     issue_b(0, cur.tn, 0 * gpt);
@@ -208,6 +243,8 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
 
     float amax = 0.f;
     int parity = 0;  // patch parity: which exception counter this item uses
+    int item_no = 0;
+    (void)item_no;
     const int act = p.act;
 
     for (;;) {
@@ -215,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
         const bool has_next = it_next < it_end;
         const SItem nxt = s_item(has_next ? it_next : it, tiles_n, txs, tys);
         int* const ecnt = reinterpret_cast<int*>(smem + S_ECNT);
+        S_STAMP(0);
 
         // ---- bilinear set-up (dcn_v2_im2col_cuda.cu:25-54, 150-187): 5 tap slots per lane, then both halves swap ----
         const int ln0 = s_opaque(lane), lrow = ln0 >> 5, q8 = (ln0 >> 2) & 7;
@@ -275,7 +313,9 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
                 if (j < 4) bw[5 + j][c >> 1][c & 1] = __uint_as_float(hi[1 + c]);
             }
         }
+        S_STAMP(1);
         __syncthreads();  // the exception list is complete
+        S_STAMP(2);
         const int nexc_all = __builtin_amdgcn_readfirstlane(ecnt[parity]);
         const bool slow = nexc_all > S_ECAP;  // block-uniform
         const int nexc = nexc_all < S_ECAP ? nexc_all : S_ECAP;
@@ -294,6 +334,13 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
         auto mma_step = [&](const float4 (&r)[4][2], const s_f32x2 (&w)[2], const u32x4 (&bh)[NT], const u32x4 (&bl)[NT],
                             auto&& mid) {
             uint32_t hi[4], lo[4];
+            if (CP_DCN_EXP & (1 << 25)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    hi[q] = __float_as_uint(r[0][q >> 1].x) ^ __float_as_uint(r[3][q >> 1].y) ^ __float_as_uint(w[0].x);
+                    lo[q] = __float_as_uint(r[1][q >> 1].z) ^ __float_as_uint(r[2][q >> 1].w) ^ __float_as_uint(w[1].y);
+                }
+            } else
 #pragma unroll
             for (int hq = 0; hq < 2; ++hq) {
                 const float4 v1 = r[0][hq], v2 = r[1][hq], v3 = r[2][hq], v4 = r[3][hq];
@@ -314,15 +361,20 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
 #if defined(CP_DCN_EXP) && (CP_DCN_EXP & 64)
             asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // tuning build: slower K steps (tools/probe/dcn16p_race.py)
 #endif
+            if (CP_DCN_EXP & (1 << 24)) {  // keep the operands alive without the matrix pipe
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j][0] += __uint_as_float(ahv.x ^ alv.y ^ bh[j].x ^ bl[j].y);
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, *reinterpret_cast<const h8*>(&bh[j]), acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&bh[j]), al, acc[j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, *reinterpret_cast<const h8*>(&bl[j]), acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&bl[j]), ah, acc[j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, *reinterpret_cast<const h8*>(&bh[j]), acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&bh[j]), ah, acc[j], 0, 0, 0);
         };
         // inside step (ch, t): the weight set step t - 1 consumed takes the step two ahead -- of this chunk, of the next one, or of
         // the next item's first chunk
@@ -384,8 +436,15 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 blend_corners(0);
             }
+            S_STAMP(3);
             __syncthreads();
+            S_STAMP(4);
 
+            // One K step of the software pipeline (all of it one wave's instruction stream, written slot by slot): the six MFMAs of
+            // step t, each followed by an eighth-of-a-step of the NEXT step's blend (8 VALU) and two of the memory instructions that
+            // belong to later steps (the gather of step t + 2, the weight fragments of step t + 2).  A wave on its own SIMD slot
+            // hides ~5 issue slots under a 32-cycle MFMA (MI355X_MICROARCH.md); as blocks "48 VALU, then 6 MFMAs" the two waves of
+            // a SIMD ran their phases in lock-step and nothing overlapped (every ablation saved its full share: profiles/NOTES.md).
             auto chunk = [&](auto par_c, int ch) {
                 constexpr int PAR = decltype(par_c)::value;
                 // ---- request the next chunk: halo into the other buffer, exception corners into the corner buffer ----
@@ -396,36 +455,104 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
                 } else if (has_next) {
                     issue_halo(nxt, 0, PAR ^ 1);
                 }
+                S_STAMP(5 + 4 * ch);
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned char* base = smem + PAR * S_BUFB;
-                auto gather = [&](float4 (&r)[4][2], int a) {
-                    const unsigned char* ap = base + a;
+                float4 raw[2][4][2];
+                if (CP_DCN_EXP & (1 << 23)) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int co = (c >> 1) * S_ROWB + (c & 1) * S_PXB;
-                        r[c][0] = *reinterpret_cast<const float4*>(ap + co);
-                        r[c][1] = *reinterpret_cast<const float4*>(ap + co + 16);
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) raw[i][c][0] = raw[i][c][1] = make_float4(1.f, 2.f, 3.f, 4.f + (float)addr[c]);
+                }
+                // corner c (0 .. 3), both quads of this lane's channel half
+                auto gather_c = [&](float4 (&r)[4][2], int a, int c) {
+                    if (CP_DCN_EXP & (1 << 23)) return;
+                    const unsigned char* ap = base + a + (c >> 1) * S_ROWB + (c & 1) * S_PXB;
+                    r[c][0] = *reinterpret_cast<const float4*>(ap);
+                    r[c][1] = *reinterpret_cast<const float4*>(ap + 16);
+                };
+                uint32_t ahi[2][4], alo[2][4];  // split A operands of steps t (consumed by the MFMAs) and t + 1 (being produced)
+                float o[4];
+                // blend of quad hq in three pieces of 8 VALU: fma(w4, v4, fma(w3, v3, fma(w2, v2, w1 * v1))), then the hi / lo split
+                auto blend_piece = [&](const float4 (&r)[4][2], const s_f32x2 (&w)[2], uint32_t (&hi)[4], uint32_t (&lo)[4], int hq,
+                                       int piece) {
+                    if (CP_DCN_EXP & (1 << 25)) {
+                        if (piece == 2) {
+                            hi[2 * hq] = __float_as_uint(r[0][hq].x) ^ __float_as_uint(w[0].x);
+                            hi[2 * hq + 1] = __float_as_uint(r[3][hq].y);
+                            lo[2 * hq] = __float_as_uint(r[1][hq].z) ^ __float_as_uint(w[1].y);
+                            lo[2 * hq + 1] = __float_as_uint(r[2][hq].w);
+                        }
+                        return;
+                    }
+                    if (piece == 0) {
+                        const float4 v1 = r[0][hq], v2 = r[1][hq];
+                        o[0] = fmaf(w[0].y, v2.x, w[0].x * v1.x);
+                        o[1] = fmaf(w[0].y, v2.y, w[0].x * v1.y);
+                        o[2] = fmaf(w[0].y, v2.z, w[0].x * v1.z);
+                        o[3] = fmaf(w[0].y, v2.w, w[0].x * v1.w);
+                    } else if (piece == 1) {
+                        const float4 v3 = r[2][hq], v4 = r[3][hq];
+                        o[0] = fmaf(w[1].y, v4.x, fmaf(w[1].x, v3.x, o[0]));
+                        o[1] = fmaf(w[1].y, v4.y, fmaf(w[1].x, v3.y, o[1]));
+                        o[2] = fmaf(w[1].y, v4.z, fmaf(w[1].x, v3.z, o[2]));
+                        o[3] = fmaf(w[1].y, v4.w, fmaf(w[1].x, v3.w, o[3]));
+                    } else {
+                        const Split2 t0 = split2(o[0], o[1]), t1 = split2(o[2], o[3]);
+                        hi[2 * hq] = t0.hi; hi[2 * hq + 1] = t1.hi;
+                        lo[2 * hq] = t0.lo; lo[2 * hq + 1] = t1.lo;
                     }
                 };
-                float4 raw[2][4][2];
-                gather(raw[0], addr[0]);
+                auto mma1 = [&](const uint32_t (&hi)[4], const uint32_t (&lo)[4], const u32x4 (&bh)[NT], const u32x4 (&bl)[NT], int k) {
+                    // term order of igemm16.hip per accumulator: lo * hi, hi * lo, hi * hi
+                    const u32x4 ahv = {hi[0], hi[1], hi[2], hi[3]}, alv = {lo[0], lo[1], lo[2], lo[3]};
+                    const h8 ah = *reinterpret_cast<const h8*>(&ahv), al = *reinterpret_cast<const h8*>(&alv);
+                    const int j = k % NT, term = k / NT;
+                    if (CP_DCN_EXP & (1 << 24)) {
+                        acc[j][term] += __uint_as_float(ahv.x ^ alv.y ^ bh[j].x ^ bl[j].y);
+                        return;
+                    }
+                    const h8 a = term == 0 ? al : ah;
+                    const h8 b = *reinterpret_cast<const h8*>(term == 1 ? &bl[j] : &bh[j]);
+                    // weights as the first operand: the accumulators hold the TRANSPOSED tile (rows = output channels, columns =
+                    // this wave's pixels), i.e. 4 consecutive channels of the lane's own pixel per accumulator quad -> 16-byte stores
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc[j], 0, 0, 0);
+                };
+                // ---- pipeline fill: gathers of steps 0 and 1, blend of step 0 ----
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gather_c(raw[0], addr[0], c);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gather_c(raw[1], addr[1], c);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) blend_piece(raw[0], bw[0], ahi[0], alo[0], k / 3, k % 3);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < S_NSTEP; ++t) {
-                    // the order of the three phases is pinned: gather of the next tap, blend + MFMAs of this one, weight refill
-                    if (t + 1 < S_NSTEP) gather(raw[(t + 1) & 1], addr[t + 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma_step(raw[t & 1], bw[t], wbh[t % 3], wbl[t % 3], [&]() { refill(ch, t); });
-                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 3 * NT; ++k) {
+                        mma1(ahi[t & 1], alo[t & 1], wbh[t % 3], wbl[t % 3], k);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // fillers of slot k
+                        if (t + 1 < S_NSTEP) blend_piece(raw[(t + 1) & 1], bw[t + 1], ahi[(t + 1) & 1], alo[(t + 1) & 1], k / 3, k % 3);
+                        if (k == 0) refill(ch, t);   // set (t + 2) % 3: step t - 1's MFMAs retired a whole blend ago
+                        if (t + 2 < S_NSTEP && k >= 2) gather_c(raw[t & 1], addr[t + 2], k - 2);   // raw[t & 1]: consumed by blend(t)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 // ---- chunk boundary: this wave's DMA pieces have landed once at most the 2 x 2 NT weight loads issued after
                 //      them (steps 7 and 8: the next chunk's first two steps) are outstanding; its exceptions' corners are
                 //      blended into the other buffer; one barrier ----
+                S_STAMP(6 + 4 * ch);
                 if (!last || has_next) {
                     if (NT == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 if (!last) blend_corners(PAR ^ 1);
+                S_STAMP(7 + 4 * ch);
                 __syncthreads();
+                S_STAMP(8 + 4 * ch);
             };
             for (int ch = 0; ch < nch; ch += 2) {
                 chunk(std::integral_constant<int, 0>(), ch);
@@ -486,40 +613,53 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
         }
 
         // =============================== patch boundary ===============================
+        S_STAMP(40);
         if (has_next) load_record(nxt);  // arrives under the epilogue's stores
         {
-            // accumulator r of lane half h4 = fragment row (r & 3) + 8 (r >> 2) + 4 h4 = lane quad 2 (r >> 2) + h4 of the A side:
-            // patch row r >> 2, 4 x 4 block h4 ^ [0, 1, 1, 0][r >> 2], column r & 3
-            const int ln = s_opaque(lane), h4 = ln >> 5, lcol = ln & 31;
+            // transposed tile: accumulator 4 g + i of N tile j in lane (pixel = lane % 32, half h4) = output channel
+            // 32 j + 8 g + 4 h4 + i of that lane's own pixel -> one 16-byte store per (j, g), 2 NT x 4 per lane instead of 16 NT
+            // 4-byte ones (the epilogue was store-issue-bound: 4.2 k of an item's 41 k clocks, tools/dcn16s_timeline.py)
+            const int ln = s_opaque(lane), h4 = ln >> 5, q8 = (ln >> 2) & 7;
             const int pix0 = (cur.b * p.H + cur.ty0 + 4 * (wid >> 1)) * p.W + cur.tx0 + 8 * (wid & 1);  // scalar
             float* frag_out = p.out + (size_t)pix0 * p.ldo + p.coff;
             const __amdgpu_buffer_rsrc_t ro = make_rsrc(frag_out, (unsigned)((3 * p.W + 8) * p.ldo) * 4u);
+            const unsigned vpix = (unsigned)(((q8 >> 1) * p.W + 4 * ((0x96 >> q8) & 1) + (ln & 3)) * p.ldo) * 4u;
+            const int nb0 = cur.tn * (32 * NT) + 4 * h4;  // + 32 j + 8 g
+            float4 sc[NT][4], sh[NT][4];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = cur.tn * (32 * NT) + j * 32 + lcol;
-                const float sc = (p.scale ? p.scale[n] : 1.f) * ainv;
-                const float sh = p.shift ? p.shift[n] : 0.f;
-                const bool n_ok = n < p.Cout;
-                const unsigned vo = n_ok ? (unsigned)(4 * h4 * p.ldo + n) * 4u : 0x80000000u;
-                const unsigned vo1 = n_ok ? (unsigned)(4 * (1 - h4) * p.ldo + n) * 4u : 0x80000000u;
-                float v[F::NACC];
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < F::NACC; ++r) v[r] = acc[j][r] * sc + sh;
-                if (act == CP_ACT_RELU) {
-#pragma unroll
-                    for (int r = 0; r < F::NACC; ++r) v[r] = fmaxf(v[r], 0.f);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int nl = 4 * h4 + 32 * j + 8 * g4;  // channel inside the N tile (Cout % 4 == 0: a quad is inside or outside)
+                    sc[j][g4] = *reinterpret_cast<const float4*>(smem + S_SCSH + nl * 4);
+                    sh[j][g4] = *reinterpret_cast<const float4*>(smem + S_SCSH + (32 * NT + nl) * 4);
                 }
 #pragma unroll
-                for (int r = 0; r < F::NACC; ++r) amax = fmaxf(amax, fabsf(v[r]));
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < F::NACC; ++r) {
-                    const int so = ((r >> 2) * p.W + (r & 3)) * p.ldo * 4;
-                    const bool flip = (0x6 >> (r >> 2)) & 1;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ro, (int)(flip ? vo1 : vo), so, 0);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int n0 = nb0 + 32 * j + 8 * g4;
+                    float v[4] = {acc[j][4 * g4] * (sc[j][g4].x * ainv) + sh[j][g4].x, acc[j][4 * g4 + 1] * (sc[j][g4].y * ainv) + sh[j][g4].y,
+                                  acc[j][4 * g4 + 2] * (sc[j][g4].z * ainv) + sh[j][g4].z, acc[j][4 * g4 + 3] * (sc[j][g4].w * ainv) + sh[j][g4].w};
+                    if (act == CP_ACT_RELU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                    }
+                    const bool n_ok = n0 < p.Cout;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) amax = fmaxf(amax, n_ok ? fabsf(v[i]) : 0.f);
+                    const u32x4 pk4 = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                    if (!(CP_DCN_EXP & (1 << 22)) || v[0] == 1.2345e-30f)
+                        __builtin_amdgcn_raw_buffer_store_b128(pk4, ro, (int)(n_ok ? vpix + (unsigned)n0 * 4u : 0x80000000u), 0, 0);
                 }
-            }
         }
+        S_STAMP(41);
+        ++item_no;
         if (!has_next) break;
+        if (nxt.tn != cur.tn) {  // (block-uniform, rare: the grid stride is usually a multiple of the N tile count)
+            __syncthreads();
+            write_scsh(nxt.tn);
+        }
         it = it_next;
         cur = nxt;
     }
@@ -539,7 +679,8 @@ int launch_dcn16s(const ConvParams& p, int blocks, hipStream_t stream) {
 // dcn16p's conditions, plus: no residual / GroupNorm statistics, ReLU or no activation (what DeformConv and the stand-alone
 // operator use), and the 16 x 24 patch's row arithmetic inside 32-bit offsets.
 bool cp_dcn16s_supported(const ConvParams& p) {
-    return cp_dcn16p_supported(p) && !p.res && (p.act == CP_ACT_NONE || p.act == CP_ACT_RELU) && p.Cin % 32 == 0;
+    return cp_dcn16p_supported(p) && !p.res && (p.act == CP_ACT_NONE || p.act == CP_ACT_RELU) && p.Cin % 32 == 0 &&
+           p.Cout % 4 == 0 && p.ldo % 4 == 0 && p.coff % 4 == 0;  // 16-byte stores of 4 consecutive output channels
 }
 
 int cp_dcn16s_items(const ConvParams& p) { return p.B * (p.H / S_TH) * (p.W / S_TW) * (p.CoutPad / 64); }

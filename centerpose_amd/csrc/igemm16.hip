@@ -1012,11 +1012,13 @@ static bool dcn16p_wanted(const ConvParams& p) {
     return (p.dbg & 65536) || cp_dcn16p_blocks(p) >= 64;
 }
 
-// ... and, when every resident workgroup gets several (patch, N tile) items, from the persistent streamed form of the same
-// gather (dcn16s.hip).  cp_set_debug: 1048576 = never, 2097152 = every eligible launch (tests, A/B runs).
+// ... and, when every resident workgroup gets many (patch, N tile) items, from the persistent streamed form of the same
+// gather (dcn16s.hip): measured per layer shape at B = 64 (tools/dcn_ab.py, profiles/r04_dcn_ab.txt) it is ahead from 8 items
+// per workgroup (64 -> 64 @ 128 x 128: -3 %, 128 -> 128 @ 64 x 64: -3 %) and behind below that (2 - 4 items: +3 ... +6 %).
+// cp_set_debug: 1048576 = never, 2097152 = every eligible launch (tests, A/B runs).
 static bool dcn16s_wanted(const ConvParams& p) {
     if ((p.dbg & 1048576) || !dcn16p_wanted(p) || !cp_dcn16s_supported(p)) return false;
-    return (p.dbg & 2097152) || cp_dcn16s_items(p) >= 1024;
+    return (p.dbg & 2097152) || cp_dcn16s_items(p) >= 4096;
 }
 
 static bool halo16_wanted(const ConvParams& p, int bn) {
