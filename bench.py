@@ -60,7 +60,8 @@ GFLOP_PER_IMG = {"dlav1_34": 106.85, "dla_34": 85.11, "dla_34_track": 109.68,
 # feed model(x)[-1] (object_pose.py:135) and are not computed
 DEFAULT_BATCH = {"full": 64, "decode": 32, "track": 16, "track_gru": 16, "hourglass": 8, "track_e2e": 16}
 WORKLOAD_TEXT = {
-    "full": "BASELINE configs[2]: dla_34 512x512 batch=%d/GPU, Objectron-shaped synthetic frames, seeded random-init weights, "
+    "full": "BASELINE configs[2]: dla_34 512x512 batch=%d/GPU, uniform-random uint8 frames through the seeded random-init network "
+            "(about 26 detections/img above 0.3, mostly ill-posed PnP point sets; rendered-heads PnP figure: leg pnp_rendered), "
             "backbone + sigmoid + heat-map decode + post-process/soft-NMS + batched PnP, all on device",
     "decode": "BASELINE configs[1]: dlav1_34 512x512 batch=%d/GPU, synthetic random frames, backbone + sigmoid + heat-map decode",
     "track": "dla_34 512x512 batch=%d/GPU, two-frame CenterPoseTrack inputs, Gaussian-moment decode + all-gather of records",
@@ -358,6 +359,85 @@ def run_leg(workload, device, precision, steps, warmup, barrier, latency, serial
     return out
 
 
+def _event_ms(fn, n, warm=3):
+    """Average HIP-event milliseconds of `fn` on torch's current stream (n calls after `warm`)."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def decode_only_leg(device, precision, batch=32):
+    """BASELINE configs[1] as SURVEY 8(d) defines it: dlav1_34 heads, batch 32, ONLY cp_decode inside the timer, on (i) head
+    tensors drawn directly (hm / hm_hp = rand()**8, ...) and (ii) the post-sigmoid heads the dlav1_34 forward produces from
+    the random frames.  Roofline: HBM, 0.66 MB/img of algorithmic traffic (one read of hm + hm_hp, the gathers, the records)."""
+    from centerpose_amd import hip, synth
+
+    def dec(z):
+        return lambda: hip.decode_raw(z["hm"], z["hps"], z["wh"], z["hm_hp"], None, z["scale"], None, z["reg"], z["hp_offset"],
+                                      None, None, K=100, rep_mode=1)
+
+    def obj(ms):
+        gbps = DECODE_MB_PER_IMG * batch / ms  # MB / ms = GB/s
+        return {"us_per_batch": round(ms * 1e3, 2), "images_per_sec": round(batch / (ms * 1e-3), 1),
+                "roofline": {"bound": "hbm", "kernel": "peaks_kernel + assoc_kernel", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS,
+                             "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 5), "traffic": None,
+                             "algorithmic_mb_per_img": DECODE_MB_PER_IMG,
+                             "floor_us_at_hbm_peak": round(DECODE_MB_PER_IMG * batch / PEAK_HBM_GBPS * 1e3, 2)}}
+
+    drawn = {k: v.to(device).contiguous() for k, v in synth.drawn_heads(batch, seed=317).items()}
+    out = {"workload": "BASELINE configs[1] (SURVEY 8(d)): dlav1_34 heads 128x128, batch=%d, cp_decode only inside the timer" % batch,
+           "drawn_heads": obj(_event_ms(dec(drawn), 50))}
+    del drawn
+    model = hip.HipModel("dlav1_34", synth.HEADS_POSE, synth.make_state_dict("dlav1_34", synth.HEADS_POSE, False), precision=precision)
+    x = torch.cat([synth.frames(8, seed=317 + i).to(device) for i in range(0, batch, 8)])
+    z = {k: v.contiguous() for k, v in model(x, sigmoid_hm=True).items()}
+    out["network_heads"] = obj(_event_ms(dec(z), 50))
+    out["value"], out["unit"] = out["network_heads"]["images_per_sec"], "images/sec (decode only)"
+    out["ms_per_step"] = round(out["network_heads"]["us_per_batch"] / 1e3, 5)
+    del model, x, z
+    torch.cuda.empty_cache()
+    return out
+
+
+def pnp_rendered_leg(device, batch=64):
+    """The pose stage on Objectron-shaped heads (1-10 known cuboids per image rendered the way the reference
+    builds its ground truth): decode -> post-process + soft-NMS -> PnP-input assembly -> batched solve, the figure to put beside
+    the headline's random-weight detections (about 26 per image, mostly ill-posed point sets whose Levenberg-Marquardt walk
+    runs its full 20 iterations)."""
+    import numpy as np
+
+    from centerpose_amd import hip, synth
+    from centerpose_amd.lib.utils.image import get_affine_transform
+
+    heads, counts = synth.rendered_heads(batch, seed=317)
+    z = {k: v.to(device).contiguous() for k, v in heads.items()}
+    cam = torch.tensor([663.0287679036459, 663.0287679036459, 300.2775065104167, 395.00066121419275], dtype=torch.float64,
+                       device=device).repeat(batch, 1).contiguous()
+    m = np.zeros((batch, 8))
+    m[:, :6] = get_affine_transform(np.array([256.0, 256.0], np.float32), 512.0, 0, (128, 128), inv=1).reshape(-1)
+    m[:, 6] = 512.0 / 128
+    meta = torch.from_numpy(m).to(device)
+    det = hip.decode_raw(z["hm"], z["hps"], z["wh"], z["hm_hp"], None, z["scale"], None, z["reg"], z["hp_offset"], None, None,
+                         K=100, rep_mode=1)
+    state = {}
+
+    def stage():
+        post, cnt = hip.postprocess(det, meta, 0.3, nms=True)
+        state["cnt"], state["poses"] = cnt, hip.pnp_from_post(post, cnt, cam, rep_mode=1)
+
+    ms = _event_ms(stage, 20)
+    n = int(state["cnt"].sum().item())
+    return {"workload": "Objectron-shaped rendered heads (1-10 cuboids per image), batch=%d: post-process + soft-NMS + PnP" % batch,
+            "objects_rendered": int(sum(counts)), "detections_solved": n, "ms_per_batch": round(ms, 3),
+            "value": round(n / (ms * 1e-3), 1), "unit": "detections/sec (post-process + PnP)", "ms_per_step": round(ms, 3)}
+
+
 def track_e2e_leg(device, precision, n_videos, frames, warmup):
     """B concurrent videos through CenterPoseTrack's whole per-frame loop (lib/detectors/batch_tracking.py): what the
     host-side tracker costs next to the batched device stages."""
@@ -539,6 +619,71 @@ def cpu_baseline(workload, arch, budget_s=45.0, n_timed=10, n_warm=3):
     return out
 
 
+def compact_line(d):
+    """The ONE JSON line: every leg and every north-star figure, without the per-kernel tables and the long notes (those go to
+    the detail file written beside it) -- the driver keeps an 8 KB tail of stdout, and the round-3 line (> 8 KB) lost four legs."""
+    def roof(r, full):
+        if not r:
+            return None
+        keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")
+        if full:
+            keep += ("avg_launch_us", "launches_per_step", "flops_per_launch", "algorithmic_bytes_per_launch", "share_of_conv_time",
+                     "conv_ms_per_step", "timed_steps_sampled")
+        o = {k: r[k] for k in keep if k in r}
+        sub = {"dcn": ("ms_per_step", "main_ms", "offset_conv_ms", "hbm_gbps", "frac_hbm", "tflops"),
+               "conv1x1": ("tflops", "mfma_utilisation", "algorithmic_gbps"), "decode": ("us_per_step", "hbm_gbps"),
+               "pnp": ("ms_per_batch_on_side_stream", "detections_last_batch")}
+        for name, ks in sub.items():
+            if name in r and (full or name == "dcn"):
+                o[name] = {k: r[name][k] for k in (ks if full else ("ms_per_step", "frac_hbm")) if k in r[name]}
+        return o
+
+    def leg(v):
+        if v is None or "error" in v:
+            return v
+        o = {k: v[k] for k in ("value", "unit", "ms_per_step", "steps", "p50_frame_ms_batch1", "host_fraction") if k in v}
+        if v.get("roofline"):
+            o["roofline"] = roof(v["roofline"], False)
+        for k in ("drawn_heads", "network_heads"):  # decode_only
+            if k in v:
+                o[k] = {"us_per_batch": v[k]["us_per_batch"], "roofline": roof(v[k]["roofline"], False)}
+        for k in ("detections_solved", "objects_rendered"):  # pnp_rendered
+            if k in v:
+                o[k] = v[k]
+        if "host_tracker" in v:  # track_e2e
+            o["host_tracker_frames_per_sec"] = v["host_tracker"]["frames_per_sec"]
+        return o
+
+    out = {k: v for k, v in d.items() if k not in ("roofline", "legs", "cpu_baseline")}
+    out["roofline"] = roof(d.get("roofline"), True)
+    out["legs"] = {k: leg(v) for k, v in d["legs"].items()} if d.get("legs") else None
+    c = d.get("cpu_baseline")
+    if c and "value" in c:
+        out["cpu_baseline"] = {k: c[k] for k in ("value", "unit", "cores", "kind") if k in c}
+        out["cpu_baseline"]["sample"] = c["sample"][:160]
+        if "fair" in c:
+            out["cpu_baseline"]["fair_value"] = c["fair"]["value"]
+        if "pnp_detections_per_image" in c:
+            out["cpu_baseline"]["pnp_detections_per_image"] = c["pnp_detections_per_image"]
+    else:
+        out["cpu_baseline"] = c
+    return out
+
+
+def write_detail(d):
+    """The full record of the run (per-kernel tables, notes, every leg's roofline object) beside the compact line."""
+    path = os.environ.get("CP_BENCH_DETAIL")
+    if not path:
+        scratch = os.path.join(REPO, "gpurun_out")
+        path = os.path.join(scratch if os.path.isdir(scratch) else os.path.join(REPO, "profiles"), "bench_detail_last.json")
+    try:
+        with open(path, "w") as f:
+            json.dump(d, f, indent=1)
+        return os.path.relpath(path, REPO)
+    except OSError:
+        return None
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -642,6 +787,12 @@ def main():
             w = max(1, min(args.warmup, 2))
             legs["configs1"] = run_leg("decode", device, args.precision, max(4, min(args.steps, 12)), w, barrier,
                                        not args.no_latency)
+            for name, fn in (("decode_only", lambda: decode_only_leg(device, args.precision)),
+                             ("pnp_rendered", lambda: pnp_rendered_leg(device))):
+                try:
+                    legs[name] = fn()
+                except Exception as e:
+                    legs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             legs["exact_f32"] = run_leg("full", device, "f32", 4, 1, barrier, False)
             for name in ("hourglass", "track", "track_gru"):
                 legs[name] = run_leg(name, device, args.precision, k, w, barrier, False)
@@ -652,6 +803,8 @@ def main():
         cpu = None
         if not dry and world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.workload, pipe.arch)
+        elif world > 1:
+            cpu = {"skipped": "N > 1: the reference's CPU path is timed on rank 0 of the N = 1 run only"}
         key = pipe.arch + ("_track" if pipe.track else "")
         gf = GFLOP_PER_IMG[key]
         tail = {"full": " + post-process + PnP", "decode": "", "hourglass": ""}.get(args.workload, " + detection all-gather")
@@ -678,7 +831,9 @@ def main():
             "whole_step_tflops": round(value * gf / 1e3 / world, 2),
             "roofline": roof, "legs": legs, "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        line = compact_line(out)
+        line["detail"] = write_detail(out)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         barrier()  # rank 0 may still be measuring the batch-1 latency; leave together
         dist.destroy_process_group()

@@ -276,3 +276,80 @@ def frames(batch, seed=DEFAULT_SEED, h=512, w=512, device="cpu"):
     u8 = torch.randint(0, 256, (batch, h, w, 3), generator=g, dtype=torch.uint8)
     x = (u8.float() / 255.0 - torch.tensor(MEAN)) / torch.tensor(STD)
     return x.permute(0, 3, 1, 2).contiguous().to(device)
+
+
+def drawn_heads(batch, seed=DEFAULT_SEED, hw=128):
+    """Head tensors drawn directly ("Decode-only (config 2)"): hm / hm_hp = rand()**8 (sparse peaks, top-100 is
+    tie-free), hps ~ N(0, 5^2), wh ~ U(5, 35), reg / hp_offset ~ U(0, 1), scale ~ U(0.5, 1.5).  Post-sigmoid, float32 NCHW."""
+    g = _gen(seed, "drawn_heads")
+    r = lambda c: torch.rand(batch, c, hw, hw, generator=g)
+    return {"hm": r(1) ** 8, "hm_hp": r(8) ** 8, "hps": torch.randn(batch, 16, hw, hw, generator=g) * 5.0,
+            "wh": r(2) * 30.0 + 5.0, "reg": r(2), "hp_offset": r(2), "scale": r(3) + 0.5}
+
+
+def rendered_heads(batch, seed=DEFAULT_SEED, n_obj=(1, 10), img=512, hw=128, sigma=1.5, noise=0.02):
+    """"Objectron-shaped" head tensors: per image 1-10 cuboids (dataset_combined.py:128 max_objs) of random
+    pose and size projected through the demo camera (demo.py:143-144) and the 512 -> 128 affine, written the way the
+    reference builds its ground truth (dataset_combined.py:1033-1127): hm = Gaussian at the integer 2-D box centre, wh / reg /
+    hps / scale at that pixel, hm_hp[j] = Gaussian at vertex j, hp_offset = sub-pixel rest, + |N(0, noise^2)| background.
+    Returns (heads: float32 NCHW tensors with hm / hm_hp post-sigmoid, objects per image)."""
+    import numpy as np
+
+    from .lib.utils.pnp.cuboid_objectron import Cuboid3d
+
+    rng = np.random.RandomState(int(seed) % (2 ** 31))
+    K = np.array([[663.0287679036459, 0, 300.2775065104167], [0, 663.0287679036459, 395.00066121419275], [0, 0, 1]])
+    f32 = np.float32
+    h = {"hm": np.zeros((batch, 1, hw, hw), f32), "hm_hp": np.zeros((batch, 8, hw, hw), f32),
+         "hps": np.zeros((batch, 16, hw, hw), f32), "wh": np.zeros((batch, 2, hw, hw), f32), "reg": np.zeros((batch, 2, hw, hw), f32),
+         "hp_offset": np.zeros((batch, 2, hw, hw), f32), "scale": np.ones((batch, 3, hw, hw), f32)}
+    ys, xs = np.mgrid[0:hw, 0:hw]
+    ratio = hw / float(img)
+    counts = []
+    for b in range(batch):
+        want = int(rng.randint(n_obj[0], n_obj[1] + 1))
+        used, placed, tries = set(), 0, 0
+        while placed < want and tries < 400:
+            tries += 1
+            size = np.array([rng.uniform(0.5, 1.5), 1.0, rng.uniform(0.5, 1.5)]) * rng.uniform(0.12, 0.28)
+            q = rng.randn(4)
+            q /= np.linalg.norm(q)
+            x, y, z, w = q
+            R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                          [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                          [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+            t = np.array([rng.uniform(-0.9, 0.9), rng.uniform(-1.2, 0.4), rng.uniform(2.0, 4.0)])
+            V = np.asarray(Cuboid3d(size).get_vertices(), np.float64)
+            cam = V @ R.T + t
+            if cam[:, 2].min() < 0.3:
+                continue
+            uv = (cam / cam[:, 2:3]) @ K.T
+            uv = uv[:, :2]
+            if uv.min() < 8 or uv.max() > img - 8:
+                continue
+            kp = uv * ratio
+            x0, y0, x1, y1 = kp[:, 0].min(), kp[:, 1].min(), kp[:, 0].max(), kp[:, 1].max()
+            ct = np.array([(x0 + x1) / 2, (y0 + y1) / 2])
+            ci = np.floor(ct).astype(int)
+            pix = [tuple(np.floor(k).astype(int)) for k in kp]
+            keys = [("c",) + tuple(ci)] + [("k",) + pq for pq in pix]
+            # objects apart: centres / vertices never collide (hp_offset is one map shared by all joints)
+            if len(set(pix)) < 8 or any((k[0], k[1] + dx, k[2] + dy) in used for k in keys for dx in range(-5, 6) for dy in range(-5, 6)):
+                continue
+            used.update(keys)
+            g = np.exp(-((xs - ci[0]) ** 2 + (ys - ci[1]) ** 2) / (2 * sigma ** 2)).astype(f32)
+            h["hm"][b, 0] = np.maximum(h["hm"][b, 0], g * f32(0.95))
+            h["wh"][b, :, ci[1], ci[0]] = [x1 - x0, y1 - y0]
+            h["reg"][b, :, ci[1], ci[0]] = ct - ci
+            h["scale"][b, :, ci[1], ci[0]] = size / size[1]
+            for j in range(8):
+                h["hps"][b, 2 * j:2 * j + 2, ci[1], ci[0]] = kp[j] - ci
+                pj = np.array(pix[j])
+                gj = np.exp(-((xs - pj[0]) ** 2 + (ys - pj[1]) ** 2) / (2 * sigma ** 2)).astype(f32)
+                h["hm_hp"][b, j] = np.maximum(h["hm_hp"][b, j], gj * f32(0.9))
+                h["hp_offset"][b, :, pj[1], pj[0]] = kp[j] - pj
+            placed += 1
+        counts.append(placed)
+    h["hm"] = np.maximum(h["hm"], np.abs(rng.randn(batch, 1, hw, hw) * noise).astype(f32).clip(0, 0.2))
+    h["hm_hp"] = np.maximum(h["hm_hp"], np.abs(rng.randn(batch, 8, hw, hw) * noise).astype(f32).clip(0, 0.2))
+    return {k: torch.from_numpy(v) for k, v in h.items()}, counts

@@ -37,3 +37,36 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
 def test_bench_single_rank_dry_run_has_no_group():
     d = _run(["--dry-run", "--steps", "2", "--warmup", "0"])
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["config"]["global_batch"] == 64
+
+
+def test_bench_eight_ranks_dress_rehearsal():
+    """BASELINE configs[3] plumbing without hardware: 8 ranks over gloo, 64 images each, one checked all-gather; the line
+    carries a cpu_baseline stub for N > 1 so that a SCALE parser never finds the key missing."""
+    d = _run(["--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1"])
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["config"]["global_batch"] == 512
+    assert "x8" in d["config"]["parallelism"] and d["scaling"] == "weak"
+    assert isinstance(d["cpu_baseline"], dict) and "skipped" in d["cpu_baseline"]
+    assert "roofline" in d and "legs" in d
+
+
+def test_compact_line_keeps_every_leg_inside_the_drivers_tail():
+    """The driver stores an 8 KB tail of stdout: the round-3 line was longer and lost four legs.  The compact form of that very
+    record (profiles/r03_bench_default.json, a full round-3 line) must fit with every leg's value and roofline fraction."""
+    sys.path.insert(0, REPO)
+    import bench
+
+    with open(os.path.join(REPO, "profiles", "r03_bench_default.json")) as f:
+        full = json.loads(f.read().strip().splitlines()[-1])
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < 6000, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config"):
+        assert k in line
+    assert line["roofline"]["kernel"] and line["roofline"]["frac"] > 0 and "dcn" in line["roofline"]
+    assert set(full["legs"]) == set(line["legs"])
+    for name, leg in line["legs"].items():
+        assert leg["value"] > 0 and leg["ms_per_step"] > 0, name
+        if full["legs"][name].get("roofline"):
+            assert leg["roofline"]["frac"] > 0, name
+    assert line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and line["cpu_baseline"]["cores"] == full["cpu_baseline"]["cores"]
