@@ -1944,6 +1944,18 @@ int cp_track_step(cp_stream_t stream, const cp_track_params* params, const doubl
     return rc == CP_OK ? CP_OK : fail(rc, "cp_track_step: launch failed");
 }
 
+// Sticky per-video overflow counters of the device tracker (list entries dropped because a frame needed more than `cap`
+// tracks): dropped_out [B] HOST int32.  Synchronises `stream` (one small copy); call it every few frames, not every frame.
+int cp_track_status(cp_stream_t stream, const void* state, int B, int* dropped_out) {
+    if (!state || !dropped_out || B < 1) return fail(CP_ERR_INVALID, "cp_track_status: bad argument");
+    std::vector<int> hdr(4 + 4 * (size_t)B);
+    if (hipMemcpyAsync(hdr.data(), state, hdr.size() * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+        return fail(CP_ERR_LAUNCH, "cp_track_status: copy failed");
+    for (int b = 0; b < B; ++b) dropped_out[b] = hdr[4 + 4 * b + 2];
+    return CP_OK;
+}
+
 size_t cp_decode_workspace_bytes(int B, int K) { return cp_decode_ws_bytes(B, 8, K); }
 
 int cp_decode(cp_stream_t stream, int B, int H, int W, float* hm, const float* hps, const float* wh,

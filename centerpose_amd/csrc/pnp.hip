@@ -24,6 +24,9 @@
 // inside the group.  Per iteration that is ~1500 instead of ~5300 dependent instructions, and a wavefront now holds 4
 // detections instead of 64, so one slow walk (20 iterations on a poorly conditioned point set) no longer holds 63
 // finished ones.  Results are deterministic; they differ from the one-lane order only in the summation order over points.
+#include <cmath>  // (the host-testable headers below are included inside the namespace: their std includes come first)
+#include <cfloat>
+
 #include "cp_common.h"
 
 namespace {

@@ -12,6 +12,9 @@
 //      with its swap-with-last removal is inherently sequential and order dependent, so one lane walks it over
 //      (score, bbox, record index) arrays in LDS, in float64 like the Python floats of the reference;
 //   4. the surviving records are written in their final order: out[b][0 .. count[b]).
+#include <cmath>  // (the host-testable headers below are included inside the namespace: their std includes come first)
+#include <cfloat>
+
 #include "cp_common.h"
 #include "../../include/centerpose_hip.h"
 

@@ -22,17 +22,20 @@
 #define CP_DET_STRIDE 118
 #define CP_POST_STRIDE 120
 
+// No fused multiply-adds in either build: the arithmetic below restates numpy / Python expressions whose every operation
+// rounds (hipcc's default, -ffp-contract=fast, would otherwise fuse e.g. the soft-NMS union area on the device, and the CPU
+// test of this same source would not pin the device's bits).  Restored at the end of the header.
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#elif defined(__GNUC__)
+#pragma GCC optimize("fp-contract=off")
+#endif
 #ifdef __HIPCC__
 #define POST_HD __host__ __device__ __forceinline__
 #define POST_FMUL(a, b) __fmul_rn((a), (b))
 #define POST_DADD(a, b) __dadd_rn((a), (b))
 #define POST_DMUL(a, b) __dmul_rn((a), (b))
 #else
-#if defined(__clang__)
-#pragma clang fp contract(off)
-#elif defined(__GNUC__)
-#pragma GCC optimize("fp-contract=off")
-#endif
 #define POST_HD static inline
 #define POST_FMUL(a, b) ((float)(a) * (float)(b))
 #define POST_DADD(a, b) ((double)(a) + (double)(b))
@@ -139,3 +142,7 @@ POST_HD int post_filter_nms(double* s_score, double (*s_box)[4], int* s_idx, int
     }
     return N;
 }
+
+#if defined(__clang__) && defined(__HIPCC__)
+#pragma clang fp contract(fast)  // hipcc's default again for whatever the including file defines after this header
+#endif

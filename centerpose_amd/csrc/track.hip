@@ -73,11 +73,11 @@ __global__ __launch_bounds__(64) void track_associate_kernel(const TrackParams P
         for (int k = 0; k < nd; ++k) any |= u[k];
         if (!any)
             for (int k = 0; k < nd; ++k) u[k] = 1;  // no box at all: every detection takes part (tracker.py:116-117)
-        int idc = h[1];
-        const int n = trk_associate(P, d, u, nd, prev, h[0], plan, &idc, det_idx, taken);
+        int idc = h[1], dropped = 0;
+        const int n = trk_associate(P, d, u, nd, prev, h[0], plan, &idc, det_idx, taken, &dropped);
         h[1] = idc;
-        if (n < 0) h[2] = 1;  // more than `cap` tracks: reported by cp_track_step's caller through the header
-        s_n = n < 0 ? 0 : n;
+        h[2] += dropped;  // sticky count of list entries dropped because a frame needed more than `cap` (cp_track_status)
+        s_n = n;
     }
     __syncthreads();
     const int n = s_n;

@@ -96,25 +96,30 @@ struct TrackParams {
 #define CP_VMETA_STRIDE 16
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Gaussian fusion (base_detector.py:503-536), hps_uncertainty branch and the fixed-variance branch
+// Gaussian fusion (base_detector.py:503-536), hps_uncertainty branch and the fixed-variance branch.  The reference's standard
+// deviations are float32 numpy scalars and its means float64 ones, so `std ** -2`, their sum and `** -0.5` are float32
+// operations (numpy keeps float32 ** python-int / python-float in float32) and only the products with the means promote to
+// float64; `hs / np.sqrt(2)` is float64 (np.sqrt(2) is a float64 scalar).  Restated with the same widths: the fused values
+// then agree with the reference to the last float32 digit of powf instead of ~1e-7.
 CP_HD void trk_fuse(const double* post, int hps_uncertainty, double* mean, double* std) {
     for (int i = 0; i < 16; ++i) {
-        const double dm = post[PO_DISP_MEAN + i], ds = post[PO_DISP_STD + i];
-        const double hm = post[PO_HM_MEAN + i], hs = post[PO_HM_STD + i];
+        const double dm = post[PO_DISP_MEAN + i], hm = post[PO_HM_MEAN + i];
+        const float ds = (float)post[PO_DISP_STD + i], hs = (float)post[PO_HM_STD + i];
         const bool missing = hm < 0 || hs < 0;
         double s, m;
         if (hps_uncertainty) {
-            if (missing) { s = ds; m = dm; }
+            if (missing) { s = post[PO_DISP_STD + i]; m = dm; }  // (passed through as stored)
             else {
-                const double a = 1.0 / (ds * ds), b = 1.0 / (hs * hs);
-                s = 1.0 / sqrt(a + b);
-                m = s * s * (a * dm + b * hm);
+                const float a = powf(ds, -2.0f), b = powf(hs, -2.0f);
+                const float sf = powf(a + b, -0.5f);
+                s = (double)sf;
+                m = (double)(sf * sf) * ((double)a * dm + (double)b * hm);
             }
         } else if (missing) { s = 20.0; m = dm; }
         else {
-            const double b = 1.0 / (hs * hs);
-            s = hs / sqrt(2.0);
-            m = s * s * (b * dm + b * hm);
+            const float b = powf(hs, -2.0f);
+            s = (double)hs / sqrt(2.0);
+            m = s * s * ((double)b * dm + (double)b * hm);
         }
         mean[i] = m;
         std[i] = s;
@@ -473,9 +478,14 @@ CP_HD void trk_render_records(const TrackParams& P, const double* vm, const doub
 //                          kind 0 matched detection (inherits id / filter of the prev track), 1 new track (id in slot 2),
 //                          2 coasting prev track.  Order as the reference builds its list: matched (detection order),
 //                          new (detection order), coasting (track order).
-// Returns the length of the new list, or -1 when it would exceed P.cap.
+// Returns the length of the new list (<= P.cap).  A frame that would need more than P.cap entries keeps the first P.cap in the
+// reference's own order -- every matched track (there are at most P.cap of them), then new tracks in detection (= score)
+// order, then coasting tracks -- and reports the number of entries it dropped in *dropped: the state stays well defined (no id
+// is given to a dropped detection; a dropped coasting track is simply retired early) and the caller can surface the event.
 CP_HD int trk_associate(const TrackParams& P, const double* dets, const int* use, int nd_all, const double* prev, int np,
-                        int* plan, int* id_count, int* det_idx /* scratch [K] */, unsigned char* taken /* scratch [cap] */) {
+                        int* plan, int* id_count, int* det_idx /* scratch [K] */, unsigned char* taken /* scratch [cap] */,
+                        int* dropped) {
+    *dropped = 0;
     int nd = 0;
     for (int k = 0; k < nd_all; ++k)
         if (use[k]) det_idx[nd++] = k;
@@ -510,7 +520,7 @@ CP_HD int trk_associate(const TrackParams& P, const double* dets, const int* use
     for (int i = 0; i < nd; ++i) {  // matched, in detection order
         const int k = det_idx[i] & 0xffff, match = (det_idx[i] >> 16) - 1;
         if (match < 0) continue;
-        if (n_out >= P.cap) return -1;
+        if (n_out >= P.cap) { *dropped += 1; continue; }  // (cannot happen: matches <= np <= cap)
         plan[3 * n_out] = 0; plan[3 * n_out + 1] = k; plan[3 * n_out + 2] = match;
         ++n_out;
     }
@@ -518,7 +528,7 @@ CP_HD int trk_associate(const TrackParams& P, const double* dets, const int* use
         const int k = det_idx[i] & 0xffff, match = (det_idx[i] >> 16) - 1;
         if (match >= 0) continue;
         if (!(dets[(long long)k * CP_TRACK_STRIDE + TR_POST + PO_SCORE] > P.new_thresh)) continue;
-        if (n_out >= P.cap) return -1;
+        if (n_out >= P.cap) { *dropped += 1; continue; }
         *id_count += 1;
         plan[3 * n_out] = 1; plan[3 * n_out + 1] = k; plan[3 * n_out + 2] = *id_count;
         ++n_out;
@@ -526,7 +536,7 @@ CP_HD int trk_associate(const TrackParams& P, const double* dets, const int* use
     for (int t = 0; t < np; ++t) {  // unmatched tracks coast until max_age
         if (taken[t]) continue;
         if (!(prev[(long long)t * CP_TRACK_STRIDE + TR_AGE] < P.max_age)) continue;
-        if (n_out >= P.cap) return -1;
+        if (n_out >= P.cap) { *dropped += 1; continue; }
         plan[3 * n_out] = 2; plan[3 * n_out + 1] = -1; plan[3 * n_out + 2] = t;
         ++n_out;
     }
@@ -643,3 +653,7 @@ CP_HD void trk_finish_stage(const TrackParams& P, const double* vm, double* t, c
     t[TR_FLAGS] = flags;
     if (rec) trk_render_records(P, vm, t, hm_plane, hp_plane0, rec);
 }
+
+#if defined(__clang__) && defined(__HIPCC__)
+#pragma clang fp contract(fast)  // hipcc's default again: the switch above must not leak into the rest of engine.hip / track.hip
+#endif

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CENTERPOSE_HIP_LIB") or os.path.join(_HERE, "libcenterpose_hip.so")
 
 _lib = None
-ABI_VERSION = 4  # CP_ABI_VERSION of include/centerpose_hip.h this binding was written against
+ABI_VERSION = 5  # CP_ABI_VERSION of include/centerpose_hip.h this binding was written against
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -46,9 +46,16 @@ def lib():
             "centerpose_amd: %s not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C centerpose_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
     L = ctypes.CDLL(LIB_PATH)
+    # the ABI guard comes before any other symbol is bound: a stale library is exactly the case it exists for, and it must
+    # fail with "rebuild", not with ctypes' "undefined symbol"
+    if not hasattr(L, "cp_abi_version"):
+        raise RuntimeError("centerpose_amd: %s predates the ABI guard (no cp_abi_version): rebuild the library" % LIB_PATH)
+    _sig(L.cp_abi_version, c_int)
+    if L.cp_abi_version() != ABI_VERSION:
+        raise RuntimeError("centerpose_amd: %s has ABI version %d, this binding was written for %d (rebuild the library)"
+                           % (LIB_PATH, L.cp_abi_version(), ABI_VERSION))
     _sig(L.cp_version, c_char_p)
     _sig(L.cp_last_error, c_char_p)
-    _sig(L.cp_abi_version, c_int)
     _sig(L.cp_num_kernel_variants, c_int)
     _sig(L.cp_num_roles, c_int)
     _sig(L.cp_dcnv2_workspace_bytes, c_size_t, c_int, c_int, c_int, c_int, c_int)
@@ -95,6 +102,7 @@ def lib():
     _sig(L.cp_track_state_bytes, c_size_t, c_int, c_int)
     _sig(L.cp_track_workspace_bytes, c_size_t, c_int, c_int, c_int)
     _sig(L.cp_track_reset, c_int, c_void_p, c_void_p, c_int, c_int)
+    _sig(L.cp_track_status, c_int, c_void_p, c_void_p, c_int, ctypes.POINTER(c_int))
     _sig(L.cp_track_step, c_int, c_void_p, ctypes.POINTER(TrackParams), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
          c_void_p, c_void_p, c_size_t)
     if L.cp_abi_version() != ABI_VERSION:
@@ -113,7 +121,7 @@ def exported_symbols():
             "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug", "cp_preprocess", "cp_postprocess_workspace_bytes", "cp_postprocess", "cp_render_gaussians",
             "cp_model_profile_roles", "cp_role_name", "cp_pnp_from_post_workspace_bytes", "cp_pnp_from_post", "cp_resize_u8",
             "cp_abi_version", "cp_num_kernel_variants", "cp_num_roles", "cp_track_state_bytes", "cp_track_workspace_bytes",
-            "cp_track_reset", "cp_track_step"]
+            "cp_track_reset", "cp_track_step", "cp_track_status"]
 
 
 def _check(rc, what):
@@ -463,8 +471,11 @@ class DeviceTracker(object):
     ``postprocess`` / ``pnp_from_post`` of a frame of B videos, ``render`` draws the next frame's pre_hm / pre_hm_hp from
     the tracks, ``read`` copies the current lists to the host.  Nothing synchronises except ``read``."""
 
+    STATUS_EVERY = 64  # frames between two looks at the overflow counters in step() (each look synchronises the stream)
+
     def __init__(self, B, params, vmeta, device, inp_h, inp_w):
         L = lib()
+        self.frames = 0
         self.B, self.P, self.device = int(B), params, device
         self.K, self.cap = int(params.K), int(params.cap)
         self.inp_h, self.inp_w = int(inp_h), int(inp_w)
@@ -493,6 +504,22 @@ class DeviceTracker(object):
             raise RuntimeError("DeviceTracker.step: det_pnp must be the [B,K,40] float64 output of pnp_from_post")
         _check(lib().cp_track_step(_stream(), ctypes.byref(self.P), _ptr(self.vmeta), _ptr(post), _ptr(count), _ptr(det_pnp),
                                    self.B, _ptr(self.state), _ptr(self.recs), _ptr(self.ws), self.ws.numel()), "cp_track_step")
+        self.frames += 1
+        if self.frames % self.STATUS_EVERY == 0:  # the device-resident loop never calls read(): surface overflows here
+            self.check()
+
+    def dropped(self):
+        """Per video: list entries dropped so far because a frame needed more than `cap` tracks (cp_track_status; the
+        tracker then keeps the first `cap` entries in the reference's order -- matched, new by score, coasting)."""
+        out = (ctypes.c_int * self.B)()
+        _check(lib().cp_track_status(_stream(), _ptr(self.state), self.B, out), "cp_track_status")
+        return list(out)
+
+    def check(self):
+        d = self.dropped()
+        if any(d):
+            raise RuntimeError("DeviceTracker: more than cap = %d tracks in a frame of video(s) %s (entries dropped: %s); "
+                               "raise cap or the thresholds" % (self.cap, [b for b, v in enumerate(d) if v], [v for v in d if v]))
 
     def render(self):
         """-> (pre_hm [B,1,H,W], pre_hm_hp [B,8,H,W]) drawn from the current tracks (views of one plane buffer)."""
@@ -512,7 +539,7 @@ class DeviceTracker(object):
         for b in range(self.B):
             n, overflow = int(hdr[4 + 4 * b]), int(hdr[4 + 4 * b + 2])
             if overflow:
-                raise RuntimeError("DeviceTracker: video %d needed more than %d tracks" % (b, self.cap))
+                raise RuntimeError("DeviceTracker: video %d needed more than %d tracks (%d list entries dropped)" % (b, self.cap, overflow))
             out.append(tr[int(hdr[0]), b, :n].copy())
         return out
 

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from ..utils.pnp.cuboid_pnp_shell import finish_detection
-from ..utils.tracker import Tracker, Tracker_baseline
+from .base_detector import _build_tracker
 
 
 class BatchedTracking(object):
@@ -35,8 +35,9 @@ class BatchedTracking(object):
             raise RuntimeError("BatchedTracking runs on the HIP device only")
         self.det = detector
         self.n = int(n_videos)
-        cls = Tracker if opt.tracking_task else Tracker_baseline
-        self.trackers = [cls(opt) for _ in range(self.n)]
+        # the same choice as run() makes (base_detector.py:53-57: refined_Kalman wins when both flags are set)
+        self.trackers = [_build_tracker(opt) for _ in range(self.n)]
+        self._vmeta = None
         self.pre_images = None
         self.frames = 0
         self.times = {'host_records': 0.0, 'device': 0.0, 'host_tracks': 0.0, 'steps': 0}
@@ -45,7 +46,7 @@ class BatchedTracking(object):
         for t in self.trackers:
             t.reset()
         if self.dev is not None:
-            self.dev.reset()
+            self.dev = None   # rebuilt (with the next frame's meta) by the next step
         self.pre_images = None
         self.frames = 0
 
@@ -64,8 +65,15 @@ class BatchedTracking(object):
         if self.dev is None:
             if any('pre_dets' in m for m in metas):
                 raise RuntimeError("device tracker: seeding from meta['pre_dets'] is a host-tracker feature")
-            self.dev = _hip.DeviceTracker(B, _hip.track_params_from_opt(opt, K=opt.K), _hip.track_vmeta(metas), opt.device,
+            self._vmeta = np.asarray(_hip.track_vmeta(metas), np.float64)
+            self.dev = _hip.DeviceTracker(B, _hip.track_params_from_opt(opt, K=opt.K), self._vmeta, opt.device,
                                           metas[0]['inp_height'], metas[0]['inp_width'])
+        else:
+            # the device keeps the per-video meta (trans_input, frame size, intrinsics) of the first frame: a video whose meta
+            # changes from frame to frame is not what it tracks
+            if not np.array_equal(np.asarray(_hip.track_vmeta(metas), np.float64), self._vmeta):
+                raise RuntimeError("device tracker: per-video meta (trans_input / size / camera) changed since the first frame; "
+                                   "reset() the tracker or use the host tracker")
         if self.pre_images is None:
             self.pre_images = images
         pre_hm = pre_hm_hp = None
@@ -75,7 +83,7 @@ class BatchedTracking(object):
             pre_hm_hp = hp if opt.pre_hm_hp else None
         det._skip_host_dets = True
         try:
-            det.process(images, self.pre_images, pre_hm, pre_hm_hp, None)
+            det.process(images, self.pre_images if opt.tracking_task else None, pre_hm, pre_hm_hp, None)
         finally:
             det._skip_host_dets = False
         rec, cnt, poses = det.post_pnp_device(metas)

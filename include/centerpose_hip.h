@@ -37,8 +37,8 @@ typedef struct cp_model cp_model;
  * with, so a caller compiled against another revision can refuse to run instead of passing arguments with a stale
  * meaning.  History: 1 = round-1 header; 2 = cp_preprocess takes the FORWARD 2x3 affine as double[6] and inverts it
  * itself (round 1: the inverse as float[6]); 3 = cp_dcnv2_forward accepts every shape of the reference op (generic
- * kernel), cp_num_kernel_variants() / cp_num_roles() size the profile buffers; 4 = cp_track_* added. */
-#define CP_ABI_VERSION 4
+ * kernel), cp_num_kernel_variants() / cp_num_roles() size the profile buffers; 4 = cp_track_* added; 5 = cp_track_status, list truncation instead of reset on overflow. */
+#define CP_ABI_VERSION 5
 const char* cp_version(void);
 int cp_abi_version(void);
 const char* cp_last_error(void);
@@ -310,8 +310,9 @@ int cp_pnp_from_post(cp_stream_t stream, const double* post, const int* count, i
  *   det_pnp       DEVICE float64 [B,K,CP_PNP_STRIDE] from cp_pnp_from_post, or NULL when params->use_pnp == 0
  *   state         DEVICE, cp_track_state_bytes(B, cap) bytes, zeroed by cp_track_reset:
  *                   int32 hdr[4 + 4 B]: hdr[0] = which half holds the current lists; per video b at hdr[4 + 4 b]:
- *                   n tracks, last id given out, overflow flag (a frame needed more than cap tracks: results invalid),
- *                   scratch;  then (256-byte aligned) float64 tracks[2][B][cap][CP_TRACK_STRIDE]
+ *                   n tracks, last id given out, sticky count of list entries DROPPED because a frame needed more than cap
+ *                   tracks (the list then keeps its first cap entries in the reference's order -- matched, new by score,
+ *                   coasting -- and no id is spent on a dropped detection: read it with cp_track_status), scratch;  then (256-byte aligned) float64 tracks[2][B][cap][CP_TRACK_STRIDE]
  *                 track record (doubles): 0 tracking_id | 1 age | 2 active | 3 flags (bit 0 location / quaternion /
  *                   projected_cuboid / kps_3d_cam / kps_pnp valid, 1 kps_pnp_kf / kps_3d_cam_kf / kps_ori_kf valid, 2 in
  *                   this frame's `boxes`, 3 kps_ori valid, 4 filter state valid) | 4 the CP_POST_STRIDE detection fields |
@@ -337,6 +338,8 @@ size_t cp_track_workspace_bytes(int B, int K, int cap);
 int cp_track_reset(cp_stream_t stream, void* state, int B, int cap);
 int cp_track_step(cp_stream_t stream, const cp_track_params* params, const double* vmeta, const double* post, const int* count,
                   const double* det_pnp, int B, void* state, double* render_recs, void* workspace, size_t workspace_bytes);
+/* dropped_out: HOST int32 [B], the sticky overflow counters above.  Copies 16 + 16 B bytes and synchronises `stream`. */
+int cp_track_status(cp_stream_t stream, const void* state, int B, int* dropped_out);
 
 #ifdef __cplusplus
 }

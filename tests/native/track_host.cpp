@@ -5,7 +5,9 @@
 
 #include <vector>
 
+static int g_last_dropped = 0;
 extern "C" {
+int cp_track_host_last_dropped(void) { return g_last_dropped; }
 
 int cp_track_host_stride(void) { return CP_TRACK_STRIDE; }
 int cp_track_host_params_bytes(void) { return (int)sizeof(TrackParams); }
@@ -26,7 +28,9 @@ int cp_track_host_update(const TrackParams* P, const double* vm, const double* p
     if (!any)
         for (int k = 0; k < count; ++k) use[k] = 1;
     std::vector<int> plan((size_t)3 * (P->cap > 0 ? P->cap : 1));
-    const int n = trk_associate(*P, dets.data(), use.data(), count, prev, np, plan.data(), id_count, idx.data(), taken.data());
+    int dropped = 0;
+    const int n = trk_associate(*P, dets.data(), use.data(), count, prev, np, plan.data(), id_count, idx.data(), taken.data(), &dropped);
+    g_last_dropped = dropped;
     for (int t = 0; t < n; ++t)
         trk_materialise(plan.data() + 3 * t, dets.data(), prev, next + (size_t)t * CP_TRACK_STRIDE, 0, CP_TRACK_STRIDE);
     for (int t = 0; t < n; ++t)
