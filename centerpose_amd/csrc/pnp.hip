@@ -343,8 +343,13 @@ __global__ __launch_bounds__(64) void pnp_kernel(const float* __restrict__ pts, 
         if (!pt_valid(q, k)) continue;
         for (int d = 0; d < 3; ++d) Mc[d] += q.V3[k / per][d];
     }
+    int* rare = reinterpret_cast<int*>(scratch);  // [0] = number of rare detections, [1 ..] their indices (pnp_rare_kernel)
     if (nv < 6) {  // < 4: no pose; 4-5: EPnP branch of the reference (cuboid_pnp_solver.py:162-163), pnp_rare_kernel
-        if (sub == 0) { o[35] = nv; o[0] = nv < 4 ? -1 : -2; }
+        if (sub == 0) {
+            o[35] = nv;
+            o[0] = nv < 4 ? -1 : -2;
+            if (nv >= 4) rare[1 + atomicAdd(&rare[0], 1)] = i;
+        }
         return;
     }
     for (int d = 0; d < 3; ++d) Mc[d] /= nv;
@@ -375,7 +380,11 @@ __global__ __launch_bounds__(64) void pnp_kernel(const float* __restrict__ pts, 
         if (e1 < e2) { tmp = e1; e1 = e2; e2 = tmp; }
         if (e0 < e1) { tmp = e0; e0 = e1; e1 = tmp; }
         if (e2 / e1 < 1e-3) {  // planar: homography initialisation, pnp_rare_kernel
-            if (sub == 0) { o[35] = nv; o[0] = -3; }
+            if (sub == 0) {
+                o[35] = nv;
+                o[0] = -3;
+                rare[1 + atomicAdd(&rare[0], 1)] = i;
+            }
             return;
         }
     }
@@ -432,6 +441,7 @@ __global__ __launch_bounds__(64) void pnp_kernel(const float* __restrict__ pts, 
 __device__ void jacobi_eig(double* A, int n, double* V) {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) V[i * n + j] = i == j ? 1.0 : 0.0;
+    double prev_off = 0;
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = 0, dia = 0;
         for (int i = 0; i < n; ++i)
@@ -440,6 +450,8 @@ __device__ void jacobi_eig(double* A, int n, double* V) {
                 else off += A[i * n + j] * A[i * n + j];
             }
         if (off <= 1e-34 * dia || off == 0.0) break;
+        if (sweep > 0 && off <= 1e-24 * dia && off >= 0.25 * prev_off) break;  // the rounding floor (see jacobi_eig16)
+        prev_off = off;
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) {
                 const double apq = A[p * n + q];
@@ -466,6 +478,62 @@ __device__ void jacobi_eig(double* A, int n, double* V) {
     }
 }
 
+#ifdef CP_PNP_TIMING
+__device__ double g_pnp_t_jacobi;  // tuning build: shader clocks of the last EPnP eigen-decomposition (one detection at a time)
+#endif
+// The same rotations by the 16 lanes of a detection's group (A, V in LDS; every lane runs the same (p, q) walk, lane k owns
+// row / column k of each update): 3 LDS round trips per rotation instead of 3 n.  The convergence test sums in another order
+// (group reduction) than jacobi_eig; the rotation sequence and arithmetic are the same.
+__device__ void jacobi_eig16(double* A, int n, double* V, int k) {
+    const bool mine = k < n;
+    if (mine)
+        for (int j = 0; j < n; ++j) V[k * n + j] = k == j ? 1.0 : 0.0;
+    __syncthreads();
+    double prev_off = 0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0, dia = 0;
+        if (mine)
+            for (int j = 0; j < n; ++j) {
+                const double a = A[k * n + j];
+                if (k == j) dia += a * a;
+                else off += a * a;
+            }
+        off = gsum16(off);
+        dia = gsum16(dia);
+        if (off <= 1e-34 * dia || off == 0.0) break;  // (the same value on every lane)
+        // A rank-deficient matrix (EPnP's M^T M with 4 - 5 points has a 2 - 4 dimensional null space) never reaches 1e-34: the
+        // off-diagonal mass stalls at the rounding floor (~1e-30 of the diagonal) and the walk used all 60 sweeps -- 4.7 M
+        // clocks, all of pnp_rare_kernel's 2.1 ms.  Once the mass is tiny AND a whole sweep no longer quarters it, it is noise.
+        if (sweep > 0 && off <= 1e-24 * dia && off >= 0.25 * prev_off) break;
+        prev_off = off;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * n + q];
+                if (fabs(apq) < 1e-300) continue;
+                const double tau = (A[q * n + q] - A[p * n + p]) / (2 * apq);
+                const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1 + tau * tau));
+                const double c = 1 / sqrt(1 + t * t), sn = t * c;
+                __syncthreads();  // everyone has read apq / app / aqq
+                if (mine) {
+                    const double a = A[k * n + p], b = A[k * n + q];
+                    A[k * n + p] = c * a - sn * b;
+                    A[k * n + q] = sn * a + c * b;
+                    const double va = V[k * n + p], vb = V[k * n + q];
+                    V[k * n + p] = c * va - sn * vb;
+                    V[k * n + q] = sn * va + c * vb;
+                }
+                __syncthreads();
+                if (mine) {
+                    const double a = A[p * n + k], b = A[q * n + k];
+                    A[p * n + k] = c * a - sn * b;
+                    A[q * n + k] = sn * a + c * b;
+                }
+                __syncthreads();
+            }
+    }
+    __syncthreads();
+}
+
 // order[k] = index of the k-th smallest diagonal entry of A (n <= 12)
 __device__ void ascending(const double* A, int n, int* order) {
     for (int i = 0; i < n; ++i) order[i] = i;
@@ -478,36 +546,66 @@ __device__ void ascending(const double* A, int n, int* order) {
 }
 
 // least squares A x = b (rows x m, m <= 5) through the normal equations; false when they are singular
-__device__ bool lstsq_small(const double* A, const double* b, int rows, int m, double* x) {
-    double Nn[25], r[5];
-    for (int i = 0; i < m; ++i) {
+// Least squares through the normal equations (ROWS x M, M <= 5), everything in registers: compile-time shapes, the pivot
+// search unrolled and the row exchange as predicated selects (pnp_linalg.h: solve6).  The run-time-shaped form kept its
+// matrices in scratch memory, and the 18 solves of an EPnP detection were most of its 2 ms (profiles/NOTES.md, round 4).
+// Same comparisons and operations in the same order as the loop it replaces.
+template <int ROWS, int M>
+__device__ __forceinline__ bool lstsq_t(const double (&A)[ROWS * M], const double (&b)[ROWS], double (&x)[M]) {
+    double Nn[M * M], r[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
         r[i] = 0;
-        for (int k = 0; k < rows; ++k) r[i] += A[k * m + i] * b[k];
-        for (int j = 0; j < m; ++j) {
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) r[i] += A[k * M + i] * b[k];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
             double v = 0;
-            for (int k = 0; k < rows; ++k) v += A[k * m + i] * A[k * m + j];
-            Nn[i * m + j] = v;
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) v += A[k * M + i] * A[k * M + j];
+            Nn[i * M + j] = v;
         }
     }
-    for (int c = 0; c < m; ++c) {
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
         int piv = c;
-        for (int k = c + 1; k < m; ++k)
-            if (fabs(Nn[k * m + c]) > fabs(Nn[piv * m + c])) piv = k;
-        if (!(fabs(Nn[piv * m + c]) > 1e-300)) return false;
-        if (piv != c) {
-            for (int k = 0; k < m; ++k) { const double t = Nn[c * m + k]; Nn[c * m + k] = Nn[piv * m + k]; Nn[piv * m + k] = t; }
-            const double t = r[c]; r[c] = r[piv]; r[piv] = t;
+        double best = fabs(Nn[c * M + c]);
+#pragma unroll
+        for (int k = c + 1; k < M; ++k) {
+            const double a = fabs(Nn[k * M + c]);
+            if (a > best) { best = a; piv = k; }
         }
-        for (int k = c + 1; k < m; ++k) {
-            const double f = Nn[k * m + c] / Nn[c * m + c];
-            for (int j = c; j < m; ++j) Nn[k * m + j] -= f * Nn[c * m + j];
+        ok = ok && (best > 1e-300);
+#pragma unroll
+        for (int k2 = c + 1; k2 < M; ++k2) {
+            const bool sw = piv == k2;
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+                const double t = Nn[c * M + k], u = Nn[k2 * M + k];
+                Nn[c * M + k] = sw ? u : t;
+                Nn[k2 * M + k] = sw ? t : u;
+            }
+            const double t = r[c], u = r[k2];
+            r[c] = sw ? u : t;
+            r[k2] = sw ? t : u;
+        }
+        const double d = ok ? Nn[c * M + c] : 1.0;
+#pragma unroll
+        for (int k = c + 1; k < M; ++k) {
+            const double f = Nn[k * M + c] / d;
+#pragma unroll
+            for (int j = c; j < M; ++j) Nn[k * M + j] -= f * Nn[c * M + j];
             r[k] -= f * r[c];
         }
     }
-    for (int i = m - 1; i >= 0; --i) {
+    if (!ok) return false;
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
         double v = r[i];
-        for (int j = i + 1; j < m; ++j) v -= Nn[i * m + j] * x[j];
-        x[i] = v / Nn[i * m + i];
+#pragma unroll
+        for (int j = i + 1; j < M; ++j) v -= Nn[i * M + j] * x[j];
+        x[i] = v / Nn[i * M + i];
     }
     return true;
 }
@@ -534,7 +632,7 @@ __device__ bool polar_checked(const double* A, double* R) {
 // (+3 ms per call), and a single lane walking Jacobi sweeps over a global-memory matrix pays a DRAM round trip per
 // element (measured: 15.8 ms for a handful of planar detections).
 constexpr int RARE_WS = 600;   // doubles per detection
-constexpr int RARE_LANES = 8;  // detections per workgroup: 8 x 600 x 8 B = 38 KB of LDS
+
 struct Valid {  // the surviving correspondences of one detection
     int n;
     double (*X)[3];   // [16] model point
@@ -639,7 +737,9 @@ __device__ bool planar_init(const Problem& q, const Valid& v, double param[6], d
 // EPnP (Lepetit, Moreno-Noguer, Fua 2009) as cv::epnp runs it (oracle/pnp.py solve_pnp_epnp): control points, barycentric
 // coordinates, null space of M^T M, three beta linearisations + 5 Gauss-Newton steps each, absolute orientation, best
 // reprojection error.  No LM refinement follows for this flag.
-__device__ bool epnp(const Problem& q, const Valid& v, double param[6], double* w) {
+// Called by all 16 lanes of the detection's group with identical arguments: everything is computed redundantly (the LDS work
+// space receives the same values from every lane) except the 12 x 12 eigen-decomposition, which the lanes share.
+__device__ bool epnp(const Problem& q, const Valid& v, double param[6], double* w, int sub) {
     const int n = v.n;
     const Cam cam = q.cam;
     double cws[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -684,18 +784,28 @@ __device__ bool epnp(const Problem& q, const Valid& v, double param[6], double* 
         for (int a = 0; a < 12; ++a)
             for (int b = 0; b < 12; ++b) MtM[a * 12 + b] += r0[a] * r0[b] + r1[a] * r1[b];
     }
-    jacobi_eig(MtM, 12, EV);
+#ifdef CP_PNP_TIMING
+    const long long tj0 = clock64();
+#endif
+    __syncthreads();
+    jacobi_eig16(MtM, 12, EV, sub);
+#ifdef CP_PNP_TIMING
+    g_pnp_t_jacobi = (double)(clock64() - tj0);
+#endif
     int o12[12];
     ascending(MtM, 12, o12);
     double(*vv)[12] = reinterpret_cast<double(*)[12]>(w + 432);  // 48: the four null-space vectors
     for (int k = 0; k < 4; ++k)
         for (int a = 0; a < 12; ++a) vv[k][a] = EV[a * 12 + o12[k]];
-    const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
+    constexpr int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
     double(*L)[10] = reinterpret_cast<double(*)[10]>(w + 480);  // 60
     double rho[6];
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
         double d[4][3];
+#pragma unroll
         for (int k = 0; k < 4; ++k)
+#pragma unroll
             for (int c = 0; c < 3; ++c) d[k][c] = vv[k][3 * pa[i] + c] - vv[k][3 * pb[i] + c];
         auto dot = [&](int a, int b) { return d[a][0] * d[b][0] + d[a][1] * d[b][1] + d[a][2] * d[b][2]; };
         L[i][0] = dot(0, 0); L[i][1] = 2 * dot(0, 1); L[i][2] = dot(1, 1); L[i][3] = 2 * dot(0, 2); L[i][4] = 2 * dot(1, 2);
@@ -707,21 +817,38 @@ __device__ bool epnp(const Problem& q, const Valid& v, double param[6], double* 
     bool cok[3] = {false, false, false};
     {   // N = 1: betas 11, 12, 13, 14
         double A[24], x[4];
-        const int cols[4] = {0, 1, 3, 6};
+        constexpr int cols[4] = {0, 1, 3, 6};
+#pragma unroll
         for (int i = 0; i < 6; ++i)
+#pragma unroll
             for (int j = 0; j < 4; ++j) A[i * 4 + j] = L[i][cols[j]];
-        if (lstsq_small(A, rho, 6, 4, x)) {
+        if (lstsq_t<6, 4>(A, rho, x)) {
             const double sgn = x[0] < 0 ? -1.0 : 1.0, b0 = sqrt(fabs(x[0]));
             cand[0][0] = b0; cand[0][1] = sgn * x[1] / b0; cand[0][2] = sgn * x[2] / b0; cand[0][3] = sgn * x[3] / b0;
             cok[0] = b0 > 0;
         }
     }
+#pragma unroll
     for (int variant = 0; variant < 2; ++variant) {  // N = 2 (betas 11, 12, 22) and N = 3 (+ 13, 23)
-        const int m = variant == 0 ? 3 : 5;
-        double A[30], x[5];
-        for (int i = 0; i < 6; ++i)
-            for (int j = 0; j < m; ++j) A[i * m + j] = L[i][j];
-        if (!lstsq_small(A, rho, 6, m, x)) continue;
+        double x[5] = {0, 0, 0, 0, 0};
+        bool solved;
+        if (variant == 0) {
+            double A[18], x3[3];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) A[i * 3 + j] = L[i][j];
+            solved = lstsq_t<6, 3>(A, rho, x3);
+            x[0] = x3[0]; x[1] = x3[1]; x[2] = x3[2];
+        } else {
+            double A[30];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) A[i * 5 + j] = L[i][j];
+            solved = lstsq_t<6, 5>(A, rho, x);
+        }
+        if (!solved) continue;
         double b0, b1;
         if (x[0] < 0) { b0 = sqrt(-x[0]); b1 = x[2] < 0 ? sqrt(-x[2]) : 0.0; }
         else { b0 = sqrt(x[0]); b1 = x[2] > 0 ? sqrt(x[2]) : 0.0; }
@@ -733,6 +860,7 @@ __device__ bool epnp(const Problem& q, const Valid& v, double param[6], double* 
     }
     double best = 1e300, bestR[9], bestT[3];
     bool have = false;
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
         if (!cok[c]) continue;
         double b[4] = {cand[c][0], cand[c][1], cand[c][2], cand[c][3]};
@@ -748,7 +876,7 @@ __device__ bool epnp(const Problem& q, const Valid& v, double param[6], double* 
                 r[i] = rho[i] - (l[0] * b[0] * b[0] + l[1] * b[0] * b[1] + l[2] * b[1] * b[1] + l[3] * b[0] * b[2] + l[4] * b[1] * b[2] +
                                  l[5] * b[2] * b[2] + l[6] * b[0] * b[3] + l[7] * b[1] * b[3] + l[8] * b[2] * b[3] + l[9] * b[3] * b[3]);
             }
-            if (!lstsq_small(A, r, 6, 4, dx)) { fin = false; break; }
+            if (!lstsq_t<6, 4>(A, r, dx)) { fin = false; break; }
             for (int k = 0; k < 4; ++k) b[k] += dx[k];
         }
         if (!fin) continue;
@@ -789,40 +917,55 @@ __device__ bool epnp(const Problem& q, const Valid& v, double param[6], double* 
     return true;
 }
 
-__global__ __launch_bounds__(64) void pnp_rare_kernel(const float* __restrict__ pts, const float* __restrict__ scale,
+// One 16-lane workgroup per RARE detection, taken from the list pnp_kernel compacted (round 3 walked all N slots with one
+// lane per detection, eight detections of different branches sharing a wavefront: 8 ms for 650 of them).  Lane 0 runs the
+// branch's initialisation (EPnP: the whole solve; planar: homography -> pose) out of the workgroup's LDS work space; the
+// Levenberg-Marquardt refinement of the planar branch then runs on all 16 lanes like pnp_kernel's (lane = image point).
+__global__ __launch_bounds__(16) void pnp_rare_kernel(const float* __restrict__ pts, const float* __restrict__ scale,
                                                       const double* __restrict__ camp, int N, int npts,
-                                                      double* __restrict__ out) {
-    __shared__ double lw[RARE_LANES][RARE_WS];
-    const int i = blockIdx.x * RARE_LANES + threadIdx.x;
-    if (threadIdx.x >= RARE_LANES || i >= N) return;
+                                                      double* __restrict__ out, const int* __restrict__ rare) {
+    __shared__ double w[RARE_WS];
+    if ((int)blockIdx.x >= rare[0]) return;
+    const int i = rare[1 + blockIdx.x], sub = threadIdx.x;
     double* o = out + (size_t)i * CP_PNP_STRIDE;
-    const int status = (int)o[0];
-    if (status != -2 && status != -3) return;
+    const int status = (int)o[0];  // -2 (4-5 valid points) / -3 (planar model), written by pnp_kernel
+#ifdef CP_PNP_TIMING
+    const long long t0 = clock64();
+#endif
     Problem q;
     load_problem(q, pts, scale, camp, i, npts);
-    double* w = lw[threadIdx.x];
+    // every lane runs the branch's initialisation with the same data (same values into the shared work space)
     Valid v;
     collect(q, v, w);
     double param[6];
-    int iters = 0;
     bool ok;
     if (status == -2) {
-        ok = epnp(q, v, param, w);  // SOLVEPNP_EPNP: the pose is returned as is (no iterative refinement in OpenCV)
+        ok = epnp(q, v, param, w, sub);  // SOLVEPNP_EPNP: the pose is returned as is (no iterative refinement in OpenCV)
     } else {
         ok = planar_init(q, v, param, w);
         if (!ok)
             for (int k = 0; k < 6; ++k) param[k] = 0.0;  // cvFindExtrinsicCameraParams2 falls back to r = t = 0
-        iters = lm_refine(q, param);
         ok = true;
     }
+#ifdef CP_PNP_TIMING
+    const long long t1 = clock64();
+#endif
+    int iters = 0;
+    if (status == -3) iters = lm_refine16(q, param, sub);
     for (int k = 0; k < 6; ++k) ok = ok && (param[k] == param[k]) && fabs(param[k]) < 1e300;
-    if (!ok) { o[0] = 0; return; }
-    write_pose(q, param, iters, o);
+    if (!ok) {
+        if (sub == 0) o[0] = 0;
+        return;
+    }
+    write_pose16(q, param, iters, o, sub);
+#ifdef CP_PNP_TIMING
+    if (sub == 0) { o[37] = (double)(t1 - t0); o[38] = (double)(clock64() - t1); o[39] = status == -2 ? g_pnp_t_jacobi : 0.0; }
+#endif
 }
 
 }  // namespace
 
-size_t cp_pnp_ws_bytes(int N) { return (size_t)N * 288 * sizeof(double) + 256; }  // (unused by the current kernels)
+size_t cp_pnp_ws_bytes(int N) { return (size_t)N * 288 * sizeof(double) + 256; }  // used: (1 + N) ints, the rare-detection list
 
 int cp_launch_pnp(hipStream_t s, const float* pts, const float* scale, const double* cam, int N, int npts, double* out,
                   void* ws) {
@@ -833,12 +976,13 @@ int cp_launch_pnp(hipStream_t s, const float* pts, const float* scale, const dou
     // ill-posed ones sharing a wavefront run one after the other (batch-1 frame of the random-weight network: 2.09 -> 2.02 ms).
     // Larger batches keep four detections per wavefront: with well-posed detections the walks agree and a quarter of the
     // wavefronts is the better trade (640 / 6400 detections: 314 / 583 us against 424 / 741).
+    if (!ws || hipMemsetAsync(ws, 0, sizeof(int), s) != hipSuccess) return CP_ERR_INVALID;  // the rare list's counter
     if (N <= 256)
         hipLaunchKernelGGL(pnp_kernel, dim3(N), dim3(16), 0, s, pts, scale, cam, N, npts, out, (double*)ws);
     else
         hipLaunchKernelGGL(pnp_kernel, dim3((N * 16 + 63) / 64), dim3(64), 0, s, pts, scale, cam, N, npts, out, (double*)ws);
-    // detections the common-case kernel marked -2 (4-5 valid points) / -3 (planar model); a no-op otherwise
-    hipLaunchKernelGGL(pnp_rare_kernel, dim3((N + RARE_LANES - 1) / RARE_LANES), dim3(64), 0, s, pts, scale, cam, N, npts,
-                       out);
+    // detections the common-case kernel marked -2 (4-5 valid points) / -3 (planar model) and appended to the list at `ws`:
+    // one 16-lane workgroup per list entry (the grid covers the worst case; workgroups past the count leave at once)
+    hipLaunchKernelGGL(pnp_rare_kernel, dim3(N), dim3(16), 0, s, pts, scale, cam, N, npts, out, (const int*)ws);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }

@@ -46,7 +46,8 @@ class BatchedTracking(object):
         for t in self.trackers:
             t.reset()
         if self.dev is not None:
-            self.dev = None   # rebuilt (with the next frame's meta) by the next step
+            self.dev.reset()
+            self._vmeta = None   # the next frame's meta is taken as the videos' meta again
         self.pre_images = None
         self.frames = 0
 
@@ -68,6 +69,9 @@ class BatchedTracking(object):
             self._vmeta = np.asarray(_hip.track_vmeta(metas), np.float64)
             self.dev = _hip.DeviceTracker(B, _hip.track_params_from_opt(opt, K=opt.K), self._vmeta, opt.device,
                                           metas[0]['inp_height'], metas[0]['inp_width'])
+        elif self._vmeta is None:  # first frame after reset()
+            self._vmeta = np.asarray(_hip.track_vmeta(metas), np.float64)
+            self.dev.vmeta.copy_(torch.from_numpy(self._vmeta).reshape(B, 16))
         else:
             # the device keeps the per-video meta (trans_input, frame size, intrinsics) of the first frame: a video whose meta
             # changes from frame to frame is not what it tracks

@@ -49,7 +49,11 @@ def scenes(N, seed=0, noise=1.5, live=1.0, drop=0.0):
 
 def main():
     dev = torch.device("cuda:0")
-    for N, live, drop in ((1, 1.0, 0.0), (64, 1.0, 0.0), (640, 1.0, 0.0), (6400, 1.0, 0.0), (6400, 0.1, 0.0), (6400, 0.1, 0.3)):
+    cases = ((1, 1.0, 0.0), (64, 1.0, 0.0), (640, 1.0, 0.0), (6400, 1.0, 0.0), (6400, 0.1, 0.0), (6400, 0.1, 0.3))
+    if len(sys.argv) > 1:  # python tools/pnp_bench.py 5  -> only that case (under rocprofv3: per-kernel times of one case)
+        cases = cases[int(sys.argv[1]):int(sys.argv[1]) + 1]
+    for N, live, drop in cases:
+        timing = os.environ.get("CENTERPOSE_HIP_LIB", "").endswith("pnpt.so")
         p, s, c = scenes(N, seed=N, live=live, drop=drop)
         p, s, c = torch.from_numpy(p).to(dev), torch.from_numpy(s).to(dev), torch.from_numpy(c).to(dev)
         for _ in range(3):
@@ -66,6 +70,11 @@ def main():
         print("N %5d live %.2f drop %.1f: %8.1f us per call; status counts %s; LM iterations mean %.1f max %d; rms mean %.3f"
               % (N, live, drop, e0.elapsed_time(e1) * 100, dict(zip(*np.unique(st, return_counts=True))),
                  it[st > 0].mean() if (st > 0).any() else 0, it.max(), float(out[:, 7][out[:, 0] > 0].mean()) if (st > 0).any() else 0))
+        if timing:  # -DCP_PNP_TIMING build: shader clocks of the rare detections' phases in the spare columns of their rows
+            ph = out[:, 37:40].cpu().numpy()
+            for i in np.nonzero(ph[:, 0] > 0)[0]:
+                print("   rare detection %d (status %d, %d valid points): init %.0f clocks (EPnP eigen-decomposition %.0f), refine + pose %.0f"
+                      % (i, st[i], int(out[i, 35]), ph[i, 0], ph[i, 2], ph[i, 1]))
 
 
 if __name__ == "__main__":
