@@ -115,6 +115,22 @@ _OBJECT_POSE_INFO = {
 }
 
 
+def _csv(text, kind):
+    return [kind(v) for v in text.split(',')]
+
+
+def _gpu_ids(text):
+    ids = _csv(text, int)
+    return list(range(len(ids))) if ids[0] >= 0 else [-1]
+
+
+def _chunks(batch, master, n_gpus):
+    """Per-GPU chunk sizes of a DataParallel batch: the master's share first, the rest spread as evenly as it divides."""
+    rest, others = batch - master, n_gpus - 1
+    return [master] + [rest // others + (1 if i < rest % others else 0) for i in range(others)]
+
+
+
 class opts(object):
     def __init__(self):
         self.parser = argparse.ArgumentParser()
@@ -131,87 +147,72 @@ class opts(object):
             else:
                 self.parser.add_argument(name, default=f[2])
 
+    # ---- derived options: one table, evaluated in order (each rule sees the fields set before it).  The field names, their
+    #      meaning and the two console lines are the reference's interface (opts.py:330-429); the formulation is this repo's,
+    #      and tests/golden/opts_scenarios.json pins the resulting Namespace field by field against the reference's own parse().
+    _DERIVED = (
+        ('gpus_str', lambda o: o.gpus),
+        ('gpus', lambda o: _gpu_ids(o.gpus)),
+        ('lr_step', lambda o: _csv(o.lr_step, int)),
+        ('test_scales', lambda o: _csv(o.test_scales, float)),
+        ('fix_res', lambda o: not o.keep_res),
+        ('reg_offset', lambda o: not o.not_reg_offset),
+        ('reg_bbox', lambda o: not o.not_reg_bbox),
+        ('hm_hp', lambda o: not o.not_hm_hp),
+        ('reg_hp_offset', lambda o: o.hm_hp and not o.not_reg_hp_offset),
+        ('head_conv', lambda o: o.head_conv if o.head_conv != -1 else (256 if 'dla' in o.arch else 64)),
+        ('pad', lambda o: 127 if 'hourglass' in o.arch else 31),
+        ('num_stacks', lambda o: 2 if o.arch == 'hourglass' else 1),
+        ('val_intervals', lambda o: 100000000 if o.trainval else o.val_intervals),
+        # --debug > 0: single worker-less, single-image, single-GPU run
+        ('num_workers', lambda o: 0 if o.debug > 0 else o.num_workers),
+        ('batch_size', lambda o: 1 if o.debug > 0 else o.batch_size),
+        ('gpus', lambda o: o.gpus[:1] if o.debug > 0 else o.gpus),
+        ('master_batch_size', lambda o: o.batch_size // len(o.gpus) if (o.debug > 0 or o.master_batch_size == -1)
+            else o.master_batch_size),
+        ('chunk_sizes', lambda o: _chunks(o.batch_size, o.master_batch_size, len(o.gpus))),
+        ('root_dir', lambda o: os.path.join(os.path.dirname(__file__), '..', '..')),
+        ('data_dir', lambda o: os.path.join(o.root_dir, 'data')),
+        ('exp_dir', lambda o: os.path.join(o.root_dir, 'exp', o.task)),
+        ('save_dir', lambda o: os.path.join(o.exp_dir, o.exp_id)),
+        ('debug_dir', lambda o: os.path.join(o.save_dir, 'debug')),
+    )
+    # head name -> (channels, enabled?) in the order the reference inserts them into the dict
+    _HEADS = (
+        ('hm', lambda o: o.num_classes, lambda o: True),
+        ('wh', lambda o: 2, lambda o: True),
+        ('hps', lambda o: 16, lambda o: True),
+        ('hps_uncertainty', lambda o: 16, lambda o: o.hps_uncertainty),
+        ('reg', lambda o: 2, lambda o: o.reg_offset),
+        ('hm_hp', lambda o: 8, lambda o: o.hm_hp),
+        ('hp_offset', lambda o: 2, lambda o: o.reg_hp_offset),
+        ('scale', lambda o: 3, lambda o: o.obj_scale),
+        ('scale_uncertainty', lambda o: 3, lambda o: o.obj_scale and o.obj_scale_uncertainty),
+        ('tracking', lambda o: 2, lambda o: o.tracking == True),        # noqa: E712 (the reference's truthiness test)
+        ('tracking_hp', lambda o: 16, lambda o: o.tracking_hp == True),  # noqa: E712
+    )
+
     def parse(self, opt):
-        """Derived options, opts.py:330-376."""
-        opt.gpus_str = opt.gpus
-        opt.gpus = [int(g) for g in opt.gpus.split(',')]
-        opt.gpus = list(range(len(opt.gpus))) if opt.gpus[0] >= 0 else [-1]
-        opt.lr_step = [int(i) for i in opt.lr_step.split(',')]
-        opt.test_scales = [float(i) for i in opt.test_scales.split(',')]
-
-        opt.fix_res = not opt.keep_res
+        """Derived options (the reference's opts.py:330-376 as a table)."""
+        for name, rule in self._DERIVED:
+            setattr(opt, name, rule(opt))
         print('Fix size testing.' if opt.fix_res else 'Keep resolution testing.')
-        opt.reg_offset = not opt.not_reg_offset
-        opt.reg_bbox = not opt.not_reg_bbox
-        opt.hm_hp = not opt.not_hm_hp
-        opt.reg_hp_offset = (not opt.not_reg_hp_offset) and opt.hm_hp
-
-        if opt.head_conv == -1:
-            opt.head_conv = 256 if 'dla' in opt.arch else 64
-        opt.pad = 127 if 'hourglass' in opt.arch else 31
-        opt.num_stacks = 2 if opt.arch == 'hourglass' else 1
-
-        if opt.trainval:
-            opt.val_intervals = 100000000
-        if opt.debug > 0:
-            opt.num_workers = 0
-            opt.batch_size = 1
-            opt.gpus = [opt.gpus[0]]
-            opt.master_batch_size = -1
-        if opt.master_batch_size == -1:
-            opt.master_batch_size = opt.batch_size // len(opt.gpus)
-        rest = opt.batch_size - opt.master_batch_size
-        opt.chunk_sizes = [opt.master_batch_size]
-        for i in range(len(opt.gpus) - 1):
-            chunk = rest // (len(opt.gpus) - 1)
-            if i < rest % (len(opt.gpus) - 1):
-                chunk += 1
-            opt.chunk_sizes.append(chunk)
         print('training chunk_sizes:', opt.chunk_sizes)
-
-        opt.root_dir = os.path.join(os.path.dirname(__file__), '..', '..')
-        opt.data_dir = os.path.join(opt.root_dir, 'data')
-        opt.exp_dir = os.path.join(opt.root_dir, 'exp', opt.task)
-        opt.save_dir = os.path.join(opt.exp_dir, opt.exp_id)
-        opt.debug_dir = os.path.join(opt.save_dir, 'debug')
         print('The output will be saved to ', opt.save_dir)
         return opt
 
     def update_dataset_info_and_set_heads(self, opt, dataset):
-        """opts.py:378-429"""
-        input_h, input_w = dataset.default_resolution
-        opt.mean, opt.std = dataset.mean, dataset.std
-        opt.num_classes = dataset.num_classes
-        input_h = opt.input_res if opt.input_res > 0 else input_h
-        input_w = opt.input_res if opt.input_res > 0 else input_w
-        opt.input_h = opt.input_h if opt.input_h > 0 else input_h
-        opt.input_w = opt.input_w if opt.input_w > 0 else input_w
-        opt.output_h = opt.input_h // opt.down_ratio
-        opt.output_w = opt.input_w // opt.down_ratio
-        opt.input_res = max(opt.input_h, opt.input_w)
-        opt.output_res = max(opt.output_h, opt.output_w)
-        opt.flip_idx = dataset.flip_idx
-
-        opt.heads = {'hm': opt.num_classes, 'wh': 2, 'hps': 16}
-        if opt.hps_uncertainty:
-            opt.heads.update({'hps_uncertainty': 16})
-        if opt.reg_offset:
-            opt.heads.update({'reg': 2})
-        if opt.hm_hp:
-            opt.heads.update({'hm_hp': 8})
-        if opt.reg_hp_offset:
-            opt.heads.update({'hp_offset': 2})
-        if opt.obj_scale:
-            opt.heads.update({'scale': 3})
-            if opt.obj_scale_uncertainty:
-                opt.heads.update({'scale_uncertainty': 3})
+        """Resolution fields and the head dictionary (opts.py:378-429)."""
+        opt.mean, opt.std, opt.num_classes, opt.flip_idx = dataset.mean, dataset.std, dataset.num_classes, dataset.flip_idx
+        for axis, default in zip(('input_h', 'input_w'), dataset.default_resolution):
+            explicit = getattr(opt, axis)
+            setattr(opt, axis, explicit if explicit > 0 else (opt.input_res if opt.input_res > 0 else default))
+        opt.output_h, opt.output_w = opt.input_h // opt.down_ratio, opt.input_w // opt.down_ratio
+        opt.input_res, opt.output_res = max(opt.input_h, opt.input_w), max(opt.output_h, opt.output_w)
+        opt.heads = {name: width(opt) for name, width, on in self._HEADS if on(opt)}
         if opt.use_residual:
-            ref = dataset.dimension_ref['mug'] if (opt.c == 'cup' and opt.mug) else dataset.dimension_ref[opt.c]
-            opt.dimension_ref = ref[0][0:3] if opt.use_absolute_scale else [ref[0][3], 1, ref[0][4]]
-        if opt.tracking == True:  # noqa: E712 (same truthiness test as the reference)
-            opt.heads.update({'tracking': 2})
-        if opt.tracking_hp == True:  # noqa: E712
-            opt.heads.update({'tracking_hp': 16})
+            ref = dataset.dimension_ref['mug' if (opt.c == 'cup' and opt.mug) else opt.c][0]
+            opt.dimension_ref = ref[0:3] if opt.use_absolute_scale else [ref[3], 1, ref[4]]
         print('heads', opt.heads)
         return opt
 
