@@ -59,6 +59,10 @@ __global__ __launch_bounds__(64) void track_associate_kernel(const TrackParams P
     __shared__ int det_idx[128];
     __shared__ unsigned char taken[128];
     __shared__ int s_n;
+    // work space of the optimal assignment (P.hungarian): one entry per detection / track, LS = 129
+    __shared__ double ls_u[129], ls_v[129], ls_spc[129];
+    __shared__ int ls_path[129], ls_c4r[129], ls_r4c[129], ls_rem[129], ls_match[129];
+    __shared__ unsigned char ls_sr[129], ls_sc[129];
     const int b = blockIdx.x, lane = threadIdx.x;
     StateView S = view(state, B);
     const int par = S.hdr[0];
@@ -74,7 +78,8 @@ __global__ __launch_bounds__(64) void track_associate_kernel(const TrackParams P
         if (!any)
             for (int k = 0; k < nd; ++k) u[k] = 1;  // no box at all: every detection takes part (tracker.py:116-117)
         int idc = h[1], dropped = 0;
-        const int n = trk_associate(P, d, u, nd, prev, h[0], plan, &idc, det_idx, taken, &dropped);
+        const TrkLsapWork W = {ls_u, ls_v, ls_spc, ls_path, ls_c4r, ls_r4c, ls_rem, ls_sr, ls_sc};
+        const int n = trk_associate(P, d, u, nd, prev, h[0], plan, &idc, det_idx, taken, &dropped, &W, ls_match);
         h[1] = idc;
         h[2] += dropped;  // sticky count of list entries dropped because a frame needed more than `cap` (cp_track_status)
         s_n = n;

@@ -84,6 +84,8 @@ struct TrackParams {
                    // cereal_box (6 points), 2 = bike / laptop / shoe (none)
     int render_hm_mode, render_hmhp_mode, pre_hm, pre_hm_hp;
     int K, cap;
+    int hungarian;  // association by optimal assignment (tracker.py:154-170) instead of the greedy walk
+    int pad_;
 };
 
 // per video: trans_input (2 x 3, row-major) | width height inp_w inp_h | fx fy cx cy
@@ -94,6 +96,79 @@ struct TrackParams {
 #define VM_INP_H 9
 #define VM_CAM 10
 #define CP_VMETA_STRIDE 16
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Rectangular linear sum assignment exactly as scipy.optimize.linear_sum_assignment computes it (the reference calls
+// sklearn 0.22's linear_assignment, tracker.py:157; sklearn is absent and the goldens come from scipy's solver, which returns
+// the same optimum): Crouse's shortest augmenting path (2016) with scipy's conventions -- rows are the shorter side (a tall
+// matrix is transposed), the candidate list is filled in reverse, ties prefer a column that ends the path, the duals are
+// updated after every augmentation -- and the same float64 operations in the same order, so that even the assignments among
+// 1e18-"forbidden" pairs (whose duals swallow the low bits of the real costs) come out as scipy's do.
+// cost(i, j): det i x track j; nd x nt; match[i] = track of det i or -1.  Work space: u / spc [LS] doubles, v [LS] doubles,
+// path / col4row / row4col / remaining [LS] ints, SR / SC [LS] bytes with LS >= max(nd, nt).
+struct TrkLsapWork {
+    double* u; double* v; double* spc;
+    int* path; int* col4row; int* row4col; int* remaining;
+    unsigned char* SR; unsigned char* SC;
+};
+template <class Cost>
+CP_HD void trk_lsap(const Cost& cost, int nd, int nt, int* match, const TrkLsapWork& W) {
+    for (int i = 0; i < nd; ++i) match[i] = -1;
+    if (nd == 0 || nt == 0) return;
+    const bool tr = nt < nd;                 // tall: rows = tracks, columns = detections
+    const int nr = tr ? nt : nd, nc = tr ? nd : nt;
+    auto C = [&](int i, int j) -> double { return tr ? cost(j, i) : cost(i, j); };
+    for (int i = 0; i < nr; ++i) { W.u[i] = 0.0; W.col4row[i] = -1; }
+    for (int j = 0; j < nc; ++j) { W.v[j] = 0.0; W.path[j] = -1; W.row4col[j] = -1; }
+    const double INF = __builtin_huge_val();
+    for (int cur = 0; cur < nr; ++cur) {
+        // ---- shortest augmenting path from row `cur` ----
+        double minVal = 0.0;
+        int num_remaining = nc;
+        for (int it = 0; it < nc; ++it) W.remaining[it] = nc - it - 1;
+        for (int i = 0; i < nr; ++i) W.SR[i] = 0;
+        for (int j = 0; j < nc; ++j) { W.SC[j] = 0; W.spc[j] = INF; }
+        int sink = -1, i = cur;
+        while (sink == -1) {
+            int index = -1;
+            double lowest = INF;
+            W.SR[i] = 1;
+            for (int it = 0; it < num_remaining; ++it) {
+                const int j = W.remaining[it];
+                const double r = minVal + C(i, j) - W.u[i] - W.v[j];
+                if (r < W.spc[j]) { W.path[j] = i; W.spc[j] = r; }
+                if (W.spc[j] < lowest || (W.spc[j] == lowest && W.row4col[j] == -1)) { lowest = W.spc[j]; index = it; }
+            }
+            minVal = lowest;
+            if (!(minVal < INF)) return;  // infeasible (cannot happen: every cost is finite)
+            const int j = W.remaining[index];
+            if (W.row4col[j] == -1) sink = j;
+            else i = W.row4col[j];
+            W.SC[j] = 1;
+            W.remaining[index] = W.remaining[--num_remaining];
+        }
+        // ---- dual variables ----
+        W.u[cur] += minVal;
+        for (int r = 0; r < nr; ++r)
+            if (W.SR[r] && r != cur) W.u[r] += minVal - W.spc[W.col4row[r]];
+        for (int j = 0; j < nc; ++j)
+            if (W.SC[j]) W.v[j] -= minVal - W.spc[j];
+        // ---- augment ----
+        int j = sink;
+        for (;;) {
+            const int r = W.path[j];
+            W.row4col[j] = r;
+            const int t = W.col4row[r];
+            W.col4row[r] = j;
+            j = t;
+            if (r == cur) break;
+        }
+    }
+    for (int r = 0; r < nr; ++r) {
+        if (tr) match[W.col4row[r]] = r;  // row = track, its column = the detection
+        else match[r] = W.col4row[r];
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Gaussian fusion (base_detector.py:503-536), hps_uncertainty branch and the fixed-variance branch.  The reference's standard
@@ -484,12 +559,44 @@ CP_HD void trk_render_records(const TrackParams& P, const double* vm, const doub
 // is given to a dropped detection; a dropped coasting track is simply retired early) and the caller can surface the event.
 CP_HD int trk_associate(const TrackParams& P, const double* dets, const int* use, int nd_all, const double* prev, int np,
                         int* plan, int* id_count, int* det_idx /* scratch [K] */, unsigned char* taken /* scratch [cap] */,
-                        int* dropped) {
+                        int* dropped, const TrkLsapWork* lsap = nullptr, int* lsap_match /* scratch [K] */ = nullptr) {
     *dropped = 0;
     int nd = 0;
     for (int k = 0; k < nd_all; ++k)
         if (use[k]) det_idx[nd++] = k;
     for (int t = 0; t < np; ++t) taken[t] = 0;
+    if (P.hungarian && lsap) {
+        // ---- optimal assignment over the same cost matrix (:130-157), forbidden pairs undone afterwards (:167-174) ----
+        auto cost = [&](int i, int t) -> double {
+            const double* d = dets + (long long)det_idx[i] * CP_TRACK_STRIDE;
+            const double* tr = prev + (long long)t * CP_TRACK_STRIDE;
+            const float dcx = f32(d[TR_POST + PO_CT] + d[TR_POST + PO_TRACKING]);
+            const float dcy = f32(d[TR_POST + PO_CT + 1] + d[TR_POST + PO_TRACKING + 1]);
+            const float darea = f32((d[TR_POST + PO_BBOX + 2] - d[TR_POST + PO_BBOX]) *
+                                    (d[TR_POST + PO_BBOX + 3] - d[TR_POST + PO_BBOX + 1]));
+            const float ex = f32(tr[TR_POST + PO_CT]) - dcx, ey = f32(tr[TR_POST + PO_CT + 1]) - dcy;
+            const float ex2 = ex * ex, ey2 = ey * ey;
+            const float c32 = ex2 + ey2;
+            const float tarea = f32((tr[TR_POST + PO_BBOX + 2] - tr[TR_POST + PO_BBOX]) *
+                                    (tr[TR_POST + PO_BBOX + 3] - tr[TR_POST + PO_BBOX + 1]));
+            const bool bad = c32 > tarea || c32 > darea || (int)d[TR_POST + PO_CLS] != (int)tr[TR_POST + PO_CLS];
+            const double c = (double)c32 + (bad ? 1e18 : 0.0);
+            return c > 1e18 ? 1e18 : c;  // dist[dist > 1e18] = 1e18
+        };
+        trk_lsap(cost, nd, np, lsap_match, *lsap);
+        for (int i = 0; i < nd; ++i) {
+            const int match = lsap_match[i];
+            if (match >= 0 && cost(i, match) > 1e16) {
+                // a forbidden pair of the optimum is undone (:167-174): both ends go to the END of the unmatched lists, in pair
+                // order -- after the detections / tracks the assignment left out altogether
+                taken[match] = 2;
+                det_idx[i] |= (1 << 30) | ((match + 1) << 16);
+            } else {
+                if (match >= 0) taken[match] = 1;
+                det_idx[i] |= (match + 1) << 16;
+            }
+        }
+    } else
     // ---- greedy: detections in order, each takes its nearest still-free admissible track (:305-314) ----
     for (int i = 0; i < nd; ++i) {
         const double* d = dets + (long long)det_idx[i] * CP_TRACK_STRIDE;
@@ -518,23 +625,35 @@ CP_HD int trk_associate(const TrackParams& P, const double* dets, const int* use
     }
     int n_out = 0;
     for (int i = 0; i < nd; ++i) {  // matched, in detection order
-        const int k = det_idx[i] & 0xffff, match = (det_idx[i] >> 16) - 1;
-        if (match < 0) continue;
+        const int k = det_idx[i] & 0xffff, match = ((det_idx[i] >> 16) & 0x3fff) - 1;
+        if (match < 0 || (det_idx[i] & (1 << 30))) continue;
         if (n_out >= P.cap) { *dropped += 1; continue; }  // (cannot happen: matches <= np <= cap)
         plan[3 * n_out] = 0; plan[3 * n_out + 1] = k; plan[3 * n_out + 2] = match;
         ++n_out;
     }
-    for (int i = 0; i < nd; ++i) {  // unmatched detections above new_thresh start tracks
-        const int k = det_idx[i] & 0xffff, match = (det_idx[i] >> 16) - 1;
-        if (match >= 0) continue;
-        if (!(dets[(long long)k * CP_TRACK_STRIDE + TR_POST + PO_SCORE] > P.new_thresh)) continue;
+    // unmatched detections above new_thresh start tracks: first the ones the association left out, then (Hungarian only) the
+    // ones whose forbidden pair was undone -- the order in which the reference's list grows and ids are handed out
+    for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < nd; ++i) {
+            const int k = det_idx[i] & 0xffff, match = ((det_idx[i] >> 16) & 0x3fff) - 1;
+            const bool undone = (det_idx[i] & (1 << 30)) != 0;
+            if (pass == 0 ? (match >= 0 || undone) : !undone) continue;
+            if (!(dets[(long long)k * CP_TRACK_STRIDE + TR_POST + PO_SCORE] > P.new_thresh)) continue;
+            if (n_out >= P.cap) { *dropped += 1; continue; }
+            *id_count += 1;
+            plan[3 * n_out] = 1; plan[3 * n_out + 1] = k; plan[3 * n_out + 2] = *id_count;
+            ++n_out;
+        }
+    for (int t = 0; t < np; ++t) {  // unmatched tracks coast until max_age: the left-out ones in track order ...
+        if (taken[t]) continue;
+        if (!(prev[(long long)t * CP_TRACK_STRIDE + TR_AGE] < P.max_age)) continue;
         if (n_out >= P.cap) { *dropped += 1; continue; }
-        *id_count += 1;
-        plan[3 * n_out] = 1; plan[3 * n_out + 1] = k; plan[3 * n_out + 2] = *id_count;
+        plan[3 * n_out] = 2; plan[3 * n_out + 1] = -1; plan[3 * n_out + 2] = t;
         ++n_out;
     }
-    for (int t = 0; t < np; ++t) {  // unmatched tracks coast until max_age
-        if (taken[t]) continue;
+    for (int i = 0; i < nd; ++i) {  // ... then the tracks of undone pairs, in pair (= detection) order
+        if (!(det_idx[i] & (1 << 30))) continue;
+        const int t = ((det_idx[i] >> 16) & 0x3fff) - 1;
         if (!(prev[(long long)t * CP_TRACK_STRIDE + TR_AGE] < P.max_age)) continue;
         if (n_out >= P.cap) { *dropped += 1; continue; }
         plan[3 * n_out] = 2; plan[3 * n_out + 1] = -1; plan[3 * n_out + 2] = t;

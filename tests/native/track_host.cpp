@@ -29,13 +29,29 @@ int cp_track_host_update(const TrackParams* P, const double* vm, const double* p
         for (int k = 0; k < count; ++k) use[k] = 1;
     std::vector<int> plan((size_t)3 * (P->cap > 0 ? P->cap : 1));
     int dropped = 0;
-    const int n = trk_associate(*P, dets.data(), use.data(), count, prev, np, plan.data(), id_count, idx.data(), taken.data(), &dropped);
+    const int LS = (count > np ? count : np) + 1;
+    std::vector<double> wu(LS), wv(LS), ws(LS);
+    std::vector<int> wp(LS), wc(LS), wr(LS), wrem(LS), lm(LS);
+    std::vector<unsigned char> wsr(LS), wsc(LS);
+    const TrkLsapWork W = {wu.data(), wv.data(), ws.data(), wp.data(), wc.data(), wr.data(), wrem.data(), wsr.data(), wsc.data()};
+    const int n = trk_associate(*P, dets.data(), use.data(), count, prev, np, plan.data(), id_count, idx.data(), taken.data(), &dropped,
+                                &W, lm.data());
     g_last_dropped = dropped;
     for (int t = 0; t < n; ++t)
         trk_materialise(plan.data() + 3 * t, dets.data(), prev, next + (size_t)t * CP_TRACK_STRIDE, 0, CP_TRACK_STRIDE);
     for (int t = 0; t < n; ++t)
         trk_track_stage(*P, next + (size_t)t * CP_TRACK_STRIDE, prev, pts + (size_t)t * 16, scale + (size_t)t * 3);
     return n;
+}
+
+// the assignment alone, on an explicit nd x nt cost matrix (tests: against scipy.optimize.linear_sum_assignment)
+void cp_track_host_lsap(const double* cost, int nd, int nt, int* match) {
+    const int LS = (nd > nt ? nd : nt) + 1;
+    std::vector<double> wu(LS), wv(LS), ws(LS);
+    std::vector<int> wp(LS), wc(LS), wr(LS), wrem(LS);
+    std::vector<unsigned char> wsr(LS), wsc(LS);
+    const TrkLsapWork W = {wu.data(), wv.data(), ws.data(), wp.data(), wc.data(), wr.data(), wrem.data(), wsr.data(), wsc.data()};
+    trk_lsap([&](int i, int j) { return cost[(size_t)i * nt + j]; }, nd, nt, match, W);
 }
 
 // stage 5: tracks [n][STRIDE] (in place), pnp_rows [n][40] or null, recs [n][9][5]

@@ -207,8 +207,9 @@ def test_tracker_logic_matches_python_loop_with_pnp(host, monkeypatch):
     assert n_checked >= 8
 
 
-def test_tracker_logic_random_scenarios_vs_python_tracker(host):
-    """Crowded random videos (objects crossing, leaving, re-entering, weak detections, same-frame births and deaths) through
+@pytest.mark.parametrize("hungarian", [False, True])
+def test_tracker_logic_random_scenarios_vs_python_tracker(host, hungarian):
+    """(greedy, and the Hungarian association of tracker.py:154-174 whose Python side solves with scipy.)  Crowded random videos (objects crossing, leaving, re-entering, weak detections, same-frame births and deaths) through
     the harness and through the reference-pinned Python ``Tracker`` (greedy, Kalman + scale pool, no PnP): identical ids,
     ages, activity and filter read-outs in every frame -- association order, coasting up to max_age, the new-track
     threshold and the float32 cost arithmetic included."""
@@ -224,12 +225,12 @@ def test_tracker_logic_random_scenarios_vs_python_tracker(host):
         base = rng.uniform(60, 450, (n_obj, 2))
         vel = rng.uniform(-9, 9, (n_obj, 2))
         size = rng.uniform(25, 80, n_obj)
-        o = Opt(False)
+        o = Opt(hungarian)
         py = Tracker(o)
         py.init_track({"id": 0})
         P = Params(new_thresh=o.new_thresh, pre_thresh=0.3, R=o.R, conf_lo=3, conf_hi=9, max_age=o.max_age, kalman=1,
                    scale_pool=1, use_pnp=0, hps_uncertainty=1, show_axes=0, cat_rule=0, render_hm_mode=1, render_hmhp_mode=2,
-                   pre_hm=1, pre_hm_hp=1, K=100)
+                   pre_hm=1, pre_hm_hp=1, K=100, hungarian=int(hungarian))
         vm = np.zeros(16)
         vm[[0, 4]] = 1.0
         vm[6:10] = 512
@@ -293,3 +294,73 @@ def test_tracker_logic_truncates_and_reports_overflow(host):
     kept = sorted(float(v) for v in nxt[:, TR["POST"] + 0])       # field 0 of the post record = score
     want = sorted(float(d["score"]) for d in strong)[1:]          # the weakest of the strong detections is the one dropped
     np.testing.assert_allclose(kept, want, rtol=1e-6)
+
+
+def test_assignment_equals_scipy_linear_sum_assignment(host):
+    """trk_lsap (track_common.h, compiled for the host) against scipy.optimize.linear_sum_assignment -- the solver the
+    Hungarian goldens come from (sklearn 0.22's linear_assignment, which the reference imports, is absent; both return the
+    optimum).  Same pairs, not just the same cost: continuous costs, tie-heavy small integers, constant matrices, tall and wide
+    shapes, and the tracker's own pattern (float32 distances + 1e18 for forbidden pairs, clamped), where the duals swallow the
+    low bits of the real costs and only the same operations in the same order reproduce scipy's choice."""
+    from scipy.optimize import linear_sum_assignment
+
+    host.cp_track_host_lsap.restype = None
+    rng = np.random.RandomState(11)
+    n_cases = 0
+    for trial in range(1500):
+        nd, nt = int(rng.randint(1, 14)), int(rng.randint(1, 14))
+        kind = trial % 5
+        if kind == 0:
+            c = rng.rand(nd, nt) * 100.0
+        elif kind == 1:
+            c = rng.randint(0, 4, (nd, nt)).astype(np.float64)            # many ties
+        elif kind == 2:
+            c = np.full((nd, nt), float(rng.randint(0, 3)))                  # constant: scipy returns the identity pattern
+        else:  # the tracker's matrix: squared float32 distances, forbidden pairs at exactly 1e18
+            d32 = (rng.rand(nd, nt) * (2000.0 if kind == 3 else 90.0)).astype(np.float32)
+            bad = rng.rand(nd, nt) < (0.6 if kind == 3 else 0.3)
+            c = d32 + bad * 1e18
+            c[c > 1e18] = 1e18
+        c = np.ascontiguousarray(c, np.float64)
+        r, col = linear_sum_assignment(c)
+        want = -np.ones(nd, np.int32)
+        want[r] = col
+        got = np.zeros(nd, np.int32)
+        host.cp_track_host_lsap(_ptr(c), nd, nt, _ptr(got))
+        assert np.array_equal(got, want), (trial, kind, nd, nt, got.tolist(), want.tolist())
+        n_cases += 1
+    # a few large ones (the device's upper sizes: 100 detections x 128 tracks)
+    for nd, nt in ((100, 128), (128, 100), (128, 128)):
+        d32 = (rng.rand(nd, nt) * 5000.0).astype(np.float32)
+        c = np.ascontiguousarray(d32 + (rng.rand(nd, nt) < 0.9) * 1e18)
+        c[c > 1e18] = 1e18
+        r, col = linear_sum_assignment(c)
+        want = -np.ones(nd, np.int32)
+        want[r] = col
+        got = np.zeros(nd, np.int32)
+        host.cp_track_host_lsap(_ptr(c), nd, nt, _ptr(got))
+        assert np.array_equal(got, want), (nd, nt)
+    assert n_cases == 1500
+
+
+def test_tracker_logic_hungarian_matches_reference_golden(host):
+    """The Hungarian mode of Tracker.step (tracker.py:154-174) against the reference's own run (tracker_ref.json["hungarian"],
+    generated by the reference class with scipy's solver behind its linear_assignment import)."""
+    with open(os.path.join(GOLD, "tracker_ref.json")) as f:
+        gold = json.load(f)["hungarian"]
+    o = mg.TrackOpt(True)
+    P = Params(new_thresh=o.new_thresh, pre_thresh=0.3, R=o.R, conf_lo=3, conf_hi=9, max_age=o.max_age, kalman=1,
+               scale_pool=1, use_pnp=0, hps_uncertainty=1, show_axes=0, cat_rule=0, render_hm_mode=1, render_hmhp_mode=2,
+               pre_hm=1, pre_hm_hp=1, K=100, hungarian=1)
+    vm = np.zeros(16)
+    vm[[0, 4]] = 1.0
+    vm[6:10] = 512
+    ht = HostTracker(host, P, vm)
+    for f, dets in enumerate(mg.tracker_frames()):
+        post = np.stack([_post_from_dict(d, True) for d in dets])
+        tracks, _ = ht.step(post)
+        assert len(tracks) == len(gold[f]), f
+        for t, g in zip(tracks, gold[f]):
+            assert (int(t[0]), int(t[1]), int(t[2])) == (g["tracking_id"], g["age"], g["active"]), f
+            np.testing.assert_allclose(t[4 + 28:4 + 30], g["ct"], rtol=1e-12)
+            np.testing.assert_allclose(t[TR["MEAN_KF"]:TR["MEAN_KF"] + 16], g["kps_mean_kf"], rtol=1e-9, atol=1e-9)

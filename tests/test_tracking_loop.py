@@ -229,18 +229,20 @@ def test_batched_tracking_matches_reference_per_video(device, monkeypatch, devic
 
 
 @pytest.mark.gpu
-def test_device_tracker_matches_reference_tracker_golden(device):
+@pytest.mark.parametrize("mode", ["greedy", "hungarian"])
+def test_device_tracker_matches_reference_tracker_golden(device, mode):
     """cp_track_step alone (no PnP) on the seeded detections of tests/golden/tracker_ref.json -- the REFERENCE's own
-    Tracker.step: ids, ages, coasting, Kalman read-out and scale pool, for three videos that start one frame apart."""
+    Tracker.step: ids, ages, coasting, Kalman read-out and scale pool, for three videos that start one frame apart; greedy
+    association and (round 4) the Hungarian mode, whose device solver restates scipy's rectangular assignment."""
     from oracle.tools import make_goldens as mg
 
     with open(os.path.join(os.path.dirname(GOLD), "tracker_ref.json")) as fh:
-        gold = json.load(fh)["greedy"]
-    o = mg.TrackOpt(False)
+        gold = json.load(fh)[mode]
+    o = mg.TrackOpt(mode == "hungarian")
     B, K = 3, 100
     P = hip.TrackParams(new_thresh=o.new_thresh, pre_thresh=0.3, R=o.R, conf_lo=3, conf_hi=9, max_age=o.max_age, kalman=1,
                         scale_pool=1, use_pnp=0, hps_uncertainty=1, show_axes=0, cat_rule=0, render_hm_mode=1,
-                        render_hmhp_mode=2, pre_hm=1, pre_hm_hp=1, K=K, cap=hip.TRACK_CAP)
+                        render_hmhp_mode=2, pre_hm=1, pre_hm_hp=1, K=K, cap=hip.TRACK_CAP, hungarian=int(mode == "hungarian"))
     vm = np.zeros((B, 16))
     vm[:, [0, 4]] = 1.0
     vm[:, 6:10] = 512
