@@ -140,6 +140,9 @@ struct ConvParams {
     // applies the usual epilogue.
     int splitk;
     float* partial;
+    // tile of a split-K launch when it should be smaller than the default 128 x cp_conv_tile_n(Cout) (0 = default): the slab
+    // volume is slices x M x Cout x 4 bytes, and smaller tiles reach the same workgroup count with fewer slices
+    int tile_m, tile_n;
     // Fused prediction head (dlav1 heads: conv3x3 -> ReLU -> conv1x1, pose_dla_dcn.py head Sequential): the 3x3 tile
     // is multiplied by the 1x1 weights inside the kernel and only [slices = CoutPad/128][fuse_c2][M] partial sums of the
     // final maps are written (fuse_out); cp_launch_head_reduce adds the slices + bias (+ sigmoid) into NCHW.  The
@@ -180,7 +183,7 @@ int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream);
 // K steps (of 16 for the f32 kernels, 32 for f16x3) and output tiles of the launch cp_launch_conv[16] would make
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 37
+#define CP_NUM_CONV_VARIANTS 38
 #define CP_VARIANT_GRU 26
 // split-f16 ("f16x3") implicit GEMM (igemm16.hip)
 bool cp_conv16_supported(const ConvParams& p);
@@ -205,6 +208,7 @@ int cp_launch_dcn16p(const ConvParams& p, hipStream_t stream);
 // dcn16s.hip: the same gather as a persistent kernel with the halo streamed by LDS-DMA into two 16-channel buffers
 // (launches with several (patch, N tile) items per resident workgroup)
 #define CP_VARIANT_DCN16S 36
+#define CP_VARIANT_M64N64 37  // igemm16p on 64 x 64 tiles (small launches)
 bool cp_dcn16s_supported(const ConvParams& p);
 int cp_dcn16s_items(const ConvParams& p);
 int cp_launch_dcn16s(const ConvParams& p, hipStream_t stream);

@@ -954,7 +954,17 @@ struct Fwd {
         {
             int tiles = 0, nk = 0;
             cp_conv_geometry(p, use16, &tiles, &nk);
-            if (tiles > 0 && tiles < kSplitTiles && nk >= 8 && !p.gn_stats) {
+            // small launches of the f16x3 path run on 64 x 64 tiles (four times the workgroups per slice): a quarter of the
+            // slices and of the slab bytes (slices x M x Cout x 4) for the same workgroup count, and no split at all where that
+            // already gives kSplitTiles workgroups.  cp_set_debug 16: the 128-row tiles everywhere (A/B runs).
+            // Measured at B = 1 / 2 / 4 / 8 (profiles/NOTES.md): pays up to 32 tiles of 128 rows, up to 64 when K is short.
+            if (use16 && tiles > 0 && (tiles <= 32 || (tiles <= 64 && nk <= 36)) && nk >= 8 && !p.gn_stats && !offmask && !p.gn_in_a &&
+                p.CoutPad % 64 == 0 && w.Cout >= 64 && !(g_dbg & 16)) {
+                p.tile_m = p.tile_n = 64;
+                cp_conv_geometry(p, use16, &tiles, &nk);
+            }
+            // (64 x 64 tiles are a quarter of the work each: they are still cut along K below one workgroup per CU)
+            if (tiles > 0 && tiles < (p.tile_m == 64 ? 256 : kSplitTiles) && nk >= 8 && !p.gn_stats) {
                 int want = (kSplitTarget + tiles - 1) / tiles;
                 if (want > nk / 2) want = nk / 2;
                 if (want > 32) want = 32;
@@ -1702,7 +1712,7 @@ int cp_model_detect(cp_model* m, cp_stream_t stream, int B, int H, int W, const 
     std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)H, (uint64_t)W, (uint64_t)images, (uint64_t)pre_img,
                                  (uint64_t)pre_hm, (uint64_t)pre_hm_hp, (uint64_t)K, (uint64_t)rep_mode,
                                  (uint64_t)fit_gaussian, (uint64_t)legacy_bool_mask, (uint64_t)det, (uint64_t)workspace,
-                                 (uint64_t)m->precision, (uint64_t)(balance * 1e6f), (uint64_t)s};
+                                 (uint64_t)m->precision, (uint64_t)(balance * 1e6f), (uint64_t)s, (uint64_t)(unsigned)g_dbg};
     for (size_t i = 0; i < m->headw.size(); ++i) key.push_back((uint64_t)head_out[i]);
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {

@@ -384,14 +384,15 @@ const char* cp_conv_variant_name(int v) {
         "igemm16_cat_f16x3_m128n128", "igemm16_head_f16x3_m128n128",
         "lowc_stem7x7_f16x3", "lowc_3x3_c16_f16x3", "lowc_3x3s2_c16_f16x3", "igemm16_gru_f16x3_m128n96",
         "halo16_f16x3_m128n32", "halo16_f16x3_m128n64", "halo16_f16x3_m128n128", "dcn16p_f16x3_p128n64", "gn_final_f32_valu", "halo16_head_f16x3_m128n128",
-        "halo16_gru_f16x3_m128n96", "pw16_f16x3_m128n64", "pw16_f16x3_m128n128", "dcn16s_f16x3_p128n64"};
+        "halo16_gru_f16x3_m128n96", "pw16_f16x3_m128n64", "pw16_f16x3_m128n128", "dcn16s_f16x3_p128n64", "igemm16_f16x3_m64n64"};
     return (v >= 0 && v < CP_NUM_CONV_VARIANTS) ? names[v] : "?";
 }
 
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk) {
     int bn = cp_conv_tile_n(p.Cout);
     if (f16x3 && bn < 32) bn = 32;
-    const int bm = f16x3 ? 128 : (bn <= 32 ? 256 : 128);
+    if (f16x3 && p.tile_n && p.tile_n < bn && p.CoutPad % p.tile_n == 0 && !p.offmask) bn = p.tile_n;
+    const int bm = f16x3 ? ((bn == 64 && p.tile_m == 64 && !p.offmask) ? 64 : 128) : (bn <= 32 ? 256 : 128);
     const int M = p.B * p.Ho * p.Wo;
     *tiles = ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn);
     *nk = f16x3 ? p.Kpad16 / 32 : p.Kpad / BK;

@@ -999,6 +999,7 @@ int cp_launch_absmax(const float* x, size_t n, unsigned* slot, hipStream_t s) {
 // (the GroupNorm'd final 1x1 heads) take the 32-wide tile
 static int conv16_tile_n(const ConvParams& p) {
     const int bn = cp_conv_tile_n(p.Cout);
+    if (p.tile_n && p.tile_n < bn && p.CoutPad % p.tile_n == 0 && !p.offmask) return p.tile_n;
     return (bn < 32 && p.CoutPad >= 32 && p.CoutPad % 32 == 0) ? 32 : bn;
 }
 
@@ -1077,6 +1078,8 @@ int cp_launch_conv16(const ConvParams& p, hipStream_t stream) {
     // N 128 288 -> 290: with 64+ output channels the loop is bound by MFMA issue + fragment reads at the sustained
     // clock, not by the A-side loads / conversion the halo removes, so only the 32-wide tile uses it by default.
     // cp_set_debug: 4096 = never, 8192 = every eligible layer (A/B runs).
+    // small launches on 64 x 64 tiles (ConvParams::tile_m): the LDS-staged loop, whatever the layer shape
+    if (bn == 64 && p.tile_m == 64) return cat ? launch16<1, 1, 2, 2, false, true>(p, stream) : launch16<1, 1, 2, 2, false, false>(p, stream);
     if (halo16_wanted(p, bn)) return cp_launch_halo16(p, bn, stream);
     if (pw16_wanted(p)) return cp_launch_pw16(p, stream);
     if (bn == 128) return cat ? launch16<2, 2, 2, 2, false, true>(p, stream) : launch16<2, 2, 2, 2, false, false>(p, stream);
@@ -1089,6 +1092,7 @@ int cp_conv16_variant(const ConvParams& p) {
     const int bn = conv16_tile_n(p);
     if (p.offmask) return dcn16s_wanted(p) ? CP_VARIANT_DCN16S : dcn16p_wanted(p) ? CP_VARIANT_DCN16P : bn == 128 ? 18 : 17;
     const int t = bn == 32 ? 0 : bn == 64 ? 1 : 2;
+    if (bn == 64 && p.tile_m == 64) return CP_VARIANT_M64N64;
     if (halo16_wanted(p, bn)) return 27 + t;
     if (pw16_wanted(p)) return CP_VARIANT_PW16 + (p.CoutPad % 128 == 0 ? 1 : 0);
     return (p.nsrc > 1 ? 19 : 14) + t;
