@@ -160,6 +160,13 @@ struct ConvParams {
     int fuse_ngroups, fuse_gtiles;
     int fuse_gc2[CP_MAX_HEAD_GROUP];
     int fuse_gbase[CP_MAX_HEAD_GROUP];
+    // fuse_final (halo16 grouped launch, Cin == 64): a workgroup stages its patch once, walks all fuse_gtiles hidden tiles of
+    // its head and writes the finished maps -- sum of the tiles in index order + bias (+ sigmoid), NCHW, the arithmetic of
+    // head_reduce_grouped_kernel -- so neither the slabs nor the reduction launch exist.  fuse_out is then unused.
+    int fuse_final;
+    int fuse_gsig[CP_MAX_HEAD_GROUP];
+    const float* fuse_gbias[CP_MAX_HEAD_GROUP];
+    float* fuse_gout[CP_MAX_HEAD_GROUP];
     // ---- range-safe split-f16 arithmetic (f16x3 kernels) ----
     // Binary16 only has 5 exponent bits, so the hi/lo split is exact to 2^-21 only while the operand sits well inside
     // the normal range.  Both operands are therefore pre-scaled by exact powers of two: weights per output channel at

@@ -814,6 +814,8 @@ struct Fwd {
         p.fuse_ngroups = n;
         p.fuse_gtiles = g.hid / 128;
         p.fuse_out = (float*)0x1000;  // placeholder for the eligibility check
+        // the kernel walks a head's hidden tiles and writes the finished maps itself (cp_set_debug 1: slabs + reduction launch)
+        p.fuse_final = (g.Cin == 64 && !(g_dbg & 1)) ? 1 : 0;
         if (!cp_halo16_fused_head_supported(p)) return false;
         if (B * (x.H / 8) * (x.W / 16) * (p.CoutPad / 128) < kSplitTiles) return false;  // small maps: per-head split-K path
         HeadReduceGroup rg;
@@ -831,16 +833,20 @@ struct Fwd {
             rg.sigmoid[i] = sigmoid_hm && (hw.name == "hm" || hw.name == "hm_hp");
             rg.bias[i] = hw.c1.shift;
             rg.out[i] = m->dry ? nullptr : head_out[i];
+            p.fuse_gsig[i] = rg.sigmoid[i];
+            p.fuse_gbias[i] = rg.bias[i];
+            p.fuse_gout[i] = rg.out[i];
             flops += 2.0 * M * g.hid * (9.0 * g.Cin) + 2.0 * M * hw.classes * (double)g.hid;
             bytes += 4.0 * (M * hw.classes + 9.0 * g.Cin * g.hid + (double)g.hid * hw.classes);
         }
         bytes += 4.0 * M * g.Cin;  // the shared input is read once
-        Tensor slabs = make(planes, x.H, x.W);
+        Tensor slabs;
+        if (!p.fuse_final) slabs = make(planes, x.H, x.W);
         if (m->dry) return true;
-        p.fuse_out = slabs.ptr();
+        p.fuse_out = p.fuse_final ? nullptr : slabs.ptr();
         auto launch = [&]() -> int {
             int rc = cp_launch_halo16_fused_head(p, s);
-            if (rc == CP_OK) rc = cp_launch_head_reduce_grouped(slabs.ptr(), rg, B, x.H * x.W, s);
+            if (rc == CP_OK && !p.fuse_final) rc = cp_launch_head_reduce_grouped(slabs.ptr(), rg, B, x.H * x.W, s);
             return rc;
         };
         if (m->profile) {

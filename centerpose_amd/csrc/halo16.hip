@@ -51,6 +51,8 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
     __shared__ __attribute__((aligned(16))) _Float16 patch_hi[NPIX * PROW];
     __shared__ __attribute__((aligned(16))) _Float16 patch_lo[NPIX * PROW];
     __shared__ __attribute__((aligned(16))) _Float16 bt[BDIRECT ? 1 : 2][BDIRECT ? 8 : 2 * B_SZ];  // [buffer][hi | lo]
+    __shared__ float red_s[EPI == 1 ? 2 * 2 * 16 * 64 : 1];  // fused head: the second hidden half's partial maps [wm][i][r][lane]
+    __shared__ float sum_s[EPI == 1 ? 2 * 2 * 16 * 64 : 1];  // fuse_final: the maps summed over the tiles walked so far
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar register
@@ -66,7 +68,8 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
         // of the first grouped form), n-fastest over all heads cycled through 4.1 MB of weights per patch (3 % slower)
         const int bsel = (p.dbg >> 18) & 3;  // cp_set_debug bits 18-19 (A/B): band of 8 / 128 patches / the whole map
         const int HEAD_BAND = bsel == 0 ? 32 : bsel == 1 ? 8 : bsel == 2 ? 128 : tiles_m;
-        const int gt = p.fuse_gtiles, per_band = HEAD_BAND * tiles_n;
+        // fuse_final: one workgroup per (patch, head) -- tiles_n counts heads, tn becomes the head's first hidden tile below
+        const int gt = p.fuse_final ? 1 : p.fuse_gtiles, per_band = HEAD_BAND * tiles_n;
         const int band = tile / per_band, m0 = band * HEAD_BAND;
         const int bsz = min(HEAD_BAND, tiles_m - m0);  // patches in this band (the last one may be short)
         const int rem = tile - band * per_band;
@@ -74,6 +77,8 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
         tn = g * gt + rr % gt;
         tm = m0 + rr / gt;
     }
+    const int ntl = (EPI == 1 && p.fuse_final) ? p.fuse_gtiles : 1;  // hidden tiles this workgroup walks
+    if (EPI == 1 && p.fuse_final) tn *= p.fuse_gtiles;
     const int txs = p.W / TW, tys = p.H / TH;
     const int tx0 = (tm % txs) * TW;
     tm /= txs;
@@ -120,13 +125,6 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
     };
 
     acc_t acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < F::NACC; ++r) acc[i][j][r] = 0.f;
-
     // ---- fragment geometry: row m of the tile = pixel (m / 16, m % 16); lane reads rows lcol + 32 i + 32 MT wm ----
     const int lrow = lane >> 5, lcol = lane & 31;
     int q0[MT];  // patch pixel of the fragment row at tap (0, 0)
@@ -158,224 +156,255 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
                 dbl[set][ks][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)bd_off[j], (g + ks) * 1024, 0);
             }
     };
-    if (BDIRECT) {  // the first K tiles in flight while the first patch is staged
-        issue_bd(0, 0, 0);
-        if (NSET == 3) issue_bd(1, 0, 1);
-    }
+    for (int t2 = 0; t2 < ntl; ++t2) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < F::NACC; ++r) acc[i][j][r] = 0.f;
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-        // first weight tile of the chunk in flight while the patch is staged
-        if (!BDIRECT) issue_b(((0 * p.Cin) + ch * CK) * 2);
-        if (ch > 0) __syncthreads();  // every wave is done reading the previous chunk's patch
-        // ---- stage the halo patch of this 64-channel chunk: float32 global -> hi / lo binary16 planes ----
-        // all loads of a round are issued before the first conversion: one HBM round trip per round instead of one per
-        // slot (the round size is what the register file leaves: 6 slots next to 128 accumulators' worth of state)
-        constexpr int SR = (BDIRECT || MT * NT >= 4) ? 6 : 12;
-        // the thread id is rebuilt per chunk (not held in a vector register across the K loop)
-        int lane_c = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        asm volatile("" : "+v"(lane_c));
-        const int tid_c = wid * 64 + lane_c, c4c = tid_c & 15;
+        if (BDIRECT) {  // the first K tiles in flight while the first patch is staged
+            if (t2 > 0) {
 #pragma unroll
-        for (int s0 = 0; s0 < ST; s0 += SR) {
-            float4 sv[SR];
-#pragma unroll
-            for (int s = 0; s < SR; ++s) {
-                const int q = (tid_c >> 4) + 16 * (s0 + s);
-                const int py = q / PW, px = q - py * PW;
-                const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
-                const bool in = q < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const unsigned off = in ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + ch * CK + c4c * 4) * 4u : OOB;
-                sv[s] = buf_ld4(r_x, off);
+                for (int j = 0; j < NT; ++j) bd_off[j] += (unsigned)((BN / 32) * G * 1024);
             }
-            if (!have_scale) {  // once per block, with the first round of staging loads already in flight
-                conv_in_scale_finish(p, amax_raw, &afwd, &ainv);
-                have_scale = true;
-            }
-#pragma unroll
-            for (int s = 0; s < SR; ++s) {
-                const int q = (tid_c >> 4) + 16 * (s0 + s);
-                if (q < NPIX) {
-                    const float4 v = sv[s];
-                    const Split2 h0 = split2(v.x * afwd, v.y * afwd), h1 = split2(v.z * afwd, v.w * afwd);
-                    const int col = ((((c4c >> 1) ^ pswz(q)) << 1) | (c4c & 1)) * 4;  // halfs
-                    *reinterpret_cast<u32x2*>(patch_hi + q * PROW + col) = u32x2{h0.hi, h1.hi};
-                    *reinterpret_cast<u32x2*>(patch_lo + q * PROW + col) = u32x2{h0.lo, h1.lo};
-                }
-            }
+            issue_bd(0, 0, 0);
+            if (NSET == 3) issue_bd(1, 0, 1);
         }
-        if (!BDIRECT) store_b(0);
-        __syncthreads();
-        // ---- 18 K tiles: (tap, 32-channel half) ----
-        auto k_tile = [&](int kt, const _Float16* Bh, const _Float16* Bl, const u32x4 (&fh)[2][NT], const u32x4 (&fl)[2][NT]) {
-            const int tap = kt >> 1, half = kt & 1;
-            const int kh = tap / 3, kw = tap - kh * 3;
-            const int dq = kh * PW + kw;
+
+        for (int ch = 0; ch < nchunks; ++ch) {
+            // first weight tile of the chunk in flight while the patch is staged
+            if (!BDIRECT) issue_b(((0 * p.Cin) + ch * CK) * 2);
+            if (t2 == 0) {  // (fuse_final: one chunk, staged once for all hidden tiles of the head)
+                if (ch > 0) __syncthreads();  // every wave is done reading the previous chunk's patch
+                // ---- stage the halo patch of this 64-channel chunk: float32 global -> hi / lo binary16 planes ----
+                // all loads of a round are issued before the first conversion: one HBM round trip per round instead of one per
+                // slot (the round size is what the register file leaves: 6 slots next to 128 accumulators' worth of state)
+                constexpr int SR = (BDIRECT || MT * NT >= 4) ? 6 : 12;
+                // the thread id is rebuilt per chunk (not held in a vector register across the K loop)
+                int lane_c = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                asm volatile("" : "+v"(lane_c));
+                const int tid_c = wid * 64 + lane_c, c4c = tid_c & 15;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                h8 ah[MT], al[MT], bh[NT], bl[NT];
-                const int c8 = half * 4 + ks * 2 + lrow;  // 16-byte chunk of the 64-channel pixel row
+                for (int s0 = 0; s0 < ST; s0 += SR) {
+                    float4 sv[SR];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int q = q0[i] + dq;
-                    const int o = q * PROW + ((c8 ^ pswz(q)) * 8);
-                    ah[i] = *reinterpret_cast<const h8*>(patch_hi + o);
-                    al[i] = *reinterpret_cast<const h8*>(patch_lo + o);
-                }
-                const int co = ((ks * 2 + lrow) ^ swz(lcol)) * 8;
+                    for (int s = 0; s < SR; ++s) {
+                        const int q = (tid_c >> 4) + 16 * (s0 + s);
+                        const int py = q / PW, px = q - py * PW;
+                        const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+                        const bool in = q < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                        const unsigned off = in ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + ch * CK + c4c * 4) * 4u : OOB;
+                        sv[s] = buf_ld4(r_x, off);
+                    }
+                    if (!have_scale) {  // once per block, with the first round of staging loads already in flight
+                        conv_in_scale_finish(p, amax_raw, &afwd, &ainv);
+                        have_scale = true;
+                    }
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if (BDIRECT) {
-                        bh[j] = *reinterpret_cast<const h8*>(&fh[ks][j]);
-                        bl[j] = *reinterpret_cast<const h8*>(&fl[ks][j]);
-                    } else {
-                        bh[j] = *reinterpret_cast<const h8*>(Bh + j * 32 * LDH + co);
-                        bl[j] = *reinterpret_cast<const h8*>(Bl + j * 32 * LDH + co);
+                    for (int s = 0; s < SR; ++s) {
+                        const int q = (tid_c >> 4) + 16 * (s0 + s);
+                        if (q < NPIX) {
+                            const float4 v = sv[s];
+                            const Split2 h0 = split2(v.x * afwd, v.y * afwd), h1 = split2(v.z * afwd, v.w * afwd);
+                            const int col = ((((c4c >> 1) ^ pswz(q)) << 1) | (c4c & 1)) * 4;  // halfs
+                            *reinterpret_cast<u32x2*>(patch_hi + q * PROW + col) = u32x2{h0.hi, h1.hi};
+                            *reinterpret_cast<u32x2*>(patch_lo + q * PROW + col) = u32x2{h0.lo, h1.lo};
+                        }
                     }
                 }
-                // (fused head: transposed product -- rows = output channels, columns = pixels)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = EPI == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0)
-                                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = EPI == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0)
-                                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = EPI == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0)
-                                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-            }
-        };
-        if (BDIRECT) {
-#pragma unroll
-            for (int kt = 0; kt < 18; ++kt) {
-                // (phase order pinned: the scheduler would otherwise sink the loads to just above their use)
-                // set (kt + NSET - 1) % NSET = (kt - 1) % NSET was consumed by the previous tile
-                issue_bd((kt + NSET - 1) % NSET, ch, kt + NSET - 1);
-                __builtin_amdgcn_sched_barrier(0);
-                k_tile(kt, nullptr, nullptr, dbh[kt % NSET], dbl[kt % NSET]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-#pragma unroll 2
-            for (int kt = 0; kt < 18; ++kt) {
-                const int cur = kt & 1;
-                if (kt + 1 < 18) {
-                    const int tap1 = (kt + 1) >> 1, half1 = (kt + 1) & 1;
-                    issue_b((tap1 * p.Cin + ch * CK + half1 * 32) * 2);
-                }
-                k_tile(kt, bt[cur] + b_frag, bt[cur] + b_frag + B_SZ, dbh[0], dbl[0]);
-                if (kt + 1 < 18) store_b(cur ^ 1);
+                if (!BDIRECT) store_b(0);
                 __syncthreads();
             }
-        }
-    }
-
-    // (the lane id is rebuilt here instead of living in a vector register across the K loop)
-    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if constexpr (EPI == 1) {
-        // ---- fused prediction head (the arithmetic of igemm16.hip's FUSE epilogue on this kernel's pixel order) ----
-        const int M = p.B * p.H * p.W;
-        // head of this N tile (several heads in one launch: ConvParams::fuse_ngroups), its channel count and first plane
-        const int hg = p.fuse_ngroups > 0 ? tn / p.fuse_gtiles : 0;
-        const int c2 = p.fuse_ngroups > 0 ? p.fuse_gc2[hg] : p.fuse_c2;
-        const int plane0 = p.fuse_ngroups > 0 ? p.fuse_gbase[hg] + (tn - hg * p.fuse_gtiles) * c2 : tn * p.fuse_c2;
-        const u32x4* w2h = reinterpret_cast<const u32x4*>(p.fuse_w2_hi) + (size_t)((tn * WN + wn) * 4) * 64 + lane_e;
-        const u32x4* w2l = reinterpret_cast<const u32x4*>(p.fuse_w2_lo) + (size_t)((tn * WN + wn) * 4) * 64 + lane_e;
-        h8 wh[2][2], wl[2][2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const u32x4 a = w2h[(j * 2 + ks) * 64], c = w2l[(j * 2 + ks) * 64];
-                wh[j][ks] = *reinterpret_cast<const h8*>(&a);
-                wl[j][ks] = *reinterpret_cast<const h8*>(&c);
-            }
-        acc_t acc2[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
-        const bool relu = p.act == CP_ACT_RELU;
-        float hmax = 0.f;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ch = tn * BN + wn * 64 + j * 32 + F::row(r, lane_e);
-                const float sc = (p.scale ? p.scale[ch] : 1.f) * ainv, sh = p.shift ? p.shift[ch] : 0.f;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    float x = acc[i][j][r] * sc + sh;
-                    if (relu) x = fmaxf(x, 0.f);
-                    acc[i][j][r] = x;
-                    hmax = fmaxf(hmax, fabsf(x));
-                }
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) hmax = fmaxf(hmax, __shfl_xor(hmax, o, 64));
-        float hfwd, hinv;
-        cp_amax_to_scale(__float_as_uint(hmax), &hfwd, &hinv);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            // ---- 18 K tiles: (tap, 32-channel half) ----
+            auto k_tile = [&](int kt, const _Float16* Bh, const _Float16* Bl, const u32x4 (&fh)[2][NT], const u32x4 (&fl)[2][NT]) {
+                const int tap = kt >> 1, half = kt & 1;
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const int dq = kh * PW + kw;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    uint32_t hh[4], hl[4];
+                    h8 ah[MT], al[MT], bh[NT], bl[NT];
+                    const int c8 = half * 4 + ks * 2 + lrow;  // 16-byte chunk of the 64-channel pixel row
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int r = ks * 8 + q * 2;
-                        const Split2 sp = split2(acc[i][j][r] * hfwd, acc[i][j][r + 1] * hfwd);
-                        hh[q] = sp.hi;
-                        hl[q] = sp.lo;
+                    for (int i = 0; i < MT; ++i) {
+                        const int q = q0[i] + dq;
+                        const int o = q * PROW + ((c8 ^ pswz(q)) * 8);
+                        ah[i] = *reinterpret_cast<const h8*>(patch_hi + o);
+                        al[i] = *reinterpret_cast<const h8*>(patch_lo + o);
                     }
-                    const u32x4 vh = {hh[0], hh[1], hh[2], hh[3]}, vl = {hl[0], hl[1], hl[2], hl[3]};
-                    const h8 bhh = *reinterpret_cast<const h8*>(&vh), bhl = *reinterpret_cast<const h8*>(&vl);
-                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j][ks], bhh, acc2[i], 0, 0, 0);
-                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j][ks], bhl, acc2[i], 0, 0, 0);
-                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j][ks], bhh, acc2[i], 0, 0, 0);
+                    const int co = ((ks * 2 + lrow) ^ swz(lcol)) * 8;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        if (BDIRECT) {
+                            bh[j] = *reinterpret_cast<const h8*>(&fh[ks][j]);
+                            bl[j] = *reinterpret_cast<const h8*>(&fl[ks][j]);
+                        } else {
+                            bh[j] = *reinterpret_cast<const h8*>(Bh + j * 32 * LDH + co);
+                            bl[j] = *reinterpret_cast<const h8*>(Bl + j * 32 * LDH + co);
+                        }
+                    }
+                    // (fused head: transposed product -- rows = output channels, columns = pixels)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = EPI == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = EPI == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = EPI == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+            };
+            if (BDIRECT) {
+#pragma unroll
+                for (int kt = 0; kt < 18; ++kt) {
+                    // (phase order pinned: the scheduler would otherwise sink the loads to just above their use)
+                    // set (kt + NSET - 1) % NSET = (kt - 1) % NSET was consumed by the previous tile
+                    issue_bd((kt + NSET - 1) % NSET, ch, kt + NSET - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    k_tile(kt, nullptr, nullptr, dbh[kt % NSET], dbl[kt % NSET]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll 2
+                for (int kt = 0; kt < 18; ++kt) {
+                    const int cur = kt & 1;
+                    if (kt + 1 < 18) {
+                        const int tap1 = (kt + 1) >> 1, half1 = (kt + 1) & 1;
+                        issue_b((tap1 * p.Cin + ch * CK + half1 * 32) * 2);
+                    }
+                    k_tile(kt, bt[cur] + b_frag, bt[cur] + b_frag + B_SZ, dbh[0], dbl[0]);
+                    if (kt + 1 < 18) store_b(cur ^ 1);
+                    __syncthreads();
                 }
             }
         }
-        __syncthreads();  // every wave is done with the patch planes
-        float* red = reinterpret_cast<float*>(patch_hi);  // [wm][i][r][lane]: 16 KB of the 23 KB plane
+
+        // (the lane id is rebuilt here instead of living in a vector register across the K loop)
+        const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if constexpr (EPI == 1) {
+            // ---- fused prediction head (the arithmetic of igemm16.hip's FUSE epilogue on this kernel's pixel order) ----
+            const int M = p.B * p.H * p.W;
+            // head of this N tile (several heads in one launch: ConvParams::fuse_ngroups), its channel count and first plane
+            const int hg = p.fuse_ngroups > 0 ? tn / p.fuse_gtiles : 0;
+            const int c2 = p.fuse_ngroups > 0 ? p.fuse_gc2[hg] : p.fuse_c2;
+            const int plane0 = p.fuse_ngroups > 0 ? p.fuse_gbase[hg] + (tn - hg * p.fuse_gtiles) * c2 : tn * p.fuse_c2;
+            const u32x4* w2h = reinterpret_cast<const u32x4*>(p.fuse_w2_hi) + (size_t)((tn * WN + wn) * 4) * 64 + lane_e;
+            const u32x4* w2l = reinterpret_cast<const u32x4*>(p.fuse_w2_lo) + (size_t)((tn * WN + wn) * 4) * 64 + lane_e;
+            h8 wh[2][2], wl[2][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float wi = (p.fuse_w2_inv ? p.fuse_w2_inv[hg * 64 + F::row(r, lane_e)] : 1.f) * hinv;
-            acc2[0][r] *= wi;
-            acc2[1][r] *= wi;
-        }
-        if (wn == 1) {
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const u32x4 a = w2h[(j * 2 + ks) * 64], c = w2l[(j * 2 + ks) * 64];
+                    wh[j][ks] = *reinterpret_cast<const h8*>(&a);
+                    wl[j][ks] = *reinterpret_cast<const h8*>(&c);
+                }
+            acc_t acc2[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[((wm * 2 + i) * 16 + r) * 64 + lane_e] = acc2[i][r];
-        }
-        __syncthreads();
-        if (wn == 0) {
+                for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
+            const bool relu = p.act == CP_ACT_RELU;
+            float hmax = 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ml = wm * 64 + i * 32 + (lane_e & 31);  // tile row -> patch pixel (ml / 16, ml % 16)
-                const int m = (b * p.H + ty0 + (ml >> 4)) * p.W + tx0 + (ml & 15);
+            for (int j = 0; j < 2; ++j) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int c = F::row(r, lane_e);
-                    const float v = acc2[i][r] + red[((wm * 2 + i) * 16 + r) * 64 + lane_e];
-                    if (c < c2) p.fuse_out[((size_t)plane0 + c) * M + m] = v;
+                    const int ch = tn * BN + wn * 64 + j * 32 + F::row(r, lane_e);
+                    const float sc = (p.scale ? p.scale[ch] : 1.f) * ainv, sh = p.shift ? p.shift[ch] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        float x = acc[i][j][r] * sc + sh;
+                        if (relu) x = fmaxf(x, 0.f);
+                        acc[i][j][r] = x;
+                        hmax = fmaxf(hmax, fabsf(x));
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) hmax = fmaxf(hmax, __shfl_xor(hmax, o, 64));
+            float hfwd, hinv;
+            cp_amax_to_scale(__float_as_uint(hmax), &hfwd, &hinv);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        uint32_t hh[4], hl[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int r = ks * 8 + q * 2;
+                            const Split2 sp = split2(acc[i][j][r] * hfwd, acc[i][j][r + 1] * hfwd);
+                            hh[q] = sp.hi;
+                            hl[q] = sp.lo;
+                        }
+                        const u32x4 vh = {hh[0], hh[1], hh[2], hh[3]}, vl = {hl[0], hl[1], hl[2], hl[3]};
+                        const h8 bhh = *reinterpret_cast<const h8*>(&vh), bhl = *reinterpret_cast<const h8*>(&vl);
+                        acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j][ks], bhh, acc2[i], 0, 0, 0);
+                        acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j][ks], bhl, acc2[i], 0, 0, 0);
+                        acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j][ks], bhh, acc2[i], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();  // the previous tile's partial maps have been read
+            float* red = red_s;  // [wm][i][r][lane]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float wi = (p.fuse_w2_inv ? p.fuse_w2_inv[hg * 64 + F::row(r, lane_e)] : 1.f) * hinv;
+                acc2[0][r] *= wi;
+                acc2[1][r] *= wi;
+            }
+            if (wn == 1) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((wm * 2 + i) * 16 + r) * 64 + lane_e] = acc2[i][r];
+            }
+            __syncthreads();
+            if (wn == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ml = wm * 64 + i * 32 + (lane_e & 31);  // tile row -> patch pixel (ml / 16, ml % 16)
+                    const int m = (b * p.H + ty0 + (ml >> 4)) * p.W + tx0 + (ml & 15);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = F::row(r, lane_e);
+                        const float v = acc2[i][r] + red[((wm * 2 + i) * 16 + r) * 64 + lane_e];
+                        if (!p.fuse_final) {
+                            if (c < c2) p.fuse_out[((size_t)plane0 + c) * M + m] = v;
+                            continue;
+                        }
+                        // head_reduce_grouped_kernel's arithmetic: tiles summed in index order from 0, + bias, sigmoid
+                        // (the running sum lives in LDS, each lane its own word: 32 registers less across the K loop)
+                        float* run = sum_s + ((wm * 2 + i) * 16 + r) * 64 + lane_e;
+                        const float vs = (t2 == 0 ? 0.f : *run) + v;
+                        if (t2 + 1 < ntl) *run = vs;
+                        else if (c < c2) {
+                            float y = vs + (p.fuse_gbias[hg] ? p.fuse_gbias[hg][c] : 0.f);
+                            if (p.fuse_gsig[hg]) y = 1.f / (1.f + expf(-y));
+                            const int HW = p.H * p.W, pix = (ty0 + (ml >> 4)) * p.W + tx0 + (ml & 15);
+                            p.fuse_gout[hg][((size_t)b * c2 + c) * HW + pix] = y;
+                        }
+                    }
                 }
             }
         }
-        return;
-    }
+        if (EPI == 1) ++tn;
+    }  // hidden tiles
+    if constexpr (EPI == 1) return;
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     if constexpr (EPI == 2) {
         // ---- fused ConvGRU gates (igemm16.hip's GRU epilogue): r = sig(x_r + h_r); z = sig(x_z + h_z);
         //      n = tanh(x_n + r * h_n); h' = (1 - z) * n + z * h   (convGRU.py:32-39) ----
@@ -419,7 +448,8 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
 template <int MT, int NT, int WM, int WN, bool BDIRECT = false, int EPI = 0>
 int launch_halo(const ConvParams& p, hipStream_t stream) {
     constexpr int BN = 32 * NT * WN;
-    const int tiles_m = p.B * (p.H / TH) * (p.W / TW), tiles_n = p.CoutPad / BN;
+    // (fused heads that finish in the kernel: one workgroup per patch and head, ConvParams::fuse_final)
+    const int tiles_m = p.B * (p.H / TH) * (p.W / TW), tiles_n = (EPI == 1 && p.fuse_final) ? p.fuse_ngroups : p.CoutPad / BN;
     hipLaunchKernelGGL((halo16_kernel<MT, NT, WM, WN, BDIRECT, EPI>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p,
                        tiles_m, tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
@@ -456,7 +486,8 @@ static bool halo16_fused_geometry(const ConvParams& p) {
 
 // fused prediction head on the halo-resident kernel (same operands as cp_launch_conv16_fused_head)
 bool cp_halo16_fused_head_supported(const ConvParams& p) {
-    return halo16_fused_geometry(p) && p.CoutPad % 128 == 0 && p.fuse_w2_hi && p.fuse_w2_lo && p.fuse_out;
+    if (p.fuse_final && (p.fuse_ngroups < 1 || p.Cin != CK || p.CoutPad != p.fuse_ngroups * p.fuse_gtiles * 128)) return false;
+    return halo16_fused_geometry(p) && p.CoutPad % 128 == 0 && p.fuse_w2_hi && p.fuse_w2_lo && (p.fuse_out || p.fuse_final);
 }
 int cp_launch_halo16_fused_head(const ConvParams& p, hipStream_t stream) {
     if (!cp_halo16_fused_head_supported(p)) return CP_ERR_INVALID;

@@ -515,21 +515,24 @@ def test_backbone_at_bench_batch_spot_parity(device, arch, B, pick):
 @pytest.mark.parametrize("arch,B,hw", [("dla_34", 2, 256), ("hourglass", 1, 512), ("dla_34", 1, 512)])
 def test_grouped_fused_heads_equal_per_head_launches(device, arch, B, hw):
     """All fused prediction heads in ONE launch (engine.hip: fused_heads_grouped; concatenated operands, per-tile head
-    table) against one launch per head (cp_set_debug 16777216): the same kernel arithmetic tile by tile -> bit-identical
-    head tensors, sigmoid included."""
+    table; a workgroup walks the hidden tiles of its head and finishes the maps) against one launch per head and against the
+    slab + reduction-launch form: the same arithmetic in the same order -> bit-identical head tensors, sigmoid included."""
     heads = synth.HEADS_POSE
     sd = synth.make_state_dict(arch, heads)
     x = synth.frames(B, seed=77, h=hw, w=hw).to(device)
     model = hip.HipModel(arch, heads, sd, precision="f16x3")
     z = {k: v.clone() for k, v in model(x, sigmoid_hm=True).items()}
-    hip.lib().cp_set_debug(16777216)
-    try:
-        z1 = {k: v.clone() for k, v in model(x, sigmoid_hm=True).items()}
-    finally:
-        hip.lib().cp_set_debug(0)
-    for k in heads:
-        assert torch.isfinite(z[k]).all(), k
-        assert torch.equal(z[k], z1[k]), (k, float((z[k] - z1[k]).abs().max()))
+    # 16777216: one launch per head; 1: one grouped launch that writes per-tile slabs + the reduction launch (the default
+    # grouped launch walks a head's hidden tiles in one workgroup and writes the finished maps itself)
+    for dbg in (16777216, 1):
+        hip.lib().cp_set_debug(dbg)
+        try:
+            z1 = {k: v.clone() for k, v in model(x, sigmoid_hm=True).items()}
+        finally:
+            hip.lib().cp_set_debug(0)
+        for k in heads:
+            assert torch.isfinite(z[k]).all(), k
+            assert torch.equal(z[k], z1[k]), (dbg, k, float((z[k] - z1[k]).abs().max()))
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
