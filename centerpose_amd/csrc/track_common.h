@@ -85,7 +85,7 @@ struct TrackParams {
     int render_hm_mode, render_hmhp_mode, pre_hm, pre_hm_hp;
     int K, cap;
     int hungarian;  // association by optimal assignment (tracker.py:154-170) instead of the greedy walk
-    int pad_;
+    int baseline;   // Tracker_baseline (--refined_Kalman, utils/tracker_baseline.py): position-only filter, plain scale average
 };
 
 // per video: trans_input (2 x 3, row-major) | width height inp_w inp_h | fx fy cx cy
@@ -214,9 +214,10 @@ CP_HD void trk_quat_to_matrix(const double* q, double* R) {  // scipy Rotation.f
 // Writes location / quaternion / projected_cuboid / kps_3d_cam / kps_pnp into `t` (the reference sets them before its
 // visibility rejects) and kps_ori into `ori`; returns 1 when the detection survives the rejects.
 CP_HD int trk_finish(const TrackParams& P, const double* vm, const double* row, const double* scale3, const double* kps16,
-                     double* t, double* ori) {
-    const double* loc = P.show_axes ? row + 4 : row + 28;
-    const double* quat = P.show_axes ? row + 24 : row + 31;
+                     double* t, double* ori, int opencv_frame) {
+    // OPENCV_RETURN of pnp_shell: opt.show_axes, except for Tracker_baseline's filtered PnP (default frame, :276)
+    const double* loc = opencv_frame ? row + 4 : row + 28;
+    const double* quat = opencv_frame ? row + 24 : row + 31;
     for (int i = 0; i < 3; ++i) t[TR_LOC + i] = loc[i];
     for (int i = 0; i < 4; ++i) t[TR_QUAT + i] = quat[i];
     for (int i = 0; i < 16; ++i) t[TR_PROJ + i] = row[8 + i];
@@ -323,7 +324,76 @@ CP_HD void trk_obs(const TrackParams& P, const double* t, int v, double* z, doub
     r[2] = r[3] = P.R;
 }
 
+CP_HD void m2_inv(const double* A, double* X) {  // the same elimination on a 2 x 2 block
+    double a[2][4] = {{A[0], A[1], 1.0, 0.0}, {A[2], A[3], 0.0, 1.0}};
+    for (int c = 0; c < 2; ++c) {
+        const int piv = (c == 0 && fabs(a[1][0]) > fabs(a[0][0])) ? 1 : c;
+        if (piv != c)
+            for (int j = 0; j < 4; ++j) { const double tmp = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = tmp; }
+        const double inv = 1.0 / a[c][c];
+        for (int j = 0; j < 4; ++j) a[c][j] *= inv;
+        const int r = 1 - c;
+        const double f = a[r][c];
+        if (f != 0.0)
+            for (int j = 0; j < 4; ++j) a[r][j] -= f * a[c][j];
+    }
+    X[0] = a[0][2]; X[1] = a[0][3]; X[2] = a[1][2]; X[3] = a[1][3];
+}
+
+// Tracker_baseline.init_kf (tracker_baseline.py:54-78): only (x, y) observed; x = (mean_x, mean_y, 0, 0); P = I with its
+// position block set to [[vx, vy], [vx, vy]] (the reference assigns a 2-vector to the 2 x 2 block, which broadcasts over rows)
+CP_HD void trk_kf_init_base(double* t) {
+    for (int v = 0; v < 8; ++v) {
+        const double sx = t[TR_FUS_STD + 2 * v], sy = t[TR_FUS_STD + 2 * v + 1];
+        double* Pb = t + TR_KF_P + 16 * v;
+        for (int i = 0; i < 16; ++i) Pb[i] = 0.0;
+        for (int i = 0; i < 4; ++i) Pb[5 * i] = 1.0;
+        Pb[0] = sx * sx; Pb[1] = sy * sy;
+        Pb[4] = sx * sx; Pb[5] = sy * sy;
+        t[TR_KF_X + 4 * v] = t[TR_FUS_MEAN + 2 * v];
+        t[TR_KF_X + 4 * v + 1] = t[TR_FUS_MEAN + 2 * v + 1];
+        t[TR_KF_X + 4 * v + 2] = t[TR_KF_X + 4 * v + 3] = 0.0;
+    }
+}
+
+// Tracker_baseline: predict() then update(z, R) with H = [I2 0] (tracker_baseline.py:80-92; filterpy's Joseph form):
+// y = z - H x, S = H P H^T + R, K = P H^T S^-1, x += K y, P = (I - K H) P (I - K H)^T + K R K^T
+CP_HD void trk_kf_step_base(double* t) {
+    const double F[16] = {1, 0, 1, 0, 0, 1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (int v = 0; v < 8; ++v) {
+        double* x = t + TR_KF_X + 4 * v;
+        double* Pb = t + TR_KF_P + 16 * v;
+        double xp[4], T[16], Pp[16];
+        const double z[2] = {t[TR_FUS_MEAN + 2 * v], t[TR_FUS_MEAN + 2 * v + 1]};
+        const double sx = t[TR_FUS_STD + 2 * v], sy = t[TR_FUS_STD + 2 * v + 1];
+        const double r[2] = {sx * sx, sy * sy};
+        for (int i = 0; i < 4; ++i) {
+            double s = 0;
+            for (int k = 0; k < 4; ++k) s += F[4 * i + k] * x[k];
+            xp[i] = s;
+        }
+        m4_mul(F, Pb, T);
+        m4_mul_bt(T, F, Pp);
+        for (int i = 0; i < 4; ++i) Pp[5 * i] += 1.0;
+        const double S[4] = {Pp[0] + r[0], Pp[1], Pp[4], Pp[5] + r[1]};
+        double Si[4], Kg[8];  // K: 4 x 2 = (P H^T) S^-1, P H^T = the first two columns of P
+        m2_inv(S, Si);
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 2; ++j) Kg[2 * i + j] = Pp[4 * i] * Si[j] + Pp[4 * i + 1] * Si[2 + j];
+        const double y0 = z[0] - xp[0], y1 = z[1] - xp[1];
+        for (int i = 0; i < 4; ++i) x[i] = xp[i] + (Kg[2 * i] * y0 + Kg[2 * i + 1] * y1);
+        double IK[16], A[16], B[16];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) IK[4 * i + j] = (i == j ? 1.0 : 0.0) - (j < 2 ? Kg[2 * i + j] : 0.0);
+        m4_mul(IK, Pp, A);
+        m4_mul_bt(A, IK, B);
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) Pb[4 * i + j] = B[4 * i + j] + (Kg[2 * i] * r[0] * Kg[2 * j] + Kg[2 * i + 1] * r[1] * Kg[2 * j + 1]);
+    }
+}
+
 CP_HD void trk_kf_init(const TrackParams& P, double* t) {  // init_kf: x = observation, P = R
+    if (P.baseline) { trk_kf_init_base(t); return; }
     for (int v = 0; v < 8; ++v) {
         double z[4], r[4];
         trk_obs(P, t, v, z, r);
@@ -338,6 +408,7 @@ CP_HD void trk_kf_init(const TrackParams& P, double* t) {  // init_kf: x = obser
 
 // filterpy predict() then update(z, R) on the state in `t` (already holding the previous frame's x and P)
 CP_HD void trk_kf_step(const TrackParams& P, double* t) {
+    if (P.baseline) { trk_kf_step_base(t); return; }
     const double F[16] = {1, 0, 1, 0, 0, 1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1};
     for (int v = 0; v < 8; ++v) {
         double* x = t + TR_KF_X + 4 * v;
@@ -377,10 +448,10 @@ CP_HD void trk_kf_step(const TrackParams& P, double* t) {
 
 // scale pool (tracker.py:98-110): one more (mean, uncertainty) sample; the running sums equal the reference's re-summation
 // of its list in the same order
-CP_HD void trk_pool_add(double* t) {
+CP_HD void trk_pool_add(const TrackParams& P, double* t) {
     for (int i = 0; i < 3; ++i) {
         const double u = t[TR_POST + PO_SCALE_UNC + i];
-        const double w = 1.0 / (u * u);
+        const double w = P.baseline ? 1.0 : 1.0 / (u * u);  // Tracker_baseline: a plain average (tracker_baseline.py:94-101)
         t[TR_POOL_PREC + i] += w;
         t[TR_POOL_ACC + i] += w * t[TR_POST + PO_SCALE + i];
     }
@@ -398,7 +469,14 @@ CP_HD double trk_conf(const TrackParams& P, double comb) {  // tracker.py:254-26
 CP_HD void trk_readout(const TrackParams& P, double* t, double* pts16, double* scale3) {
     if (P.kalman) {
         for (int v = 0; v < 8; ++v) {
-            const double vx = t[TR_KF_P + 16 * v + 0], vy = t[TR_KF_P + 16 * v + 5];
+            double vx = t[TR_KF_P + 16 * v + 0], vy = t[TR_KF_P + 16 * v + 5];
+            if (P.baseline) {
+                // the reference reads P[2v, 2v] and P[2v+1, 2v+1] of the 32 x 32 matrix here (tracker_baseline.py:251-254):
+                // diagonal entries 2v, 2v+1 -- position variances of vertex v/2 for even v, velocity variances for odd v
+                const int k0 = 2 * v, k1 = 2 * v + 1;
+                vx = t[TR_KF_P + 16 * (k0 >> 2) + 5 * (k0 & 3)];
+                vy = t[TR_KF_P + 16 * (k1 >> 2) + 5 * (k1 & 3)];
+            }
             t[TR_MEAN_KF + 2 * v] = t[TR_KF_X + 4 * v];
             t[TR_MEAN_KF + 2 * v + 1] = t[TR_KF_X + 4 * v + 1];
             t[TR_STD_KF + 2 * v] = sqrt(vx);
@@ -414,9 +492,14 @@ CP_HD void trk_readout(const TrackParams& P, double* t, double* pts16, double* s
     }
     if (P.scale_pool) {
         for (int i = 0; i < 3; ++i) {
-            const double std = 1.0 / sqrt(t[TR_POOL_PREC + i]);
-            t[TR_SCALE_KF + i] = t[TR_POOL_ACC + i] * (std * std);
-            t[TR_SCALE_UNC_KF + i] = std;
+            if (P.baseline) {  // mean of the samples, placeholder uncertainty (tracker_baseline.py:97-101, :269)
+                t[TR_SCALE_KF + i] = t[TR_POOL_ACC + i] / t[TR_POOL_N];
+                t[TR_SCALE_UNC_KF + i] = 0.0;
+            } else {
+                const double std = 1.0 / sqrt(t[TR_POOL_PREC + i]);
+                t[TR_SCALE_KF + i] = t[TR_POOL_ACC + i] * (std * std);
+                t[TR_SCALE_UNC_KF + i] = std;
+            }
             scale3[i] = t[TR_SCALE_KF + i];
         }
     } else {
@@ -564,17 +647,36 @@ CP_HD int trk_associate(const TrackParams& P, const double* dets, const int* use
     int nd = 0;
     for (int k = 0; k < nd_all; ++k)
         if (use[k]) det_idx[nd++] = k;
+    // centres compared (float32 arrays in the reference).  Tracker: detection centre moved by its tracking offset against the
+    // track's centre (tracker.py:130, :143); Tracker_baseline: the raw detection centre against the track's centre moved by the
+    // mean filtered velocity of its eight vertices (tracker_baseline.py:121, :134-140; float64 sum, then the float32 array)
+    auto det_centre = [&](const double* d, float* cx, float* cy) {
+        if (P.baseline) { *cx = f32(d[TR_POST + PO_CT]); *cy = f32(d[TR_POST + PO_CT + 1]); }
+        else {
+            *cx = f32(d[TR_POST + PO_CT] + d[TR_POST + PO_TRACKING]);
+            *cy = f32(d[TR_POST + PO_CT + 1] + d[TR_POST + PO_TRACKING + 1]);
+        }
+    };
+    auto trk_centre = [&](const double* tr, float* cx, float* cy) {
+        if (P.baseline) {
+            double vx = 0, vy = 0;
+            for (int i = 0; i < 8; ++i) { vx += tr[TR_KF_X + 4 * i + 2]; vy += tr[TR_KF_X + 4 * i + 3]; }
+            *cx = f32((double)f32(tr[TR_POST + PO_CT]) + vx / 8);
+            *cy = f32((double)f32(tr[TR_POST + PO_CT + 1]) + vy / 8);
+        } else { *cx = f32(tr[TR_POST + PO_CT]); *cy = f32(tr[TR_POST + PO_CT + 1]); }
+    };
     for (int t = 0; t < np; ++t) taken[t] = 0;
     if (P.hungarian && lsap) {
         // ---- optimal assignment over the same cost matrix (:130-157), forbidden pairs undone afterwards (:167-174) ----
         auto cost = [&](int i, int t) -> double {
             const double* d = dets + (long long)det_idx[i] * CP_TRACK_STRIDE;
             const double* tr = prev + (long long)t * CP_TRACK_STRIDE;
-            const float dcx = f32(d[TR_POST + PO_CT] + d[TR_POST + PO_TRACKING]);
-            const float dcy = f32(d[TR_POST + PO_CT + 1] + d[TR_POST + PO_TRACKING + 1]);
+            float dcx, dcy, tcx, tcy;
+            det_centre(d, &dcx, &dcy);
+            trk_centre(tr, &tcx, &tcy);
             const float darea = f32((d[TR_POST + PO_BBOX + 2] - d[TR_POST + PO_BBOX]) *
                                     (d[TR_POST + PO_BBOX + 3] - d[TR_POST + PO_BBOX + 1]));
-            const float ex = f32(tr[TR_POST + PO_CT]) - dcx, ey = f32(tr[TR_POST + PO_CT + 1]) - dcy;
+            const float ex = tcx - dcx, ey = tcy - dcy;
             const float ex2 = ex * ex, ey2 = ey * ey;
             const float c32 = ex2 + ey2;
             const float tarea = f32((tr[TR_POST + PO_BBOX + 2] - tr[TR_POST + PO_BBOX]) *
@@ -600,8 +702,8 @@ CP_HD int trk_associate(const TrackParams& P, const double* dets, const int* use
     // ---- greedy: detections in order, each takes its nearest still-free admissible track (:305-314) ----
     for (int i = 0; i < nd; ++i) {
         const double* d = dets + (long long)det_idx[i] * CP_TRACK_STRIDE;
-        const float dcx = f32(d[TR_POST + PO_CT] + d[TR_POST + PO_TRACKING]);
-        const float dcy = f32(d[TR_POST + PO_CT + 1] + d[TR_POST + PO_TRACKING + 1]);
+        float dcx, dcy;
+        det_centre(d, &dcx, &dcy);
         const float darea = f32((d[TR_POST + PO_BBOX + 2] - d[TR_POST + PO_BBOX]) *
                                 (d[TR_POST + PO_BBOX + 3] - d[TR_POST + PO_BBOX + 1]));
         const int dcls = (int)d[TR_POST + PO_CLS];
@@ -609,7 +711,9 @@ CP_HD int trk_associate(const TrackParams& P, const double* dets, const int* use
         double bestc = 0;
         for (int t = 0; t < np; ++t) {
             const double* tr = prev + (long long)t * CP_TRACK_STRIDE;
-            const float ex = f32(tr[TR_POST + PO_CT]) - dcx, ey = f32(tr[TR_POST + PO_CT + 1]) - dcy;
+            float tcx, tcy;
+            trk_centre(tr, &tcx, &tcy);
+            const float ex = tcx - dcx, ey = tcy - dcy;
             const float ex2 = ex * ex, ey2 = ey * ey;
             const float c32 = ex2 + ey2;  // float32: each square rounded, then their sum
             const float tarea = f32((tr[TR_POST + PO_BBOX + 2] - tr[TR_POST + PO_BBOX]) *
@@ -700,14 +804,14 @@ CP_HD void trk_advance(const TrackParams& P, double* t, const double* prev, doub
         }
         if (P.scale_pool) {
             for (int i = 0; i < 7; ++i) t[TR_POOL_PREC + i] = old[TR_POOL_PREC + i];
-            trk_pool_add(t);
+            trk_pool_add(P, t);
         }
         flags |= 16;
     } else if (src == -1) {  // new track
         if (P.kalman) trk_kf_init(P, t);
         if (P.scale_pool) {
             for (int i = 0; i < 7; ++i) t[TR_POOL_PREC + i] = 0.0;
-            trk_pool_add(t);
+            trk_pool_add(P, t);
         }
         flags |= 16;
     }
@@ -730,7 +834,7 @@ CP_HD int trk_prepare_det(const TrackParams& P, const double* vm, const double* 
     int flags = 0, ok = 0;
     if (P.use_pnp && pnp_row && (int)pnp_row[0] == 1) {
         double ori[18];
-        ok = trk_finish(P, vm, pnp_row, post + PO_SCALE, post + PO_KPS, d, ori);
+        ok = trk_finish(P, vm, pnp_row, post + PO_SCALE, post + PO_KPS, d, ori, P.show_axes);
         flags |= 1;
         if (ok) {
             for (int i = 0; i < 18; ++i) d[TR_KPS_ORI + i] = ori[i];
@@ -757,7 +861,7 @@ CP_HD void trk_finish_stage(const TrackParams& P, const double* vm, double* t, c
     if (P.use_pnp && pnp_row && (int)pnp_row[0] == 1) {
         double ori[18], s3[3];
         for (int i = 0; i < 3; ++i) s3[i] = P.scale_pool ? t[TR_SCALE_KF + i] : t[TR_POST + PO_SCALE + i];
-        const int ok = trk_finish(P, vm, pnp_row, s3, t + TR_POST + PO_KPS, t, ori);
+        const int ok = trk_finish(P, vm, pnp_row, s3, t + TR_POST + PO_KPS, t, ori, P.baseline ? 0 : P.show_axes);
         flags |= 1;
         if (ok) {
             for (int i = 0; i < 18; ++i) t[TR_KPS_PNP_KF + i] = t[TR_KPS_PNP + i];

@@ -28,7 +28,7 @@ class TrackParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in ("new_thresh", "pre_thresh", "R", "conf_lo", "conf_hi")] + \
                [(n, ctypes.c_int) for n in ("max_age", "kalman", "scale_pool", "use_pnp", "hps_uncertainty", "show_axes",
                                             "cat_rule", "render_hm_mode", "render_hmhp_mode", "pre_hm", "pre_hm_hp", "K",
-                                            "cap", "hungarian", "pad_")]
+                                            "cap", "hungarian", "baseline")]
 
 
 def _sig(fn, restype, *argtypes):
@@ -436,8 +436,9 @@ TRACK_FIELDS = OrderedDict([  # field -> (offset, width) inside a device track r
 
 def track_params_from_opt(opt, K=100, cap=TRACK_CAP):
     """cp_track_params for a reference ``opt`` (opts.py:242-300); raises for what only the host tracker does."""
-    if not getattr(opt, "tracking_task", False) or not (opt.kalman or opt.scale_pool):
-        raise RuntimeError("device tracker: tracking_task with kalman and / or scale_pool (demo.py:117-129)")
+    baseline = bool(getattr(opt, "refined_Kalman", False))  # Tracker_baseline wins when both flags are set (base_detector.py:53-57)
+    if not (getattr(opt, "tracking_task", False) or baseline) or not (opt.kalman or opt.scale_pool):
+        raise RuntimeError("device tracker: tracking_task or refined_Kalman, with kalman and / or scale_pool (demo.py:117-129)")
     if getattr(opt, "gt_pre_hm_hmhp", False) or getattr(opt, "gt_pre_hm_hmhp_first", False) or getattr(opt, "empty_pre_hm", False):
         raise RuntimeError("device tracker: ground-truth / empty previous heat-maps are host-only modes")
     cat = {"camera": 0, "bottle": 0, "cup": 0, "book": 1, "chair": 1, "cereal_box": 1, "bike": 2, "laptop": 2, "shoe": 2}
@@ -448,7 +449,7 @@ def track_params_from_opt(opt, K=100, cap=TRACK_CAP):
                        show_axes=int(bool(opt.show_axes)), cat_rule=cat[opt.c], render_hm_mode=int(opt.render_hm_mode),
                        render_hmhp_mode=int(opt.render_hmhp_mode), pre_hm=int(bool(opt.pre_hm)),
                        pre_hm_hp=int(bool(opt.pre_hm_hp)), K=int(K), cap=int(cap), hungarian=int(bool(getattr(opt, "hungarian", False))),
-                       pad_=0)
+                       baseline=int(baseline))
 
 
 def track_vmeta(metas):

@@ -299,7 +299,8 @@ int cp_pnp_from_post(cp_stream_t stream, const double* post, const int* count, i
  *   utils/tracker.py:112-302 `Tracker.step`: greedy association, 32-state Kalman filter per track, scale pool, filtered
  *   PnP; utils/pnp/cuboid_pnp_shell.py:26-91 packaging and visibility rejects).
  * Supported configuration = the demo's (src/demo.py:117-129): `tracking_task` with `kalman` and / or `scale_pool`,
- * greedy or Hungarian association (`hungarian`), no ground-truth seeding; anything else stays on the host mirror
+ * greedy or Hungarian association (`hungarian`), `Tracker` or -- `baseline`, the reference's `--refined_Kalman` --
+ * `Tracker_baseline` (utils/tracker_baseline.py:14-310), no ground-truth seeding; anything else stays on the host mirror
  * (centerpose_amd/lib/utils/tracker.py).  Per video the state holds at most `cap` (<= CP_TRACK_CAP) tracks.
  *
  *   params        HOST struct (opt fields; cat_rule: 0 camera / bottle / cup, 1 book / chair / cereal_box, 2 bike / laptop /
@@ -333,7 +334,8 @@ typedef struct cp_track_params {
     int max_age, kalman, scale_pool, use_pnp, hps_uncertainty, show_axes, cat_rule, render_hm_mode, render_hmhp_mode, pre_hm,
         pre_hm_hp, K, cap;
     int hungarian; /* 1: optimal assignment (tracker.py:154-170, scipy's rectangular LSAP) instead of the greedy walk */
-    int pad_;
+    int baseline;  /* 1: Tracker_baseline (--refined_Kalman, utils/tracker_baseline.py:14-310): only (x, y) of a vertex observed,
+                      plain scale average, association on raw centres against velocity-advanced track centres */
 } cp_track_params;
 size_t cp_track_state_bytes(int B, int cap);
 size_t cp_track_workspace_bytes(int B, int K, int cap);

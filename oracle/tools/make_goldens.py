@@ -253,9 +253,14 @@ def run_tracker(cls, hungarian):
 
 
 def tracker_goldens():
-    """Reference Tracker.step (utils/tracker.py:112-302) on the seeded video, greedy and Hungarian -> tracker_ref.json."""
+    """Reference Tracker.step (utils/tracker.py:112-302) and Tracker_baseline.step (utils/tracker_baseline.py) on the seeded
+    video, greedy and Hungarian -> tracker_ref.json."""
     ref = rh.reference_tracker()
     out = {"greedy": run_tracker(ref, False), "hungarian": run_tracker(ref, True)}
+    # the position-only Kalman baseline (utils/tracker_baseline.py, --refined_Kalman), both association modes
+    base = rh.reference_tracker_baseline()
+    out["baseline"] = run_tracker(base, False)
+    out["baseline_hungarian"] = run_tracker(base, True)
     with open(os.path.join(GOLD, "tracker_ref.json"), "w") as f:
         json.dump(out, f)
     print("tracker_ref.json: tracks per frame", [len(x) for x in out["greedy"]])

@@ -157,6 +157,18 @@ def reference_tracker():
     return Tracker
 
 
+def reference_tracker_baseline():
+    """The reference's ``Tracker_baseline`` class (utils/tracker_baseline.py: ``--refined_Kalman``) under the host shims."""
+    setup()
+    install_host_shims()
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from lib.utils.tracker_baseline import Tracker_baseline
+    return Tracker_baseline
+
+
 def reference_host_modules():
     """(lib.utils.image, lib.utils.post_process, lib.detectors.object_pose) of the reference."""
     setup()

@@ -31,6 +31,7 @@ GOLD = os.path.join(REPO, "tests", "golden")
 N_FRAMES, N_OBJ, SEED = 5, 2, 21
 K_DEMO = np.array([[663.0287679036459, 0, 300.2775065104167], [0, 663.0287679036459, 395.00066121419275], [0, 0, 1]])
 TRACK_ARGV = ["--tracking_task", "--arch", "dla_34", "--c", "cup", "--gpus", "-1", "--debug", "0"]
+BASELINE_ARGV = TRACK_ARGV + ["--refined_Kalman"]
 
 
 def demo_flags(opt):
@@ -299,6 +300,14 @@ def main():
         json.dump({"argv": TRACK_ARGV, "frames": frames}, f)
     print("track_run.json: tracks per frame", [len(x["tracks"]) for x in frames], "boxes", [x["n_boxes"] for x in frames],
           "pre_hm_hp pixels", [x["pre_hm_hp_nonzero"] for x in frames])
+    # the same video with --refined_Kalman on top: base_detector.py:53-57 then installs Tracker_baseline (position-only
+    # filter, plain scale average) inside the same two-frame loop
+    det, gat = reference_detector(BASELINE_ARGV)
+    with contextlib.redirect_stdout(io.StringIO()):
+        frames = run_video(det, gat)
+    with open(os.path.join(GOLD, "track_run_baseline.json"), "w") as f:
+        json.dump({"argv": BASELINE_ARGV, "frames": frames}, f)
+    print("track_run_baseline.json: tracks per frame", [len(x["tracks"]) for x in frames])
 
 
 if __name__ == "__main__":

@@ -90,13 +90,18 @@ def _post_from_dict(d, fusion_as_displacement=False):
     return r
 
 
-def test_tracker_logic_matches_reference_golden(host):
+@pytest.mark.parametrize("mode", ["greedy", "baseline", "baseline_hungarian"])
+def test_tracker_logic_matches_reference_golden(host, mode):
+    """The device tracker's logic (host build of track_common.h) against the REFERENCE's own runs on the seeded video:
+    Tracker.step (greedy; the Hungarian run has its own test below) and Tracker_baseline.step (--refined_Kalman:
+    utils/tracker_baseline.py -- position-only filter with its broadcast initial covariance, plain scale average, raw centres
+    against velocity-advanced track centres, the P[2v] read-out), greedy and Hungarian."""
     with open(os.path.join(GOLD, "tracker_ref.json")) as f:
-        gold = json.load(f)["greedy"]
-    o = mg.TrackOpt(False)
+        gold = json.load(f)[mode]
+    o = mg.TrackOpt(mode.endswith("hungarian"))
     P = Params(new_thresh=o.new_thresh, pre_thresh=0.3, R=o.R, conf_lo=3, conf_hi=9, max_age=o.max_age, kalman=1,
                scale_pool=1, use_pnp=0, hps_uncertainty=1, show_axes=0, cat_rule=0, render_hm_mode=1, render_hmhp_mode=2,
-               pre_hm=1, pre_hm_hp=1, K=100)
+               pre_hm=1, pre_hm_hp=1, K=100, hungarian=int(mode.endswith("hungarian")), baseline=int(mode.startswith("baseline")))
     vm = np.zeros(16)
     vm[[0, 4]] = 1.0
     vm[6:10] = 512
@@ -111,7 +116,8 @@ def test_tracker_logic_matches_reference_golden(host):
             np.testing.assert_allclose(t[TR["MEAN_KF"]:TR["MEAN_KF"] + 16], g["kps_mean_kf"], rtol=1e-9, atol=1e-9)
             np.testing.assert_allclose(t[TR["STD_KF"]:TR["STD_KF"] + 16], g["kps_std_kf"], rtol=1e-9, atol=1e-9)
             np.testing.assert_allclose(t[TR["SCALE_KF"]:TR["SCALE_KF"] + 3], g["obj_scale_kf"], rtol=1e-6)
-            np.testing.assert_allclose(t[TR["SCALE_UNC_KF"]:TR["SCALE_UNC_KF"] + 3], g["obj_scale_uncertainty_kf"], rtol=1e-6)
+            np.testing.assert_allclose(t[TR["SCALE_UNC_KF"]:TR["SCALE_UNC_KF"] + 3], g["obj_scale_uncertainty_kf"], rtol=1e-6,
+                                       atol=1e-12)
     ids = [t[0] for t in tracks]
     assert len(set(ids)) == len(ids)
 
@@ -207,14 +213,15 @@ def test_tracker_logic_matches_python_loop_with_pnp(host, monkeypatch):
     assert n_checked >= 8
 
 
-@pytest.mark.parametrize("hungarian", [False, True])
-def test_tracker_logic_random_scenarios_vs_python_tracker(host, hungarian):
+@pytest.mark.parametrize("hungarian,baseline", [(False, False), (True, False), (False, True), (True, True)])
+def test_tracker_logic_random_scenarios_vs_python_tracker(host, hungarian, baseline):
     """(greedy, and the Hungarian association of tracker.py:154-174 whose Python side solves with scipy.)  Crowded random videos (objects crossing, leaving, re-entering, weak detections, same-frame births and deaths) through
     the harness and through the reference-pinned Python ``Tracker`` (greedy, Kalman + scale pool, no PnP): identical ids,
     ages, activity and filter read-outs in every frame -- association order, coasting up to max_age, the new-track
     threshold and the float32 cost arithmetic included."""
-    from centerpose_amd.lib.utils.tracker import Tracker
+    from centerpose_amd.lib.utils.tracker import Tracker, Tracker_baseline
 
+    # (baseline: the reference-pinned Python Tracker_baseline, --refined_Kalman)
     class Opt(mg.TrackOpt):
         max_age = 3
         new_thresh = 0.35
@@ -226,11 +233,11 @@ def test_tracker_logic_random_scenarios_vs_python_tracker(host, hungarian):
         vel = rng.uniform(-9, 9, (n_obj, 2))
         size = rng.uniform(25, 80, n_obj)
         o = Opt(hungarian)
-        py = Tracker(o)
+        py = (Tracker_baseline if baseline else Tracker)(o)
         py.init_track({"id": 0})
         P = Params(new_thresh=o.new_thresh, pre_thresh=0.3, R=o.R, conf_lo=3, conf_hi=9, max_age=o.max_age, kalman=1,
                    scale_pool=1, use_pnp=0, hps_uncertainty=1, show_axes=0, cat_rule=0, render_hm_mode=1, render_hmhp_mode=2,
-                   pre_hm=1, pre_hm_hp=1, K=100, hungarian=int(hungarian))
+                   pre_hm=1, pre_hm_hp=1, K=100, hungarian=int(hungarian), baseline=int(baseline))
         vm = np.zeros(16)
         vm[[0, 4]] = 1.0
         vm[6:10] = 512

@@ -25,10 +25,17 @@ from oracle import pnp as opnp
 from oracle.tools import track_golden as tg
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "track_run.json")
+# the same video through the reference's run() with --refined_Kalman on top (Tracker_baseline inside the two-frame loop)
+GOLD_BASELINE = os.path.join(os.path.dirname(__file__), "golden", "track_run_baseline.json")
 
 
-def _opt(gpus):
-    argv = [a if a != "-1" else gpus for a in tg.TRACK_ARGV]
+def _gold(baseline):
+    with open(GOLD_BASELINE if baseline else GOLD) as fh:
+        return json.load(fh)["frames"]
+
+
+def _opt(gpus, baseline=False):
+    argv = [a if a != "-1" else gpus for a in (tg.BASELINE_ARGV if baseline else tg.TRACK_ARGV)]
     with contextlib.redirect_stdout(io.StringIO()):
         o = opts().parser.parse_args(argv)
         o = tg.demo_flags(o)
@@ -71,7 +78,7 @@ class _Engine(object):
         return out
 
 
-def _detector(monkeypatch, gpus):
+def _detector(monkeypatch, gpus, baseline=False):
     from centerpose_amd.lib.detectors import base_detector as bd
     from centerpose_amd.lib.detectors.object_pose import ObjectPoseDetector
 
@@ -79,7 +86,7 @@ def _detector(monkeypatch, gpus):
     monkeypatch.setattr(bd, "create_model", lambda *a, **k: stub)
     monkeypatch.setattr(bd, "load_model", lambda m, *a, **k: m)
     with contextlib.redirect_stdout(io.StringIO()):
-        det = ObjectPoseDetector(_opt(gpus))
+        det = ObjectPoseDetector(_opt(gpus, baseline))
     stub._engine = lambda: _Engine(stub, det.opt.device)
     return det
 
@@ -124,12 +131,13 @@ def _compare(frames, gold):
             np.testing.assert_allclose(ba, bg, rtol=1e-5, atol=1e-5, err_msg="frame %d box" % f)
 
 
-def test_tracking_run_matches_reference_cpu(monkeypatch):
+@pytest.mark.parametrize("baseline", [False, True])
+def test_tracking_run_matches_reference_cpu(monkeypatch, baseline):
     from centerpose_amd.lib.utils.pnp import cuboid_pnp_solver as cps
 
-    with open(GOLD) as fh:
-        gold = json.load(fh)["frames"]
-    det = _detector(monkeypatch, "-1")
+    gold = _gold(baseline)   # baseline: the reference's run() with --refined_Kalman on top (Tracker_baseline in the loop)
+    det = _detector(monkeypatch, "-1", baseline)
+    assert type(det.tracker).__name__ == ("Tracker_baseline" if baseline else "Tracker")
     det.process = _cpu_process(det)
     monkeypatch.setattr(cps, "solve_pnp_batch", _oracle_pnp_rows)
     from centerpose_amd.lib.detectors import base_detector as bd
@@ -163,10 +171,10 @@ def test_refined_kalman_baseline_runs_and_differs(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_tracking_run_matches_reference_gpu(device, monkeypatch):
-    with open(GOLD) as fh:
-        gold = json.load(fh)["frames"]
-    det = _detector(monkeypatch, "0")
+@pytest.mark.parametrize("baseline", [False, True])
+def test_tracking_run_matches_reference_gpu(device, monkeypatch, baseline):
+    gold = _gold(baseline)
+    det = _detector(monkeypatch, "0", baseline)
     assert det.opt.device.type == "cuda"
     with contextlib.redirect_stdout(io.StringIO()):
         frames = tg.run_video(det, get_affine_transform)
@@ -174,20 +182,19 @@ def test_tracking_run_matches_reference_gpu(device, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("device_tracker", [False, True])
-def test_batched_tracking_matches_reference_per_video(device, monkeypatch, device_tracker):
+@pytest.mark.parametrize("device_tracker,baseline", [(False, False), (True, False), (False, True), (True, True)])
+def test_batched_tracking_matches_reference_per_video(device, monkeypatch, device_tracker, baseline):
     """BatchedTracking (B concurrent videos: batched render / network / decode / post-process / PnP on the device; the
     per-video track bookkeeping either by the reference-shaped Python Tracker on the host or by cp_track_step on the
     device) must give every video exactly what the reference's ``run()`` gives the single video of
     tests/golden/track_run.json: tracks, filter read-outs, filtered poses, `boxes`, and the previous-frame heat-maps the
-    network is fed."""
+    network is fed.  The same for the reference's run() with --refined_Kalman (tests/golden/track_run_baseline.json)."""
     import types
 
     from centerpose_amd.lib.detectors.batch_tracking import BatchedTracking
 
-    with open(GOLD) as fh:
-        gold = json.load(fh)["frames"]
-    det = _detector(monkeypatch, "0")
+    gold = _gold(baseline)   # baseline: --refined_Kalman on top, i.e. Tracker_baseline (cp_track_params.baseline on the device)
+    det = _detector(monkeypatch, "0", baseline)
     stub, B = det.model, 3
 
     class BatchEngine(object):
@@ -229,20 +236,22 @@ def test_batched_tracking_matches_reference_per_video(device, monkeypatch, devic
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["greedy", "hungarian"])
+@pytest.mark.parametrize("mode", ["greedy", "hungarian", "baseline", "baseline_hungarian"])
 def test_device_tracker_matches_reference_tracker_golden(device, mode):
     """cp_track_step alone (no PnP) on the seeded detections of tests/golden/tracker_ref.json -- the REFERENCE's own
     Tracker.step: ids, ages, coasting, Kalman read-out and scale pool, for three videos that start one frame apart; greedy
-    association and (round 4) the Hungarian mode, whose device solver restates scipy's rectangular assignment."""
+    association and (round 4) the Hungarian mode, whose device solver restates scipy's rectangular assignment; "baseline*" = the
+    reference's Tracker_baseline.step (--refined_Kalman) on the same detections."""
     from oracle.tools import make_goldens as mg
 
     with open(os.path.join(os.path.dirname(GOLD), "tracker_ref.json")) as fh:
         gold = json.load(fh)[mode]
-    o = mg.TrackOpt(mode == "hungarian")
+    o = mg.TrackOpt(mode.endswith("hungarian"))
     B, K = 3, 100
     P = hip.TrackParams(new_thresh=o.new_thresh, pre_thresh=0.3, R=o.R, conf_lo=3, conf_hi=9, max_age=o.max_age, kalman=1,
                         scale_pool=1, use_pnp=0, hps_uncertainty=1, show_axes=0, cat_rule=0, render_hm_mode=1,
-                        render_hmhp_mode=2, pre_hm=1, pre_hm_hp=1, K=K, cap=hip.TRACK_CAP, hungarian=int(mode == "hungarian"))
+                        render_hmhp_mode=2, pre_hm=1, pre_hm_hp=1, K=K, cap=hip.TRACK_CAP, hungarian=int(mode.endswith("hungarian")),
+                        baseline=int(mode.startswith("baseline")))
     vm = np.zeros((B, 16))
     vm[:, [0, 4]] = 1.0
     vm[:, 6:10] = 512
@@ -278,4 +287,4 @@ def test_device_tracker_matches_reference_tracker_golden(device, mode):
                 np.testing.assert_allclose(t[409:425], gt["kps_mean_kf"], rtol=1e-9, atol=1e-9)
                 np.testing.assert_allclose(t[425:441], gt["kps_std_kf"], rtol=1e-9, atol=1e-9)
                 np.testing.assert_allclose(t[441:444], gt["obj_scale_kf"], rtol=1e-6)
-                np.testing.assert_allclose(t[444:447], gt["obj_scale_uncertainty_kf"], rtol=1e-6)
+                np.testing.assert_allclose(t[444:447], gt["obj_scale_uncertainty_kf"], rtol=1e-6, atol=1e-12)
