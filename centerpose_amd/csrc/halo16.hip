@@ -36,11 +36,12 @@ __device__ __forceinline__ int pswz(int q) { return q & 7; }
 // profiles/r02_halo_ab.txt.)
 // EPI: 0 = plain epilogue (patch16_common.h); 1 = fused prediction head (igemm16.hip: FUSE -- transposed main product,
 // bias + ReLU, second MFMA product with the 1x1 weights, slices to fuse_out); 2 = fused ConvGRU gates (igemm16.hip: GRU).
-template <int MT, int NT, int WM, int WN, bool BDIRECT = false, int EPI = 0>
+template <int MT, int NT, int WM, int WN, bool BDIRECT = false, int EPI = 0, int FT = 0>
 __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
     static_assert(WM * WN == 4 && 32 * MT * WM == TH * TW, "4 waves over a 128-pixel patch");
+    static_assert(FT == 0 || EPI == 1, "FT: hidden tiles a fused-head workgroup walks (ConvParams::fuse_final), 0 = one tile, slabs");
     static_assert(EPI != 1 || (MT == 2 && NT == 2 && WM == 2 && WN == 2), "fused head: 128 x 128 tiles");
     static_assert(EPI != 2 || (MT == 1 && NT == 3 && WM == 4 && WN == 1), "GRU: 128 x 96 tiles");
     constexpr int BN = 32 * NT * WN;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
         const int bsel = (p.dbg >> 18) & 3;  // cp_set_debug bits 18-19 (A/B): band of 8 / 128 patches / the whole map
         const int HEAD_BAND = bsel == 0 ? 32 : bsel == 1 ? 8 : bsel == 2 ? 128 : tiles_m;
         // fuse_final: one workgroup per (patch, head) -- tiles_n counts heads, tn becomes the head's first hidden tile below
-        const int gt = p.fuse_final ? 1 : p.fuse_gtiles, per_band = HEAD_BAND * tiles_n;
+        const int gt = FT ? 1 : p.fuse_gtiles, per_band = HEAD_BAND * tiles_n;
         const int band = tile / per_band, m0 = band * HEAD_BAND;
         const int bsz = min(HEAD_BAND, tiles_m - m0);  // patches in this band (the last one may be short)
         const int rem = tile - band * per_band;
@@ -77,8 +78,10 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
         tn = g * gt + rr % gt;
         tm = m0 + rr / gt;
     }
-    const int ntl = (EPI == 1 && p.fuse_final) ? p.fuse_gtiles : 1;  // hidden tiles this workgroup walks
-    if (EPI == 1 && p.fuse_final) tn *= p.fuse_gtiles;
+    constexpr int ntl = FT ? FT : 1;  // hidden tiles this workgroup walks (a compile-time count: the walk is unrolled, so the
+                                      // staging code and its operands are not carried through a loop -- as a run-time loop the
+                                      // kernel spilled 15 registers and wrote 1.4 GB of scratch lines back per launch)
+    if (FT) tn *= FT;
     const int txs = p.W / TW, tys = p.H / TH;
     const int tx0 = (tm % txs) * TW;
     tm /= txs;
@@ -125,21 +128,9 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
     };
 
     acc_t acc[MT][NT];
-    // ---- fragment geometry: row m of the tile = pixel (m / 16, m % 16); lane reads rows lcol + 32 i + 32 MT wm ----
-    const int lrow = lane >> 5, lcol = lane & 31;
-    int q0[MT];  // patch pixel of the fragment row at tap (0, 0)
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int m = wm * (MT * 32) + i * 32 + lcol;
-        q0[i] = (m >> 4) * PW + (m & 15);
-    }
-    const int b_frag = (wn * (NT * 32) + lcol) * LDH;
-
     // BDIRECT: fragment (n tile j, K step g of 16) = 1 KB in lane order at ((j G + g) 64 + lane) 16 bytes
     const int G = p.Kpad16 / 16, gpt = p.Cin / 16;  // K steps per weight row / per tap
     unsigned bd_off[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) bd_off[j] = (unsigned)((((tn * (BN / 32) + wn * NT + j) * G) * 64 + lane) * 16);
     constexpr int NSET = MT * NT == 1 ? 3 : 2;  // K tiles in flight + 1 (18 tiles per chunk: both rotations stay consistent)
     u32x4 dbh[NSET][2][NT], dbl[NSET][2][NT];  // [register set = K tile % NSET][k-step][fragment]
     const int nchunks = p.Cin / CK;
@@ -156,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
                 dbl[set][ks][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)bd_off[j], (g + ks) * 1024, 0);
             }
     };
+#pragma unroll
     for (int t2 = 0; t2 < ntl; ++t2) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -164,11 +156,23 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
 #pragma unroll
                 for (int r = 0; r < F::NACC; ++r) acc[i][j][r] = 0.f;
 
-        if (BDIRECT) {  // the first K tiles in flight while the first patch is staged
-            if (t2 > 0) {
+        // ---- fragment geometry: row m of the tile = pixel (m / 16, m % 16); lane reads rows lcol + 32 i + 32 MT wm ----
+        // (derived from a lane id the compiler cannot see through, once per hidden tile: otherwise the unrolled walk shares the
+        // per-tap LDS addresses of its K loops and carries them -- 15 registers -- across the epilogue in between, in scratch)
+        int lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane_t));
+        const int lrow = lane_t >> 5, lcol = lane_t & 31;
+        int q0[MT];  // patch pixel of the fragment row at tap (0, 0)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) bd_off[j] += (unsigned)((BN / 32) * G * 1024);
-            }
+        for (int i = 0; i < MT; ++i) {
+            const int m = wm * (MT * 32) + i * 32 + lcol;
+            q0[i] = (m >> 4) * PW + (m & 15);
+        }
+        const int b_frag = (wn * (NT * 32) + lcol) * LDH;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bd_off[j] = (unsigned)((((tn * (BN / 32) + wn * NT + j) * G) * 64 + lane_t) * 16);
+
+        if (BDIRECT) {  // the first K tiles in flight while the first patch is staged
             issue_bd(0, 0, 0);
             if (NSET == 3) issue_bd(1, 0, 1);
         }
@@ -290,8 +294,10 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
             }
         }
 
-        // (the lane id is rebuilt here instead of living in a vector register across the K loop)
-        const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        // (the lane id is rebuilt here instead of living in a vector register across the K loop -- opaquely, so that the
+        // unrolled tile walk does not keep one tile's epilogue addresses for the next tile's)
+        int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (EPI == 1) asm volatile("" : "+v"(lane_e));
         if constexpr (EPI == 1) {
             // ---- fused prediction head (the arithmetic of igemm16.hip's FUSE epilogue on this kernel's pixel order) ----
             const int M = p.B * p.H * p.W;
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
                     for (int r = 0; r < 16; ++r) {
                         const int c = F::row(r, lane_e);
                         const float v = acc2[i][r] + red[((wm * 2 + i) * 16 + r) * 64 + lane_e];
-                        if (!p.fuse_final) {
+                        if (!FT) {
                             if (c < c2) p.fuse_out[((size_t)plane0 + c) * M + m] = v;
                             continue;
                         }
@@ -445,12 +451,12 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
     patch_epilogue<MT, NT, WM, WN>(p, acc, b, ty0, tx0, tn, wm, wn, lane_e, ainv);
 }
 
-template <int MT, int NT, int WM, int WN, bool BDIRECT = false, int EPI = 0>
+template <int MT, int NT, int WM, int WN, bool BDIRECT = false, int EPI = 0, int FT = 0>
 int launch_halo(const ConvParams& p, hipStream_t stream) {
     constexpr int BN = 32 * NT * WN;
     // (fused heads that finish in the kernel: one workgroup per patch and head, ConvParams::fuse_final)
-    const int tiles_m = p.B * (p.H / TH) * (p.W / TW), tiles_n = (EPI == 1 && p.fuse_final) ? p.fuse_ngroups : p.CoutPad / BN;
-    hipLaunchKernelGGL((halo16_kernel<MT, NT, WM, WN, BDIRECT, EPI>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p,
+    const int tiles_m = p.B * (p.H / TH) * (p.W / TW), tiles_n = FT ? p.fuse_ngroups : p.CoutPad / BN;
+    hipLaunchKernelGGL((halo16_kernel<MT, NT, WM, WN, BDIRECT, EPI, FT>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p,
                        tiles_m, tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
@@ -486,11 +492,12 @@ static bool halo16_fused_geometry(const ConvParams& p) {
 
 // fused prediction head on the halo-resident kernel (same operands as cp_launch_conv16_fused_head)
 bool cp_halo16_fused_head_supported(const ConvParams& p) {
-    if (p.fuse_final && (p.fuse_ngroups < 1 || p.Cin != CK || p.CoutPad != p.fuse_ngroups * p.fuse_gtiles * 128)) return false;
+    if (p.fuse_final && (p.fuse_ngroups < 1 || p.Cin != CK || p.fuse_gtiles != 2 || p.CoutPad != p.fuse_ngroups * 256)) return false;
     return halo16_fused_geometry(p) && p.CoutPad % 128 == 0 && p.fuse_w2_hi && p.fuse_w2_lo && (p.fuse_out || p.fuse_final);
 }
 int cp_launch_halo16_fused_head(const ConvParams& p, hipStream_t stream) {
     if (!cp_halo16_fused_head_supported(p)) return CP_ERR_INVALID;
+    if (p.fuse_final) return launch_halo<2, 2, 2, 2, true, 1, 2>(p, stream);  // 256 hidden channels = two tiles per head
     return launch_halo<2, 2, 2, 2, true, 1>(p, stream);
 }
 
