@@ -815,7 +815,9 @@ struct Fwd {
         p.fuse_gtiles = g.hid / 128;
         p.fuse_out = (float*)0x1000;  // placeholder for the eligibility check
         // the kernel walks a head's hidden tiles and writes the finished maps itself (cp_set_debug 1: slabs + reduction launch)
-        p.fuse_final = (g.Cin == 64 && g.hid == 256 && !(g_dbg & 1)) ? 1 : 0;
+        // 2: every head of a patch in one workgroup (one staging for all of them) -- when the patches alone fill the device
+        // several times over; below that (small batches) one workgroup per patch and head
+        p.fuse_final = (g.Cin == 64 && g.hid == 256 && !(g_dbg & 1)) ? (((g_dbg & 2) || B * (x.H / 8) * (x.W / 16) < 2048) ? 1 : 2) : 0;
         if (!cp_halo16_fused_head_supported(p)) return false;
         if (B * (x.H / 8) * (x.W / 16) * (p.CoutPad / 128) < kSplitTiles) return false;  // small maps: per-head split-K path
         HeadReduceGroup rg;

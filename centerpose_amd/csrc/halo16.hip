@@ -147,6 +147,53 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
                 dbl[set][ks][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)bd_off[j], (g + ks) * 1024, 0);
             }
     };
+    // ---- stage the halo patch of one 64-channel chunk: float32 global -> hi / lo binary16 planes (called per chunk; fused heads
+    // that walk several tiles: once) ----
+    auto stage_chunk = [&](int ch) {
+        // all loads of a round are issued before the first conversion: one HBM round trip per round instead of one per
+        // slot (the round size is what the register file leaves: 6 slots next to 128 accumulators' worth of state)
+        constexpr int SR = (BDIRECT || MT * NT >= 4) ? 6 : 12;
+        // the thread id is rebuilt per chunk (not held in a vector register across the K loop)
+        int lane_c = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane_c));
+        const int tid_c = wid * 64 + lane_c, c4c = tid_c & 15;
+#pragma unroll
+        for (int s0 = 0; s0 < ST; s0 += SR) {
+            float4 sv[SR];
+#pragma unroll
+            for (int s = 0; s < SR; ++s) {
+                const int q = (tid_c >> 4) + 16 * (s0 + s);
+                const int py = q / PW, px = q - py * PW;
+                const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+                const bool in = q < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const unsigned off = in ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + ch * CK + c4c * 4) * 4u : OOB;
+                sv[s] = buf_ld4(r_x, off);
+            }
+            if (!have_scale) {  // once per block, with the first round of staging loads already in flight
+                conv_in_scale_finish(p, amax_raw, &afwd, &ainv);
+                have_scale = true;
+            }
+#pragma unroll
+            for (int s = 0; s < SR; ++s) {
+                const int q = (tid_c >> 4) + 16 * (s0 + s);
+                if (q < NPIX) {
+                    const float4 v = sv[s];
+                    const Split2 h0 = split2(v.x * afwd, v.y * afwd), h1 = split2(v.z * afwd, v.w * afwd);
+                    const int col = ((((c4c >> 1) ^ pswz(q)) << 1) | (c4c & 1)) * 4;  // halfs
+                    *reinterpret_cast<u32x2*>(patch_hi + q * PROW + col) = u32x2{h0.hi, h1.hi};
+                    *reinterpret_cast<u32x2*>(patch_lo + q * PROW + col) = u32x2{h0.lo, h1.lo};
+                }
+            }
+        }
+    };
+    if (FT) {  // one chunk (Cin = 64), staged once for every hidden tile the workgroup walks
+        stage_chunk(0);
+        __syncthreads();
+    }
+    // fuse_final 2: the workgroup walks every head of its patch (one staging for all of them), head by head
+    const int nwalk = (FT && p.fuse_final == 2) ? p.fuse_ngroups : 1;
+#pragma unroll 1
+    for (int hw = 0; hw < nwalk; ++hw)
 #pragma unroll
     for (int t2 = 0; t2 < ntl; ++t2) {
 #pragma unroll
@@ -180,44 +227,9 @@ __global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, cons
         for (int ch = 0; ch < nchunks; ++ch) {
             // first weight tile of the chunk in flight while the patch is staged
             if (!BDIRECT) issue_b(((0 * p.Cin) + ch * CK) * 2);
-            if (t2 == 0) {  // (fuse_final: one chunk, staged once for all hidden tiles of the head)
+            if (!FT) {
                 if (ch > 0) __syncthreads();  // every wave is done reading the previous chunk's patch
-                // ---- stage the halo patch of this 64-channel chunk: float32 global -> hi / lo binary16 planes ----
-                // all loads of a round are issued before the first conversion: one HBM round trip per round instead of one per
-                // slot (the round size is what the register file leaves: 6 slots next to 128 accumulators' worth of state)
-                constexpr int SR = (BDIRECT || MT * NT >= 4) ? 6 : 12;
-                // the thread id is rebuilt per chunk (not held in a vector register across the K loop)
-                int lane_c = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-                asm volatile("" : "+v"(lane_c));
-                const int tid_c = wid * 64 + lane_c, c4c = tid_c & 15;
-#pragma unroll
-                for (int s0 = 0; s0 < ST; s0 += SR) {
-                    float4 sv[SR];
-#pragma unroll
-                    for (int s = 0; s < SR; ++s) {
-                        const int q = (tid_c >> 4) + 16 * (s0 + s);
-                        const int py = q / PW, px = q - py * PW;
-                        const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
-                        const bool in = q < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                        const unsigned off = in ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + ch * CK + c4c * 4) * 4u : OOB;
-                        sv[s] = buf_ld4(r_x, off);
-                    }
-                    if (!have_scale) {  // once per block, with the first round of staging loads already in flight
-                        conv_in_scale_finish(p, amax_raw, &afwd, &ainv);
-                        have_scale = true;
-                    }
-#pragma unroll
-                    for (int s = 0; s < SR; ++s) {
-                        const int q = (tid_c >> 4) + 16 * (s0 + s);
-                        if (q < NPIX) {
-                            const float4 v = sv[s];
-                            const Split2 h0 = split2(v.x * afwd, v.y * afwd), h1 = split2(v.z * afwd, v.w * afwd);
-                            const int col = ((((c4c >> 1) ^ pswz(q)) << 1) | (c4c & 1)) * 4;  // halfs
-                            *reinterpret_cast<u32x2*>(patch_hi + q * PROW + col) = u32x2{h0.hi, h1.hi};
-                            *reinterpret_cast<u32x2*>(patch_lo + q * PROW + col) = u32x2{h0.lo, h1.lo};
-                        }
-                    }
-                }
+                stage_chunk(ch);
                 if (!BDIRECT) store_b(0);
                 __syncthreads();
             }
@@ -455,7 +467,7 @@ template <int MT, int NT, int WM, int WN, bool BDIRECT = false, int EPI = 0, int
 int launch_halo(const ConvParams& p, hipStream_t stream) {
     constexpr int BN = 32 * NT * WN;
     // (fused heads that finish in the kernel: one workgroup per patch and head, ConvParams::fuse_final)
-    const int tiles_m = p.B * (p.H / TH) * (p.W / TW), tiles_n = FT ? p.fuse_ngroups : p.CoutPad / BN;
+    const int tiles_m = p.B * (p.H / TH) * (p.W / TW), tiles_n = FT ? (p.fuse_final == 2 ? 1 : p.fuse_ngroups) : p.CoutPad / BN;
     hipLaunchKernelGGL((halo16_kernel<MT, NT, WM, WN, BDIRECT, EPI, FT>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p,
                        tiles_m, tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;

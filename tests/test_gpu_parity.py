@@ -512,7 +512,7 @@ def test_backbone_at_bench_batch_spot_parity(device, arch, B, pick):
         assert float((z[k] - zo[k]).abs().max()) < 1e-3 * max(1.0, float(zo[k].abs().max())), k
 
 
-@pytest.mark.parametrize("arch,B,hw", [("dla_34", 2, 256), ("hourglass", 1, 512), ("dla_34", 1, 512)])
+@pytest.mark.parametrize("arch,B,hw", [("dla_34", 2, 256), ("hourglass", 1, 512), ("dla_34", 1, 512), ("dla_34", 16, 512)])
 def test_grouped_fused_heads_equal_per_head_launches(device, arch, B, hw):
     """All fused prediction heads in ONE launch (engine.hip: fused_heads_grouped; concatenated operands, per-tile head
     table; a workgroup walks the hidden tiles of its head and finishes the maps) against one launch per head and against the
@@ -522,9 +522,10 @@ def test_grouped_fused_heads_equal_per_head_launches(device, arch, B, hw):
     x = synth.frames(B, seed=77, h=hw, w=hw).to(device)
     model = hip.HipModel(arch, heads, sd, precision="f16x3")
     z = {k: v.clone() for k, v in model(x, sigmoid_hm=True).items()}
-    # 16777216: one launch per head; 1: one grouped launch that writes per-tile slabs + the reduction launch (the default
-    # grouped launch walks a head's hidden tiles in one workgroup and writes the finished maps itself)
-    for dbg in (16777216, 1):
+    # 16777216: one launch per head; 1: one grouped launch that writes per-tile slabs + the reduction launch; 2: a workgroup
+    # walks the hidden tiles of ONE head and finishes its maps (the default below 2048 patches; from there -- the B = 16 case
+    # here -- a workgroup walks every head of its patch)
+    for dbg in (16777216, 1, 2):
         hip.lib().cp_set_debug(dbg)
         try:
             z1 = {k: v.clone() for k, v in model(x, sigmoid_hm=True).items()}
