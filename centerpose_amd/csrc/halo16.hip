@@ -37,7 +37,7 @@ __device__ __forceinline__ int pswz(int q) { return q & 7; }
 // EPI: 0 = plain epilogue (patch16_common.h); 1 = fused prediction head (igemm16.hip: FUSE -- transposed main product,
 // bias + ReLU, second MFMA product with the 1x1 weights, slices to fuse_out); 2 = fused ConvGRU gates (igemm16.hip: GRU).
 template <int MT, int NT, int WM, int WN, bool BDIRECT = false, int EPI = 0, int FT = 0>
-__global__ __launch_bounds__(256, 2) void halo16_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
+__global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2) void halo16_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
     static_assert(WM * WN == 4 && 32 * MT * WM == TH * TW, "4 waves over a 128-pixel patch");
