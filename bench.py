@@ -783,8 +783,8 @@ def main():
             pipe._stages.clear()
             torch.cuda.empty_cache()
             legs = {}
-            k = max(4, min(args.steps, 6))
-            w = max(1, min(args.warmup, 2))
+            k = max(4, min(args.steps, 10))   # (6 steps after 2 warm-ups gave one 35 % outlier in a dozen runs: a leg is a few
+            w = max(1, min(args.warmup, 3))   # hundred milliseconds either way)
             legs["configs1"] = run_leg("decode", device, args.precision, max(4, min(args.steps, 12)), w, barrier,
                                        not args.no_latency)
             for name, fn in (("decode_only", lambda: decode_only_leg(device, args.precision)),
