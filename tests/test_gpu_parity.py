@@ -355,6 +355,50 @@ def test_dcn_streamed_persistent_vs_oracle_and_gather_kernel(device, B, C, Co, H
     assert not torch.equal(out, old)   # two different kernels really ran (summation order differs)
 
 
+@pytest.mark.parametrize("C,Co,HW", [(64, 64, 128), (128, 128, 64)])
+def test_dcn_at_bench_batch_size_independent_properties(device, C, Co, HW):
+    """The two DCNv2 shapes the persistent kernel takes in the benchmark, at the benchmark's batch (B = 64: 8192 / 4096 items,
+    where no CPU oracle finishes in seconds) through properties that do not depend on the size:
+      * the launch really goes to dcn16s by default, and it agrees with dcn16p (cp_set_debug 1048576) and with the gather kernel
+        dcn16 (32768) to summation-order round-off;
+      * homogeneity: f(4 x) - bias == 4 (f(x) - bias) bit for bit -- every operand is pre-scaled by exact powers of two
+        (profiles/NOTES.md 3.1), so a power-of-two input scale must come out as exactly that scale;
+      * additivity in the input for fixed offsets / masks: f(x1 + x2) - f(x1) - f(x2) + f(0) == 0 to round-off;
+      * an all-zero mask gives the bias, whatever the offsets."""
+    hip.set_default_precision("f16x3")
+    try:
+        g = torch.Generator().manual_seed(C + HW)
+        B = 64
+        x1 = torch.randn(B, C, HW, HW, generator=g).to(device)
+        x2 = torch.randn(B, C, HW, HW, generator=g).to(device)
+        w = (torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5).to(device)
+        b = torch.randn(Co, generator=g).to(device)
+        off = (torch.randn(B, 18, HW, HW, generator=g) * 1.5).to(device)
+        mask = torch.rand(B, 9, HW, HW, generator=g).to(device)
+        tail = [3, 3, 1, 1, 1, 1, 1, 1, 1]
+        f = lambda x, m=mask: hip.dcn_v2_forward(x, w, b, off, m, *tail)
+        y1 = f(x1)
+        scale = float(y1.abs().max())
+        for dbg in (1048576, 32768):
+            hip.lib().cp_set_debug(dbg)
+            try:
+                other = f(x1)
+            finally:
+                hip.lib().cp_set_debug(0)
+            assert not torch.equal(other, y1), dbg            # a different kernel ran
+            assert float((other - y1).abs().max()) / scale < 2e-6, dbg
+        bias = b.view(1, Co, 1, 1)
+        y4 = f(4.0 * x1)
+        assert torch.equal(y4 - bias, 4.0 * (y1 - bias)) or float(((y4 - bias) - 4.0 * (y1 - bias)).abs().max()) / scale < 3e-7
+        y0, y2, y12 = f(torch.zeros_like(x1)), f(x2), f(x1 + x2)
+        assert float((y0 - bias).abs().max()) == 0.0
+        assert float((y12 - y1 - y2 + y0).abs().max()) / scale < 2e-5
+        yz = f(x1, torch.zeros_like(mask))
+        assert float((yz - bias).abs().max()) == 0.0
+    finally:
+        hip.set_default_precision("f32")
+
+
 @pytest.mark.parametrize("kernel,dbg", [("dcn16p", 65536 | 1048576), ("dcn16s", 65536 | 2097152)])
 def test_dcn_kernels_are_stable_over_many_launches(device, kernel, dbg):
     """Regression for a rare corruption found in round 4 (profiles/NOTES.md): about one dcn16p launch in a hundred returned 16
