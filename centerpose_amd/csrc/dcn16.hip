@@ -307,6 +307,7 @@ int cp_launch_dcn16(const ConvParams& p, int bn, int variant, hipStream_t stream
     if ((size_t)p.B * p.H * p.W * 128 >= (size_t)0xf0000000u) return CP_ERR_INVALID;  // 32-bit offsets of the records
     // measured on the dlav1_34 B=32 step (profiles/r02_dcn_ab.txt): N 64: 4 waves of 64x32, two blocks per CU (110 TFLOP/s)
     // vs 8 waves at 128 VGPRs (108); N 128: 8 waves of 64x32, one block per CU (152) vs 4 waves of 64x64 at 256 VGPRs (136)
+    if (bn == 64 && p.tile_m == 64) return launch_dcn16<1, 1, 2, 2, 2>(p, stream);  // small launches: 64 x 64 tiles (ConvParams::tile_m)
     if (bn == 64) return variant ? launch_dcn16<1, 1, 4, 2, 4>(p, stream) : launch_dcn16<2, 1, 2, 2, 2>(p, stream);
     if (bn == 128) return variant ? launch_dcn16<2, 2, 2, 2, 1>(p, stream) : launch_dcn16<2, 1, 2, 4, 2>(p, stream);
     return CP_ERR_INVALID;

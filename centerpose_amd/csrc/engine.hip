@@ -966,7 +966,7 @@ struct Fwd {
             // slices and of the slab bytes (slices x M x Cout x 4) for the same workgroup count, and no split at all where that
             // already gives kSplitTiles workgroups.  cp_set_debug 16: the 128-row tiles everywhere (A/B runs).
             // Measured at B = 1 / 2 / 4 / 8 (profiles/NOTES.md): pays up to 32 tiles of 128 rows, up to 64 when K is short.
-            if (use16 && tiles > 0 && (tiles <= 32 || (tiles <= 64 && nk <= 36)) && nk >= 8 && !p.gn_stats && !offmask && !p.gn_in_a &&
+            if (use16 && tiles > 0 && (tiles <= 32 || (tiles <= 64 && nk <= 36)) && nk >= 8 && !p.gn_stats && !p.gn_in_a &&
                 p.CoutPad % 64 == 0 && w.Cout >= 64 && !(g_dbg & 16)) {
                 p.tile_m = p.tile_n = 64;
                 cp_conv_geometry(p, use16, &tiles, &nk);

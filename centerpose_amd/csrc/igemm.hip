@@ -391,8 +391,8 @@ const char* cp_conv_variant_name(int v) {
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk) {
     int bn = cp_conv_tile_n(p.Cout);
     if (f16x3 && bn < 32) bn = 32;
-    if (f16x3 && p.tile_n && p.tile_n < bn && p.CoutPad % p.tile_n == 0 && !p.offmask) bn = p.tile_n;
-    const int bm = f16x3 ? ((bn == 64 && p.tile_m == 64 && !p.offmask) ? 64 : 128) : (bn <= 32 ? 256 : 128);
+    if (f16x3 && p.tile_n && p.tile_n < bn && p.CoutPad % p.tile_n == 0 && (!p.offmask || p.tile_n == 64)) bn = p.tile_n;
+    const int bm = f16x3 ? ((bn == 64 && p.tile_m == 64) ? 64 : 128) : (bn <= 32 ? 256 : 128);
     const int M = p.B * p.Ho * p.Wo;
     *tiles = ((M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn);
     *nk = f16x3 ? p.Kpad16 / 32 : p.Kpad / BK;

@@ -999,7 +999,7 @@ int cp_launch_absmax(const float* x, size_t n, unsigned* slot, hipStream_t s) {
 // (the GroupNorm'd final 1x1 heads) take the 32-wide tile
 static int conv16_tile_n(const ConvParams& p) {
     const int bn = cp_conv_tile_n(p.Cout);
-    if (p.tile_n && p.tile_n < bn && p.CoutPad % p.tile_n == 0 && !p.offmask) return p.tile_n;
+    if (p.tile_n && p.tile_n < bn && p.CoutPad % p.tile_n == 0 && (!p.offmask || p.tile_n == 64)) return p.tile_n;
     return (bn < 32 && p.CoutPad >= 32 && p.CoutPad % 32 == 0) ? 32 : bn;
 }
 
