@@ -359,17 +359,24 @@ def run_leg(workload, device, precision, steps, warmup, barrier, latency, serial
     return out
 
 
-def _event_ms(fn, n, warm=3):
-    """Average HIP-event milliseconds of `fn` on torch's current stream (n calls after `warm`)."""
+def _event_ms(fn, n, warm=3, chunks=5):
+    """HIP-event milliseconds per call of `fn` on torch's current stream: n calls after `warm`, timed in `chunks` groups, the
+    median group's average (these legs are tens of microseconds per call, i.e. bounded by how fast the host issues the
+    launches: one 30 ms stall of the host inside 50 calls once turned 43 us into 674)."""
     for _ in range(warm):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / n
+    per = max(1, n // chunks)
+    times = []
+    for _ in range(chunks):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(per):
+            fn()
+        e1.record()
+        e1.synchronize()
+        times.append(e0.elapsed_time(e1) / per)
+    times.sort()
+    return times[len(times) // 2]
 
 
 def decode_only_leg(device, precision, batch=32):
