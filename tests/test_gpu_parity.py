@@ -556,23 +556,27 @@ def test_backbone_at_bench_batch_spot_parity(device, arch, B, pick):
         assert float((z[k] - zo[k]).abs().max()) < 1e-3 * max(1.0, float(zo[k].abs().max())), k
 
 
-@pytest.mark.parametrize("arch,B,hw", [("dla_34", 2, 256), ("hourglass", 1, 512), ("dla_34", 1, 512), ("dla_34", 16, 512)])
-def test_grouped_fused_heads_equal_per_head_launches(device, arch, B, hw):
+@pytest.mark.parametrize("arch,B,hw,tracking", [("dla_34", 2, 256, False), ("hourglass", 1, 512, False), ("dla_34", 1, 512, False),
+                                                ("dla_34", 16, 512, False), ("dla_34", 16, 512, True)])
+def test_grouped_fused_heads_equal_per_head_launches(device, arch, B, hw, tracking):
     """All fused prediction heads in ONE launch (engine.hip: fused_heads_grouped; concatenated operands, per-tile head
     table; a workgroup walks the hidden tiles of its head and finishes the maps) against one launch per head and against the
     slab + reduction-launch form: the same arithmetic in the same order -> bit-identical head tensors, sigmoid included."""
-    heads = synth.HEADS_POSE
-    sd = synth.make_state_dict(arch, heads)
-    x = synth.frames(B, seed=77, h=hw, w=hw).to(device)
-    model = hip.HipModel(arch, heads, sd, precision="f16x3")
-    z = {k: v.clone() for k, v in model(x, sigmoid_hm=True).items()}
+    # (tracking: the twelve heads of the CenterPoseTrack network -- the most a grouped launch walks -- on the two-frame inputs)
+    heads = synth.HEADS_TRACK if tracking else synth.HEADS_POSE
+    sd = synth.make_state_dict(arch, heads, tracking)
+    x, kw = mg.backbone_inputs(tracking, res=hw, seed=77, batch=B)
+    x, kw = x.to(device), {k: v.to(device) for k, v in kw.items()}
+    model = hip.HipModel(arch, heads, sd, tracking_task=tracking, precision="f16x3")
+    run = lambda: {k: v.clone() for k, v in model(x, sigmoid_hm=True, **kw).items()}
+    z = run()
     # 16777216: one launch per head; 1: one grouped launch that writes per-tile slabs + the reduction launch; 2: a workgroup
     # walks the hidden tiles of ONE head and finishes its maps (the default below 2048 patches; from there -- the B = 16 case
     # here -- a workgroup walks every head of its patch)
     for dbg in (16777216, 1, 2):
         hip.lib().cp_set_debug(dbg)
         try:
-            z1 = {k: v.clone() for k, v in model(x, sigmoid_hm=True).items()}
+            z1 = run()
         finally:
             hip.lib().cp_set_debug(0)
         for k in heads:
