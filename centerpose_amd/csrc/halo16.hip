@@ -17,6 +17,18 @@
 // H % 8 == 0, W % 16 == 0, NHWC output, no split-K.
 #include "patch16_common.h"
 
+#ifdef CP_HALO_STAMP
+// tuning build: shader-clock stamps of wave 0 of one mid-launch workgroup (tools/halo16_timeline.py)
+__device__ unsigned long long g_halo_clk[32];
+#define HALO_STAMP(i) do { if (blockIdx.x == gridDim.x / 2 + 1 && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"); \
+                                g_halo_clk[i] = clock64(); } } while (0)
+extern "C" int cp_debug_read_halo_clk(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_clk), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1;
+}
+#else
+#define HALO_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int TH = 8, TW = 16, PW = TW + 2, PH = TH + 2, NPIX = PH * PW;  // 180 patch pixels
@@ -56,6 +68,7 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
     __shared__ float sum_s[EPI == 1 ? 2 * 2 * 16 * 64 : 1];  // fuse_final: the maps summed over the tiles walked so far
 
     const int tid = threadIdx.x, lane = tid & 63;
+    HALO_STAMP(0);  // start
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar register
     const int wm = wid / WN, wn = wid % WN;
     const int tile = tile_of_block(tiles_m, tiles_n);
@@ -229,9 +242,12 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
             if (!BDIRECT) issue_b(((0 * p.Cin) + ch * CK) * 2);
             if (!FT) {
                 if (ch > 0) __syncthreads();  // every wave is done reading the previous chunk's patch
+                if (ch < 4) HALO_STAMP(1 + 4 * ch);  // chunk: previous K loop over, barrier passed
                 stage_chunk(ch);
+                if (ch < 4) HALO_STAMP(2 + 4 * ch);  // this wave's share staged
                 if (!BDIRECT) store_b(0);
                 __syncthreads();
+                if (ch < 4) HALO_STAMP(3 + 4 * ch);  // barrier passed: K loop starts
             }
             // ---- 18 K tiles: (tap, 32-channel half) ----
             auto k_tile = [&](int kt, const _Float16* Bh, const _Float16* Bl, const u32x4 (&fh)[2][NT], const u32x4 (&fl)[2][NT]) {
@@ -306,6 +322,7 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
             }
         }
 
+        HALO_STAMP(20);  // last K loop done
         // (the lane id is rebuilt here instead of living in a vector register across the K loop -- opaquely, so that the
         // unrolled tile walk does not keep one tile's epilogue addresses for the next tile's)
         int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -461,6 +478,7 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
         return;
     }
     patch_epilogue<MT, NT, WM, WN>(p, acc, b, ty0, tx0, tn, wm, wn, lane_e, ainv);
+    HALO_STAMP(21);  // epilogue done (stores acknowledged)
 }
 
 template <int MT, int NT, int WM, int WN, bool BDIRECT = false, int EPI = 0, int FT = 0>
