@@ -4,6 +4,8 @@ run the barrier-bracketed timed region with the per-step all-gather of detection
 ranks and print ONE JSON line whose n_gpus / rccl_ranks come from the group that actually ran (the
 flag used to be parsed and ignored)."""
 import json
+
+import pytest
 import os
 import subprocess
 import sys
@@ -49,14 +51,17 @@ def test_bench_eight_ranks_dress_rehearsal():
     assert "roofline" in d and "legs" in d
 
 
-def test_compact_line_keeps_every_leg_inside_the_drivers_tail():
+@pytest.mark.parametrize("record", ["r03_bench_default.json", "r04_bench_detail.json"])
+def test_compact_line_keeps_every_leg_inside_the_drivers_tail(record):
     """The driver stores an 8 KB tail of stdout: the round-3 line was longer and lost four legs.  The compact form of that very
-    record (profiles/r03_bench_default.json, a full round-3 line) must fit with every leg's value and roofline fraction."""
+    record (profiles/r03_bench_default.json, a full round-3 line) and of the round-4 full record (the detail file, with the
+    decode-only and rendered-heads legs) must fit with every leg's value and roofline fraction."""
     sys.path.insert(0, REPO)
     import bench
 
-    with open(os.path.join(REPO, "profiles", "r03_bench_default.json")) as f:
-        full = json.loads(f.read().strip().splitlines()[-1])
+    with open(os.path.join(REPO, "profiles", record)) as f:
+        text = f.read().strip()
+    full = json.loads(text if text.startswith("{\n") else text.splitlines()[-1])   # (the detail file is pretty-printed)
     line = bench.compact_line(full)
     text = json.dumps(line)
     assert len(text) < 6000, len(text)
