@@ -78,11 +78,10 @@ __device__ __forceinline__ float4 buf_ld4s(__amdgpu_buffer_rsrc_t r, unsigned vo
 // both 32-lane halves of `v` for every lane: {lower half's value, upper half's value}
 __device__ __forceinline__ void both_halves5(const uint32_t (&v)[5], uint32_t (&lo)[5], uint32_t (&hi)[5]) {
     // v_permlane32_swap_b32 vdst, vsrc exchanges vdst[32..63] with vsrc[0..31]; with both operands holding v every lane ends up
-    // with {the lower half's value, the upper half's value}.  Written out by hand, each swap on its own pair of registers and
-    // padded with wait states on both sides: one of the measures taken against the rare wrong set-up values of round 4
-    // (profiles/NOTES.md "The rare dcn16p corruption").  The compiler's sequence (v_mov tmp, x / v_permlane32_swap x, tmp /
-    // v_mov tmp, y / ...) re-writes a swap's second operand in the very next instruction; padding alone did not change the
-    // failure rate, so this is kept as a precaution, not as the explanation -- the root cause was not pinned down.
+    // with {the lower half's value, the upper half's value}.  Written out by hand, each swap on its own pair of registers with
+    // the wait states the hazard table asks for inside the statement (VALU write -> v_permlane*_swap read: 2).  (Round 4 padded
+    // these swaps while hunting wrong set-up values; the swaps were innocent -- the cause was a packed-f32 op with a set op_sel
+    // bit, profiles/NOTES.md round 5 -- but the hand-written form costs nothing and stays.)
     uint32_t a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], b0 = v[0], b1 = v[1], b2 = v[2], b3 = v[3], b4 = v[4];
     asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %5\n\ts_nop 1\n\tv_permlane32_swap_b32 %1, %6\n\ts_nop 1\n\t"
                  "v_permlane32_swap_b32 %2, %7\n\ts_nop 1\n\tv_permlane32_swap_b32 %3, %8\n\ts_nop 1\n\t"
@@ -123,9 +122,11 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     tm /= txs;
     const int ty0 = (tm % tys) * TH, b = tm / tys;
     // EARLY (tuning build 128): every prologue load -- record, first chunk, activation scale -- in flight before anything waits.
-    // OFF since round 4: it measured +-0 (the CU's fill rate bounds the prologue, profiles/NOTES.md round 3) and it is the one
-    // configuration in which about one launch in a hundred came back with 16 pixels of one wave computed from wrong bilinear
-    // set-up values (lanes 48-63 -> 16-31 of the set-up's packed-f32 arithmetic; tools/probe/dcn16p_race.py, NOTES round 4).
+    // OFF since round 4: it measured +-0 (the CU's fill rate bounds the prologue, profiles/NOTES.md round 3).  It is also the
+    // configuration in which, WITH the SLP vectorizer on, hipcc folds the set-up's two sums into a packed add with a set op_sel
+    // bit, which this part computes wrongly in lanes 48-63 beside another wave's MFMAs (root cause of round 4's "rare
+    // corruption": tools/probe/pk_opsel_lds_hazard.hip, NOTES round 5; the library is built without the vectorizer and
+    // tests/test_host_cpu.py checks the disassembly for such ops).
     constexpr bool EARLY = (CP_DCN_EXP & 128) != 0;
     float afwd, ainv;
     if (!EARLY || (CP_DCN_EXP & 131072)) {
@@ -237,8 +238,42 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
         // tap 5 lrow + j = (kh, kw): lower half (0,0) (0,1) (0,2) (1,0) (1,1); upper half (1,2) (2,0) (2,1) (2,2) (-)
         const float khf = lrow ? (float)((5 + j) / 3) : (float)(j / 3);
         const float kwf = lrow ? (float)((5 + j) % 3) : (float)(j % 3);
+#if CP_DCN_EXP & (4194304 | 8388608 | 16777216 | 33554432 | 67108864)
+        // tuning builds for the round-5 investigation (profiles/NOTES.md): with the EARLY prologue the SLP vectorizer turns the two
+        // sums into ONE packed add written over its own cross-swizzled source,
+        //     v_pk_add_f32 v[10:11], v[14:15], v[10:11] op_sel:[0,1] op_sel_hi:[1,0]     ({w_im, h_im} = {wb, hb} + {dx, dy}),
+        // and that build computes a wrong w_im in lanes 48-63 of some wave in every second launch.  Variants, everything else left
+        // to the vectorizer: 4194304 two plain v_add_f32; 8388608 / 16777216 the packed form by hand with one / four wait
+        // states behind it; 33554432 swizzled but with a separate destination; 67108864 in place but without the swizzle
+        float h_im, w_im;
+        {
+            const float hb = fy0 + khf, wb = fx0 + kwf;
+            const f32x2 base = {wb, hb};
+#if CP_DCN_EXP & 4194304
+            asm volatile("v_add_f32 %0, %2, %3\n\tv_add_f32 %1, %4, %5" : "=&v"(h_im), "=&v"(w_im) : "v"(hb), "v"(od[2 * j]), "v"(wb), "v"(od[2 * j + 1]));
+#elif CP_DCN_EXP & 33554432
+            const f32x2 pr = {od[2 * j], od[2 * j + 1]};
+            f32x2 o;
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]\n\ts_nop 0" : "=&v"(o) : "v"(base), "v"(pr));
+            w_im = o.x; h_im = o.y;
+#elif CP_DCN_EXP & 67108864
+            f32x2 o = {od[2 * j + 1], od[2 * j]};
+            asm volatile("v_pk_add_f32 %0, %1, %0\n\ts_nop 0" : "+v"(o) : "v"(base));
+            w_im = o.x; h_im = o.y;
+#else
+            f32x2 pr = {od[2 * j], od[2 * j + 1]};
+#if CP_DCN_EXP & 16777216
+            asm volatile("v_pk_add_f32 %0, %1, %0 op_sel:[0,1] op_sel_hi:[1,0]\n\ts_nop 3" : "+v"(pr) : "v"(base));
+#else
+            asm volatile("v_pk_add_f32 %0, %1, %0 op_sel:[0,1] op_sel_hi:[1,0]\n\ts_nop 0" : "+v"(pr) : "v"(base));
+#endif
+            w_im = pr.x; h_im = pr.y;
+#endif
+        }
+#else
         float h_im = (fy0 + khf) + od[2 * j];
         float w_im = (fx0 + kwf) + od[2 * j + 1];
+#endif
         const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W && !(lrow && j == 4);
         h_im = valid ? h_im : 0.f;  // keeps the arithmetic below finite; its weights are zeroed through the mask
         w_im = valid ? w_im : 0.f;
@@ -353,10 +388,9 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     const int nch = p.Cin / CKC;
 
     // blend + split of one gathered K step, then its 3 NT MFMAs
-    // `mid` runs between the blend and the MFMAs: the refill of the weight set the PREVIOUS step consumed.  It must not be issued
-    // right behind that step's MFMAs: a load that returns from L1 / L2 while the last of six back-to-back MFMAs is still reading
-    // its B operand overwrites it (seen as wrong fragment rows 16 .. 31 in the last, lonely workgroups of a launch, about one
-    // launch in 60: profiles/NOTES.md, round 4); behind the blend's ~50 VALU instructions those MFMAs have long retired.
+    // `mid` runs between the blend and the MFMAs: the refill of the weight set the PREVIOUS step consumed (two steps ahead; round 4
+    // moved it here from behind the MFMAs on a suspicion that round 5 cleared -- tools/probe/mfma_war_probe.hip finds no
+    // write-after-read hazard on MFMA operands -- and it measured the same in both places).
     auto mma_step = [&](const float4 (&r)[4][2], const f32x2 (&w)[2], const u32x4 (&bh)[NT], const u32x4 (&bl)[NT], auto&& mid) {
         // fma(w4, v4, fma(w3, v3, fma(w2, v2, w1 * v1))) per channel (dcn16.hip's order), two per v_pk_fma_f32
         uint32_t hi[4], lo[4];
@@ -588,35 +622,64 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
             const float4 v = buf_ld4(r_om, rec + 16u * i);
             o9[4 * i] = v.x; o9[4 * i + 1] = v.y; o9[4 * i + 2] = v.z; o9[4 * i + 3] = v.w;
         }
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            float h_im = (fy0 + (float)(t / 3)) + o9[2 * t];
-            float w_im = (fx0 + (float)(t % 3)) + o9[2 * t + 1];
+        // the set-up of one tap from (h_im, w_im, mask): corner address and the four weights; false if it is an exception sample
+        auto derive = [&](float h_im, float w_im, float m, int* ea, float (&e)[4]) -> bool {
             const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W;
             h_im = valid ? h_im : 0.f;
             w_im = valid ? w_im : 0.f;
-            const float mk = valid ? o9[18 + t] * afwd : 0.f;
+            const float mk = valid ? m * afwd : 0.f;
             const float fh = floorf(h_im), fw = floorf(w_im);
             const int h_lo = (int)fh, w_lo = (int)fw;
             const float lh = h_im - fh, lw = w_im - fw;
             const float hh = 1.f - lh, hw = 1.f - lw;
-            const float e1 = hh * hw * mk, e2 = hh * lw * mk, e3 = lh * hw * mk, e4 = lh * lw * mk;
+            e[0] = hh * hw * mk; e[1] = hh * lw * mk; e[2] = lh * hw * mk; e[3] = lh * lw * mk;
             const int qy = h_lo - (ty0 - HALO), qx = w_lo - (tx0 - HALO);
             const bool inp = (unsigned)qy <= (unsigned)(PH - 2) && (unsigned)qx <= (unsigned)(PW - 2);
-            const int ea = (inp ? qy * PW + qx : 0) * PSTR + lrow * 32;
+            *ea = (inp ? qy * PW + qx : 0) * PSTR + lrow * 32;
+            return !(valid && !inp);
+        };
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float hb = fy0 + (float)(t / 3), wb = fx0 + (float)(t % 3);
+            const float dy = o9[2 * t], dx = o9[2 * t + 1];
+            const float h_im = hb + dy, w_im = wb + dx;
+            int ea;
+            float e[4];
             bool bad;
-            if (valid && !inp) bad = !(addr[t] >= NPIX * PSTR || slow);  // filed as an exception (or overflow)
-            else bad = addr[t] != ea || bw[t][0].x != e1 || bw[t][0].y != e2 || bw[t][1].x != e3 || bw[t][1].y != e4;
+            if (!derive(h_im, w_im, o9[18 + t], &ea, e)) bad = !(addr[t] >= NPIX * PSTR || slow);  // filed as an exception (or overflow)
+            else bad = addr[t] != ea || bw[t][0].x != e[0] || bw[t][0].y != e[1] || bw[t][1].x != e[2] || bw[t][1].y != e[3];
             if (bad) {
+                // which wrong operand reproduces the held set-up?  The two sums are one packed add {w_im, h_im} = {wb, hb} + {dx, dy}
+                // written over its own swizzled source {dy, dx}.  Candidates (bit in the log word):
+                //   1  h_im = hb + w_im          (high pass read the low word after the low pass had written it)
+                //   2  w_im = wb + dy            (low pass read the low source word: its op_sel dropped)
+                //   4  w_im = wb + h_im          (low pass read the high word after the high pass had written it)
+                //   8  w_im = wb + dx of tap t - 1,  16  w_im = wb + dx of tap t + 1   (a neighbouring slot's operand)
+                //   32 w_im = wb + (dx + dy)     (both source words added)
+                const float cand_h[6] = {hb + w_im, h_im, h_im, h_im, h_im, h_im};
+                const float cand_w[6] = {w_im, wb + dy, wb + h_im, wb + o9[2 * (t > 0 ? t - 1 : 0) + 1], wb + o9[2 * (t < 8 ? t + 1 : 8) + 1],
+                                         wb + (dx + dy)};
+                unsigned match = 0;
+                int eb = 0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    float g[4];
+                    int ec;
+                    const bool plain = derive(cand_h[c], cand_w[c], o9[18 + t], &ec, g);
+                    const bool m = plain ? (addr[t] == ec && bw[t][0].x == g[0] && bw[t][0].y == g[1] && bw[t][1].x == g[2] &&
+                                            bw[t][1].y == g[3])
+                                         : addr[t] >= NPIX * PSTR;
+                    if (m) match |= 1u << c;
+                    if (c == 1) eb = ec;
+                }
                 const unsigned k = atomicAdd(&g_dcn_chk[0], 1u);
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    if (match & (1u << c)) atomicAdd(&g_dcn_chk[1 + c], 1u);
                 if (k < 64) {
                     unsigned* o = g_dcn_chk + 8 + 8 * k;
-                    o[0] = blockIdx.x; o[1] = tid; o[2] = t; o[3] = (unsigned)addr[t]; o[4] = (unsigned)ea;
-                    o[5] = __float_as_uint(bw[t][0].x); o[6] = __float_as_uint(e1); o[7] = (unsigned)(valid ? 1 : 0) | (inp ? 2 : 0);
-                    if (lrow && t >= 5) {  // the stale values themselves: this lane's own copy of the tap's offsets
-                        o[5] = __float_as_uint(od[2 * (t - 5)]); o[6] = __float_as_uint(od[2 * (t - 5) + 1]);
-                        o[7] = 0x80000000u | (unsigned)(((b * p.H + y) * p.W + x));
-                    }
+                    o[0] = blockIdx.x; o[1] = (unsigned)tid | (match << 16); o[2] = t; o[3] = (unsigned)addr[t]; o[4] = (unsigned)ea;
+                    o[5] = __float_as_uint(bw[t][0].x); o[6] = __float_as_uint(e[0]); o[7] = (unsigned)eb;
                 }
             }
         }

@@ -73,11 +73,10 @@ __device__ __forceinline__ float4 s_ld4s(__amdgpu_buffer_rsrc_t r, unsigned voff
 
 __device__ __forceinline__ void s_both_halves5(const uint32_t (&v)[5], uint32_t (&lo)[5], uint32_t (&hi)[5]) {
     // v_permlane32_swap_b32 vdst, vsrc exchanges vdst[32..63] with vsrc[0..31]; with both operands holding v every lane ends up
-    // with {the lower half's value, the upper half's value}.  Written out by hand, each swap on its own pair of registers and
-    // padded with wait states on both sides: one of the measures taken against the rare wrong set-up values of round 4
-    // (profiles/NOTES.md "The rare dcn16p corruption").  The compiler's sequence (v_mov tmp, x / v_permlane32_swap x, tmp /
-    // v_mov tmp, y / ...) re-writes a swap's second operand in the very next instruction; padding alone did not change the
-    // failure rate, so this is kept as a precaution, not as the explanation -- the root cause was not pinned down.
+    // with {the lower half's value, the upper half's value}.  Written out by hand, each swap on its own pair of registers with
+    // the wait states the hazard table asks for inside the statement (VALU write -> v_permlane*_swap read: 2).  (Round 4 padded
+    // these swaps while hunting wrong set-up values; the swaps were innocent -- the cause was a packed-f32 op with a set op_sel
+    // bit, profiles/NOTES.md round 5 -- but the hand-written form costs nothing and stays.)
     uint32_t a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], b0 = v[0], b1 = v[1], b2 = v[2], b3 = v[3], b4 = v[4];
     asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %5\n\ts_nop 1\n\tv_permlane32_swap_b32 %1, %6\n\ts_nop 1\n\t"
                  "v_permlane32_swap_b32 %2, %7\n\ts_nop 1\n\tv_permlane32_swap_b32 %3, %8\n\ts_nop 1\n\t"

@@ -399,16 +399,19 @@ def test_dcn_at_bench_batch_size_independent_properties(device, C, Co, HW):
         hip.set_default_precision("f32")
 
 
+@pytest.mark.parametrize("B,C,Co,HW,n", [(16, 64, 64, 128, 300), (64, 256, 256, 32, 500)])
 @pytest.mark.parametrize("kernel,dbg", [("dcn16p", 65536 | 1048576), ("dcn16s", 65536 | 2097152)])
-def test_dcn_kernels_are_stable_over_many_launches(device, kernel, dbg):
-    """Regression for a rare corruption found in round 4 (profiles/NOTES.md): about one dcn16p launch in a hundred returned 16
-    pixels of one wave computed from wrong bilinear set-up values -- only in the last workgroups of a launch with more
-    workgroups than the chip holds at once, so no single-launch parity test ever saw it.  300 launches of the heaviest layer
-    shape at 16 images (2048 patches) must all equal the gather kernel's result to summation-order round-off."""
+def test_dcn_kernels_are_stable_over_many_launches(device, kernel, dbg, B, C, Co, HW, n):
+    """Regression for the wrong set-up values found in round 4 and explained in round 5 (profiles/NOTES.md: a packed-f32 op with a
+    set op_sel bit, which the SLP vectorizer made of the set-up's two sums in the early-prologue build, is computed wrongly in
+    lanes 48-63 beside another wave's MFMAs; that build failed in 44 % of the launches of the second shape below) -- only visible
+    in launches with more workgroups than the chip holds at once and never in the same place twice, so no single-launch parity
+    test ever saw it.  300 launches of the heaviest layer shape at 16 images (2048 patches), and 500 of the shape and batch it was
+    found on (256 -> 256 @32 x 32, B = 64: 2048 workgroups, four rounds of the chip), must all equal the gather kernel's result
+    to summation-order round-off."""
     hip.set_default_precision("f16x3")
     try:
         g = torch.Generator().manual_seed(5)
-        B, C, Co, HW = 16, 64, 64, 128
         x = torch.randn(B, C, HW, HW, generator=g).to(device)
         w = (torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5).to(device)
         b = torch.randn(Co, generator=g).to(device)
@@ -420,7 +423,7 @@ def test_dcn_kernels_are_stable_over_many_launches(device, kernel, dbg):
         hip.lib().cp_set_debug(dbg)
         scale = float(ref.abs().max())
         first, worst, nbad = None, 0.0, 0
-        for _ in range(300):
+        for _ in range(n):
             y = hip.dcn_v2_forward(*args)
             if first is None:
                 first = y.clone()
@@ -554,6 +557,101 @@ def test_backbone_at_bench_batch_spot_parity(device, arch, B, pick):
     assert float((z["hm_hp"] - torch.sigmoid(zo["hm_hp"])).abs().max()) < 1e-3
     for k in ("wh", "hps", "reg", "hp_offset", "scale"):
         assert float((z[k] - zo[k]).abs().max()) < 1e-3 * max(1.0, float(zo[k].abs().max())), k
+
+
+# kernel names (cp_kernel_variant_name) every bench-size forward must have launched: the hot path of SURVEY 8(a) M2-M7
+_HOT_VARIANTS = ("halo16_head_f16x3", "halo16_f16x3_m128n128", "halo16_f16x3_m128n64", "halo16_f16x3_m128n32", "pw16_f16x3",
+                 "lowc_stem7x7", "lowc_3x3_c16", "lowc_3x3s2", "igemm16_f16x3", "dcn16s_f16x3", "dcn16p_f16x3")
+
+
+@pytest.mark.parametrize("arch,B,reps", [("dla_34", 64, 60), ("dlav1_34", 32, 60)])
+def test_backbone_at_bench_batch_every_image_every_launch(device, arch, B, reps):
+    """BASELINE configs[2] / configs[1] sizes, f16x3, EVERY image of the batch, `reps` forwards: the class of defect round 4 met in
+    dcn16p (wrong values in the last workgroups of a launch larger than the chip, one launch in a hundred) is invisible to a
+    one-image, one-launch spot check.  (1) Every forward must be bit-identical to the first; odd forwards run the batch in
+    REVERSED image order, so each image is computed by the first workgroups of a launch in one order and by the last in the
+    other -- same batch, same |max| pre-scales, same K partition => bit-equal per image; (2) every image must agree with the same
+    image inside a batch of 8 (other split-K / tile choices: float32 round-off); (3) the kernels that ran are the hot-path
+    ones."""
+    heads = synth.HEADS_POSE
+    sd = synth.make_state_dict(arch, heads)
+    x = synth.frames(B, seed=61).to(device)
+    xr = x.flip(0).contiguous()
+    model = hip.HipModel(arch, heads, sd, precision="f16x3")
+    model.profile(True)
+    z0 = {k: v.clone() for k, v in model(x, sigmoid_hm=True).items()}
+    torch.cuda.synchronize()
+    ran = model.profile_read()
+    model.profile(False)
+    for want in _HOT_VARIANTS:
+        if arch == "dlav1_34" and want == "halo16_head_f16x3":
+            continue   # its heads carry GroupNorm between the 3x3 and the 1x1 (GN.py:4-9): the plain 3x3 kernel + gn_final, no fused head
+        assert any(name.startswith(want) for name in ran), (want, sorted(ran))
+    for k in heads:
+        assert torch.isfinite(z0[k]).all(), k
+    nbad = {}
+    for it in range(1, reps):
+        z = model(xr if it & 1 else x, sigmoid_hm=True)
+        for k in heads:
+            zk = z[k].flip(0) if it & 1 else z[k]
+            if not torch.equal(zk, z0[k]):
+                d = (zk - z0[k]).abs().amax(dim=(1, 2, 3))
+                nbad.setdefault(k, []).append((it, [int(i) for i in d.nonzero().flatten().tolist()], float(d.max())))
+    assert not nbad, nbad
+    for b0 in range(0, B, 8):
+        z8 = model(x[b0:b0 + 8].contiguous(), sigmoid_hm=True)
+        for k in heads:
+            ref = z0[k][b0:b0 + 8]
+            assert float((z8[k] - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())), (k, b0)
+
+
+def _many_launches(f, n):
+    first, nbad = None, 0
+    for _ in range(n):
+        y = f()
+        if first is None:
+            first = y.clone()
+        else:
+            nbad += int(not torch.equal(y, first))
+    return first, nbad
+
+
+@pytest.mark.parametrize("name,B,H,Cin,Cout,k,stride,res,n", [
+    ("halo16 N=64 (64->64 @128^2 BasicBlock)", 32, 128, 64, 64, 3, 1, True, 200),
+    ("halo16 N=128 (256->256 @32^2)", 64, 32, 256, 256, 3, 1, True, 200),
+    ("halo16 N=32 (offset convolution 64->27)", 32, 128, 64, 27, 3, 1, False, 200),
+    ("igemm16p stride 2 (64->128 @128^2)", 32, 128, 64, 128, 3, 2, False, 200),
+    ("pw16 1x1 (128->128 @64^2)", 64, 64, 128, 128, 1, 1, False, 200),
+    ("pw16 1x1 (512->256 @16^2... Root)", 64, 16, 512, 256, 1, 1, True, 200),
+    ("lowc level0 3x3 (16->16 @512^2)", 8, 512, 16, 16, 3, 1, False, 100),
+    ("lowc level1 3x3 stride 2 (16->32)", 8, 512, 16, 32, 3, 2, False, 100),
+])
+def test_conv_kernels_are_stable_over_many_launches(device, f16x3, name, B, H, Cin, Cout, k, stride, res, n):
+    """(The 7x7 stem reads the NCHW frames and has no stand-alone entry: it runs 60 times per architecture in
+    test_backbone_at_bench_batch_every_image_every_launch.)
+    Every hot-path convolution kernel family at a launch with more workgroups than the chip holds at once, n launches: each must
+    be bit-identical to the first (no launch-to-launch variation), and the first must agree with a float64 convolution of two
+    sampled images (the first and the LAST of the batch -- the last workgroups of the launch) to the f16x3 error bound."""
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout)
+    x = torch.randn(B, H, H, Cin, generator=g).to(device)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(device)
+    affine = Cout % 32 == 0   # (the unit-test entry takes scale / shift only for whole N tiles; the 27-channel offset convolution has a bias only in the engine)
+    scale = (0.5 + torch.rand(Cout, generator=g)).to(device) if affine else None
+    shift = torch.randn(Cout, generator=g).to(device) if affine else None
+    Ho = (H + 2 * (k // 2) - k) // stride + 1
+    r = torch.randn(B, Ho, Ho, Cout, generator=g).to(device) if res else None
+    f = lambda: hip.conv2d_nhwc(x, w, scale, shift, r, stride, k // 2, 1)
+    first, nbad = _many_launches(f, n)
+    assert nbad == 0, (name, nbad)
+    for b in (0, B - 1):
+        ref = F.conv2d(x[b:b + 1].permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), None, stride, k // 2)
+        if affine:
+            ref = ref * scale.double().cpu().view(1, -1, 1, 1) + shift.double().cpu().view(1, -1, 1, 1)
+        if res:
+            ref = ref + r[b:b + 1].permute(0, 3, 1, 2).double().cpu()
+        ref = ref.clamp_min(0.0)
+        got = first[b:b + 1].permute(0, 3, 1, 2).double().cpu()
+        assert float((got - ref).abs().max()) < 3e-5 * max(1.0, float(ref.abs().max())), (name, b)
 
 
 @pytest.mark.parametrize("arch,B,hw,tracking", [("dla_34", 2, 256, False), ("hourglass", 1, 512, False), ("dla_34", 1, 512, False),

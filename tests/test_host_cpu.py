@@ -104,3 +104,35 @@ def test_detection_record_layout_matches_reference_keys():
         assert o == off
         off += w
     assert off == hip.DET_STRIDE == 118
+
+
+def test_device_code_has_no_packed_op_with_a_set_op_sel_bit(tmp_path):
+    """Guard for the hardware hazard round 5 pinned down (tools/probe/pk_opsel_lds_hazard.hip, profiles/NOTES.md): on gfx950 a
+    packed-f32 VALU op whose LOW result takes the HIGH word of a source (`op_sel:[..1..]`) returns wrong low results in lanes
+    48-63 while another wave of the SIMD issues MFMAs + LDS reads -- no wait state cures it.  The library is built with
+    -fno-slp-vectorize so that hipcc never makes such an op out of scalar float arithmetic; this test does not trust the flag:
+    it disassembles every code object of the built library and fails on any `v_pk_*` instruction with a set op_sel bit
+    (`op_sel_hi`, the broadcast form dcn16.hip uses, is measured clean)."""
+    import re
+    import shutil
+    import subprocess
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    so = tmp_path / "lib.so"
+    shutil.copy(hip.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
+    objs = sorted(p for p in tmp_path.iterdir() if "amdgcn" in p.name)
+    assert len(objs) >= 10, objs   # one code object per .hip source
+    n_insts, bad = 0, []
+    pat = re.compile(r"\bop_sel:\[[01,]*1")
+    for o in objs:
+        dis = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(o)], check=True, capture_output=True, text=True).stdout
+        for line in dis.splitlines():
+            if "v_pk_" in line:
+                n_insts += 1
+                if pat.search(line):
+                    bad.append(line.strip())
+            n_insts += 0
+    assert n_insts > 0          # the disassembly worked (dcn16.hip's broadcast FMAs are packed ops)
+    assert not bad, bad[:8]

@@ -22,12 +22,14 @@ torch.cuda.synchronize()
 hip.lib().cp_set_debug(dbg)
 scale = float(ref.abs().max())
 fails = []
+nfail = 0
 poison = torch.full_like(ref, 12345.0)
 for it in range(iters):
     y = hip.dcn_v2_forward(x, w, bias, off, mask, 3, 3, 1, 1, 1, 1, 1, 1, 1)
     bad = ((y - ref).abs() / scale) > 1e-5
     nb = int(bad.sum())
     if nb:
+        nfail += 1
         idx = bad.nonzero()
         b0, y0, x0 = int(idx[0, 0]), int(idx[:, 2].min()) // 8 * 8, int(idx[:, 3].min()) // 16 * 16
         print("iter %d: %d bad; b %s n %d..%d y %s x %d..%d" % (it, nb, sorted(set(idx[:, 0].tolist())), int(idx[:, 1].min()),
@@ -38,26 +40,17 @@ for it in range(iters):
     del y
 hip.lib().cp_set_debug(0)
 if hasattr(hip.lib(), "cp_debug_read_dcn_chk"):
-    import ctypes
+    import ctypes, struct
     buf = (ctypes.c_uint * (8 + 64 * 8))()
     hip.lib().cp_debug_read_dcn_chk(buf)
-    print("set-up self-check: %d disagreements logged" % buf[0])
-    import struct
+    print("set-up self-check: %d disagreements logged; candidates matched: h=hb+w_im %d | w=wb+dy %d | w=wb+h_im %d | w=wb+dx[t-1] %d | "
+          "w=wb+dx[t+1] %d | w=wb+dx+dy %d" % tuple(buf[0:7]))
+    f = lambda u: struct.unpack("f", struct.pack("I", u))[0]
     for k in range(min(int(buf[0]), 64)):
         o = [int(v) for v in buf[8 + 8 * k: 16 + 8 * k]]
-        f = lambda u: struct.unpack("f", struct.pack("I", u))[0]
-        if o[7] & 0x80000000:
-            pix = o[7] & 0x7fffffff
-            bb, yy, xx = pix // (hw * hw), (pix // hw) % hw, pix % hw
-            t = o[2]
-            dy, dx = f(o[5]), f(o[6])
-            m = ((off[:, 2 * t] == dy) & (off[:, 2 * t + 1] == dx)).nonzero()
-            m2 = (off == dy).nonzero()
-            print("   block %d lane %d tap %d pixel (b %d y %d x %d): holds offsets (%.6g, %.6g); expected (%.6g, %.6g); same-tap matches in the tensor: %s; dy anywhere: %s" % (
-                o[0], o[1] & 63, t, bb, yy, xx, dy, dx, float(off[bb, 2 * t, yy, xx]), float(off[bb, 2 * t + 1, yy, xx]), m[:3].tolist(), m2[:4].tolist()))
-            continue
-        print("   block %d tid %d (wave %d lane %d) tap %d: addr %d expected %d (pixels %d / %d), w1 %.6g expected %.6g, valid/inp %d" % (
-            o[0], o[1], o[1] >> 6, o[1] & 63, o[2], o[3], o[4], o[3] // 144, o[4] // 144, f(o[5]), f(o[6]), o[7]))
-print("%s: %d failing launches of %d (B %d %d->%d @%d)" % (kern, len(fails), iters, B, ci, co, hw))
+        tid = o[1] & 0xffff
+        print("   block %d wave %d lane %d tap %d: addr %d expected %d, under the hypothesis %d (%s); w1 %.6g expected %.6g" % (
+            o[0], tid >> 6, tid & 63, o[2], o[3], o[4], o[7], "match mask %d" % (o[1] >> 16), f(o[5]), f(o[6])))
+print("%s: %d failing launches of %d (B %d %d->%d @%d)" % (kern, nfail, iters, B, ci, co, hw))
 os.makedirs("gpurun_out", exist_ok=True)
 np.savez("gpurun_out/race_%s.npz" % kern, n=len(fails), **{"%s_%d" % (k, i): np.asarray(f[k]) for i, f in enumerate(fails) for k in f})
