@@ -160,6 +160,34 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
                 dbl[set][ks][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)bd_off[j], (g + ks) * 1024, 0);
             }
     };
+    // hand-pipelined K loop (BDIRECT): weight fragments WD K steps ahead in WS = WD + 1 register sets, A fragments AD steps ahead in
+    // AS = AD + 1 sets; both set counts divide the 36 steps of a chunk, so the rotation is the same in every chunk.  WD keeps the
+    // weights' lead at 18 .. 24 MFMAs (an L2 round trip under load), AD the A fragments' at >= 6 (an LDS round trip)
+    // Measured per tile shape (profiles/r05_halo16_pipe_ab.txt, same box, alternating runs): the 128-wide plain tile -2.1 %, the
+    // 32-wide tile (offset convolutions) -1.5 %, the 64-wide tile +5 % and the fused heads +5.6 % (their walk is at the register
+    // limit: the extra A set spills) -- so PIPE is on for the first two only.  The gain is small because these kernels are bound
+    // by the matrix pipe at the clock the power limit leaves, not by exposed latency.
+#ifdef CP_HALO_OLDK
+    constexpr bool PIPE = false;
+#else
+    constexpr bool PIPE = BDIRECT && EPI == 0 && MT * NT != 2;
+#endif
+    constexpr int WD = MT * NT >= 4 ? 2 : MT * NT >= 2 ? 3 : 5, WS = WD + 1;
+    constexpr int AD = MT * NT >= 2 ? 1 : 2, AS = AD + 1;
+    static_assert(36 % WS == 0 && 36 % AS == 0, "set rotation must close over a chunk");
+    u32x4 pwh[WS][NT], pwl[WS][NT];
+    h8 pah[AS][MT], pal[AS][MT];
+    auto issue_w = [&](int set, int c, int st) {
+        if (st >= 36) { st -= 36; ++c; }
+        if (c >= nchunks) return;
+        const int kt = st >> 1;
+        const int g = (kt >> 1) * gpt + 4 * c + 2 * (kt & 1) + (st & 1);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            pwh[set][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wh, (int)bd_off[j], g * 1024, 0);
+            pwl[set][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)bd_off[j], g * 1024, 0);
+        }
+    };
     // ---- stage the halo patch of one 64-channel chunk: float32 global -> hi / lo binary16 planes (called per chunk; fused heads
     // that walk several tiles: once) ----
     auto stage_chunk = [&](int ch) {
@@ -232,9 +260,14 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
 #pragma unroll
         for (int j = 0; j < NT; ++j) bd_off[j] = (unsigned)((((tn * (BN / 32) + wn * NT + j) * G) * 64 + lane_t) * 16);
 
-        if (BDIRECT) {  // the first K tiles in flight while the first patch is staged
-            issue_bd(0, 0, 0);
-            if (NSET == 3) issue_bd(1, 0, 1);
+        if (BDIRECT) {  // the first K steps' weights in flight while the first patch is staged
+            if (PIPE) {
+#pragma unroll
+                for (int st = 0; st < WD; ++st) issue_w(st, 0, st);
+            } else {
+                issue_bd(0, 0, 0);
+                if (NSET == 3) issue_bd(1, 0, 1);
+            }
         }
 
         for (int ch = 0; ch < nchunks; ++ch) {
@@ -297,7 +330,58 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
                                                  : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
             };
-            if (BDIRECT) {
+            if (PIPE) {
+                // ---- 36 K steps (tap, 32-channel half, 16-channel quarter), software-pipelined by hand (round 5): at step s the
+                //      weight fragments of step s + WD and the A fragments of step s + AD are requested, then the MT x NT x 3 MFMAs
+                //      of step s run on operands that arrived under earlier steps' MFMAs.  Before, a K tile read each A fragment
+                //      right in front of its first MFMA (`ds_read ; s_waitcnt lgkmcnt(0) ; v_mfma` -- the scheduler sinks loads to
+                //      their use when the register file is full), so each wave exposed an LDS round trip four times per 12 MFMAs
+                //      and the pipe depended on the other wave of the SIMD being ready at exactly those moments. ----
+                auto load_a = [&](int set, int st) {
+                    const int kt = st >> 1, ks = st & 1, tap = kt >> 1, half = kt & 1;
+                    const int kh = tap / 3, kw = tap - kh * 3, dq = kh * PW + kw;
+                    const int c8 = half * 4 + ks * 2 + lrow;  // 16-byte chunk of the 64-channel pixel row
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const int q = q0[i] + dq;
+                        const int o = q * PROW + ((c8 ^ pswz(q)) * 8);
+                        pah[set][i] = *reinterpret_cast<const h8*>(patch_hi + o);
+                        pal[set][i] = *reinterpret_cast<const h8*>(patch_lo + o);
+                    }
+                };
+#pragma unroll
+                for (int st = 0; st < AD; ++st) load_a(st, st);
+#pragma unroll
+                for (int st = 0; st < 36; ++st) {
+                    issue_w((st + WD) % WS, ch, st + WD);            // (that set was consumed by step st - 1)
+                    if (st + AD < 36) load_a((st + AD) % AS, st + AD);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const h8 (&ah)[MT] = pah[st % AS];
+                    const h8 (&al)[MT] = pal[st % AS];
+                    const u32x4 (&fh)[NT] = pwh[st % WS];
+                    const u32x4 (&fl)[NT] = pwl[st % WS];
+                    // (fused head: transposed product -- rows = output channels, columns = pixels)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = EPI == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&fh[j]), al[i], acc[i][j], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], *reinterpret_cast<const h8*>(&fh[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = EPI == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&fl[j]), ah[i], acc[i][j], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], *reinterpret_cast<const h8*>(&fl[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = EPI == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&fh[j]), ah[i], acc[i][j], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], *reinterpret_cast<const h8*>(&fh[j]), acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (BDIRECT) {
 #pragma unroll
                 for (int kt = 0; kt < 18; ++kt) {
                     // (phase order pinned: the scheduler would otherwise sink the loads to just above their use)

@@ -36,9 +36,11 @@ __device__ __forceinline__ uint32_t pk(float a, float b) {
     return *reinterpret_cast<uint32_t*>(&v);
 }
 
-// (a, b) -> packed hi halves and packed lo halves.  The residuals a - float(hi) come from v_fma_mix_f32, which reads
-// the binary16 half of the packed register directly (a * 1.0 - hi, exact): 4 VALU per pair instead of 6
-// (v_cvt_f32_f16 + v_sub_f32 per element) -- the conversion is most of the loaders' VALU work.
+// (a, b) -> packed hi halves and packed lo halves.  hi = RTZ(a), RTZ(b) (one v_cvt_pkrtz); the residuals a - float(hi) are
+// formed AND rounded to binary16 by v_fma_mixlo_f16 / v_fma_mixhi_f16, which read the binary16 half of the packed hi register
+// directly (a * 1.0 - hi: exact in float32, then one rounding to nearest even) and write the low / high half of the lo
+// register: 3 VALU per pair.  (Rounds 1-4 used v_fma_mix_f32 x 2 + a second v_cvt_pkrtz: 4 VALU per pair, lo rounded towards
+// zero; CP_SPLIT4 keeps that form for A/B builds.)  The split is most of the loaders' and of the DCN blend's VALU work.
 __device__ __forceinline__ Split2 split2(float a, float b) {
     Split2 s;
 #if defined(CP_DCN_EXP) && (CP_DCN_EXP & 256)
@@ -51,10 +53,15 @@ __device__ __forceinline__ Split2 split2(float a, float b) {
 #endif
     fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
     s.hi = *reinterpret_cast<uint32_t*>(&h);
+#ifdef CP_SPLIT4
     float ra, rb;
     asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a), "v"(s.hi));
     asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(b), "v"(s.hi));
     s.lo = pk(ra, rb);
+#else
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(s.lo) : "v"(a), "v"(s.hi));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(s.lo) : "v"(b), "v"(s.hi));
+#endif
     return s;
 }
 

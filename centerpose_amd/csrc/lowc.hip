@@ -55,11 +55,11 @@ struct LowcParams {
 __device__ __forceinline__ void split2(float a, float b, uint32_t* hi, uint32_t* lo) {
     fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
     *hi = *reinterpret_cast<uint32_t*>(&h);
-    float ra, rb;  // a - float(hi) straight from the packed halves (see igemm16_common.h: split2)
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a), "v"(*hi));
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(b), "v"(*hi));
-    fp16x2 l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
-    *lo = *reinterpret_cast<uint32_t*>(&l);
+    // a - float(hi) straight from the packed halves, rounded into the two halves of lo (see igemm16_common.h: split2)
+    uint32_t l;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "v"(*hi));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "v"(*hi));
+    *lo = l;
 }
 
 template <int CIN, int KS, int S, int COUT, int TW, int TH, bool NCHW_IN, int NG = 1>
