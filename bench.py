@@ -33,7 +33,11 @@ Extra objects on the ONE JSON line rank 0 prints:
                 the PnP walk of that frame's detections)
   cpu_baseline  the reference's CPU path for the same workload timed on this host's cores (BASELINE.md section 3:
                 3 warm-ups, >= 10 timed images, median): `value` = the reference as shipped (its own scalar
-                single-thread deformable im2col, oracle/_ref, + torch CPU convolutions), `fair` = the OpenMP port
+                single-thread deformable im2col, oracle/_ref, + torch CPU convolutions), `fair` = batches of 8 through the
+                OpenMP port + torch CPU convolutions, per-stage seconds (the pure-Python PnP restatement apart)
+  legs e2e_u8 / rendered_e2e
+                the chain from 8-bit HWC frames (cp_preprocess_batch in the timer; PCIe-inclusive variant beside it) and the
+                head-to-pose stage (decode + post-process + PnP) on rendered, well-posed Objectron-shaped heads
 """
 import argparse
 import json
@@ -196,12 +200,14 @@ class Pipeline(object):
 
 
 class DryPipeline(object):
-    """--dry-run: no device, no library; fixed-size records tagged with the rank so the gather can be checked."""
+    """--dry-run: no device, no library; fixed-size records tagged with the rank (field 0) and with the device index the rank
+    would bind (field 1 = LOCAL_RANK) so the gather and the rank -> device mapping can be checked."""
 
-    def __init__(self, batch, rank):
+    def __init__(self, batch, rank, local=0):
         self.batch, self.rank = batch, rank
         self.arch, self.track, self.workload = "dla_34", False, "full"
         self.det = torch.full((batch, 100, 118), float(rank), dtype=torch.float32)
+        self.det[:, :, 1] = float(local)
         self.gathered = None
 
     def step(self, x=None, graph=False):
@@ -270,8 +276,10 @@ def north_star_figures(roles, sampled, batch, precision):
     return out
 
 
-def roofline_object(prof, roles, sampled, batch, precision):
-    """`roofline` of the dominant kernel (largest share of HIP-event time inside the timed region)."""
+def roofline_object(prof, roles, sampled, batch, precision, workload=None):
+    """`roofline` of the dominant kernel (largest share of HIP-event time inside the timed region).  `traffic` (HBM-side bytes
+    per launch from the PMC passes under profiles/) is attached only when those passes profiled THIS workload at THIS batch
+    (pmc_traffic.json: _meta); for every other leg it is null -- the counters of another shape say nothing about this one."""
     if not prof:
         return None
     name, r = max(prof.items(), key=lambda kv: kv[1]["ms"])
@@ -299,10 +307,16 @@ def roofline_object(prof, roles, sampled, batch, precision):
     tr = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(tr):
         with open(tr) as f:
-            t = json.load(f).get(name)
-        if t:  # HBM-side bytes per launch from the rocprofv3 PMC passes of profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
+            pmc = json.load(f)
+        meta = pmc.get("_meta", {})
+        t = pmc.get(name)
+        if t and meta.get("workload") == workload and meta.get("batch") == batch and meta.get("precision", "f16x3") == precision:
+            # HBM-side bytes per launch from the rocprofv3 PMC passes of profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
             roof["traffic"] = t["hbm_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `%s`)" % meta.get("command", "bench.py")
+        else:
+            roof["traffic_note"] = "no PMC pass of this workload / batch under profiles/ (pmc_traffic.json profiled %s at batch %s)" % (
+                meta.get("workload"), meta.get("batch"))
     return roof
 
 
@@ -351,7 +365,7 @@ def run_leg(workload, device, precision, steps, warmup, barrier, latency, serial
            "value": round(batch * steps / dt, 2), "unit": "images/sec", "steps": steps, "warmup": warmup,
            "ms_per_step": round(dt / steps * 1e3, 3),
            "whole_step_tflops": round(batch * steps / dt * GFLOP_PER_IMG[key] / 1e3, 2),
-           "roofline": roofline_object(prof, roles, sampled, batch, precision)}
+           "roofline": roofline_object(prof, roles, sampled, batch, precision, workload)}
     if latency and workload in ("full", "decode", "hourglass"):
         out["p50_frame_ms_batch1"] = frame_latency(pipe, 30)
     del pipe
@@ -440,9 +454,91 @@ def pnp_rendered_leg(device, batch=64):
 
     ms = _event_ms(stage, 20)
     n = int(state["cnt"].sum().item())
+
+    def chain():  # the whole head-to-pose stage on well-posed detections: decode -> post-process + soft-NMS -> assembly -> solve
+        d = hip.decode_raw(z["hm"], z["hps"], z["wh"], z["hm_hp"], None, z["scale"], None, z["reg"], z["hp_offset"], None, None,
+                           K=100, rep_mode=1)
+        post, cnt = hip.postprocess(d, meta, 0.3, nms=True)
+        state["cnt2"], state["poses2"] = cnt, hip.pnp_from_post(post, cnt, cam, rep_mode=1)
+
+    ms2 = _event_ms(chain, 20)
+    n2 = int(state["cnt2"].sum().item())
+    e2e = {"workload": "Objectron-shaped rendered heads (1-10 cuboids per image), batch=%d: cp_decode + post-process + soft-NMS + "
+                       "PnP inside the timer (the head-to-pose stage of configs[2] on well-posed detections)" % batch,
+           "objects_rendered": int(sum(counts)), "detections_solved": n2, "ms_per_step": round(ms2, 3),
+           "value": round(batch / (ms2 * 1e-3), 1), "unit": "images/sec (decode + post-process + PnP)"}
     return {"workload": "Objectron-shaped rendered heads (1-10 cuboids per image), batch=%d: post-process + soft-NMS + PnP" % batch,
             "objects_rendered": int(sum(counts)), "detections_solved": n, "ms_per_batch": round(ms, 3),
-            "value": round(n / (ms * 1e-3), 1), "unit": "detections/sec (post-process + PnP)", "ms_per_step": round(ms, 3)}
+            "value": round(n / (ms * 1e-3), 1), "unit": "detections/sec (post-process + PnP)", "ms_per_step": round(ms, 3)}, e2e
+
+
+def e2e_u8_leg(device, precision, steps, warmup, barrier, batch=64):
+    """SURVEY 8(f) N1 inside the timed chain: what BaseDetector.run() starts from (base_detector.py:91-148) -- 8-bit HWC BGR
+    frames -> cp_preprocess_batch (warp + normalise on the device) -> the headline chain (network, decode, post-process, PnP).
+    Two figures: frames resident in HBM as uint8 (`value`), and frames in pinned HOST memory copied over PCIe every step on a
+    copy stream, double-buffered against the previous batch's compute (`pcie_inclusive`)."""
+    import numpy as np
+
+    from centerpose_amd import hip, synth
+    from centerpose_amd.lib.utils.image import get_affine_transform
+
+    pipe = Pipeline("full", batch, device, seed=317, precision=precision)
+    u8_host = torch.cat([synth.frames_u8(min(8, batch - i), seed=317 + i) for i in range(0, batch, 8)]).contiguous().pin_memory()
+    trans = get_affine_transform(np.array([256.0, 256.0], np.float32), 512.0, 0, [512, 512])  # fix_res, 512 x 512 frames
+    xbuf = torch.empty(batch, 3, 512, 512, device=device, dtype=torch.float32)
+
+    def step(u8):
+        hip.preprocess_batch(u8, trans, synth.MEAN, synth.STD, 512, 512, out=xbuf)
+        return pipe.step(xbuf)
+
+    u8_dev = u8_host.to(device)
+    for _ in range(warmup):
+        step(u8_dev)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(u8_dev)
+    barrier()
+    dt = time.perf_counter() - t0
+    pre_ms = _event_ms(lambda: hip.preprocess_batch(u8_dev, trans, synth.MEAN, synth.STD, 512, 512, out=xbuf), 20)
+    # PCIe-inclusive: batch i + 1 crosses the bus on the copy stream while batch i computes
+    cur, cs = torch.cuda.current_stream(), torch.cuda.Stream(device=device)
+    bufs = [torch.empty_like(u8_dev), torch.empty_like(u8_dev)]
+    copied = [torch.cuda.Event(), torch.cuda.Event()]
+    consumed = [None, None]
+
+    def fetch(j):
+        with torch.cuda.stream(cs):
+            if consumed[j] is not None:
+                cs.wait_event(consumed[j])
+            bufs[j].copy_(u8_host, non_blocking=True)
+            copied[j].record(cs)
+
+    fetch(0)
+    dt_pcie = None
+    for i in range(warmup + steps):
+        if i == warmup:
+            barrier()
+            t0 = time.perf_counter()
+        j = i & 1
+        fetch(j ^ 1)
+        cur.wait_event(copied[j])
+        step(bufs[j])
+        consumed[j] = torch.cuda.Event()
+        consumed[j].record(cur)
+    barrier()
+    dt_pcie = time.perf_counter() - t0
+    out = {"workload": "uint8 HWC frames (B = %d, 512 x 512) -> cp_preprocess_batch -> the headline chain (network, decode, "
+                       "post-process, PnP)" % batch, "precision": precision,
+           "value": round(batch * steps / dt, 2), "unit": "images/sec", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 3), "preprocess_ms_per_batch": round(pre_ms, 3),
+           "preprocess_gbps": round(batch * (512 * 512 * 3 + 512 * 512 * 12) / 1e6 / pre_ms, 1),
+           "pcie_inclusive": {"value": round(batch * steps / dt_pcie, 2), "unit": "images/sec", "ms_per_step": round(dt_pcie / steps * 1e3, 3),
+                              "host_mb_per_step": round(u8_host.numel() / 1e6, 1),
+                              "note": "pinned host frames, one copy per step on a copy stream, double-buffered"}}
+    del pipe, bufs, u8_dev, xbuf
+    torch.cuda.empty_cache()
+    return out
 
 
 def track_e2e_leg(device, precision, n_videos, frames, warmup):
@@ -618,11 +714,42 @@ def cpu_baseline(workload, arch, budget_s=45.0, n_timed=10, n_warm=3):
            "protocol": "BASELINE.md section 3: %d warm-ups, >= %d timed images (budget %.0f s), median" % (n_warm, n_timed, budget_s)}
     if omp is not None:
         omp.omp_set_num_threads(cores)
-    fair = leg("port", budget_s / 2)
-    fmed, ftext = describe(fair, "OpenMP port of the im2col on all cores + the same torch CPU convolutions / decode")
-    out["fair"] = {"value": round(1.0 / fmed, 4), "unit": "images/sec", "kind": "port", "cores": cores, "sample": ftext}
     if n_pnp:
         out["pnp_detections_per_image"] = round(sum(n_pnp) / len(n_pnp), 2)
+    # `fair`: what the same host does when it is used the way a CPU deployment would use it -- batches of 8 through the torch CPU
+    # convolutions (all cores inside every operator) with the OpenMP port of the im2col, stage by stage, so that the pure-Python
+    # float64 PnP restatement (a cost of the ORACLE, not of the reference's cv2.solvePnP) is reported separately
+    FB = 8
+
+    def one_batch(i):
+        x = torch.cat([synth.frames(1, seed=2000 + FB * i + k) for k in range(FB)])
+        t1 = time.perf_counter()
+        z = ob.dlaseg_forward(sd, x, heads, arch=arch.split("_")[0], dcn_kind="port")
+        t2 = time.perf_counter()
+        hm, hm_hp = torch.sigmoid(z["hm"]).numpy(), torch.sigmoid(z["hm_hp"]).numpy()
+        d = odec.object_pose_decode(hm, z["hps"].numpy(), wh=z["wh"].numpy(), obj_scale=z["scale"].numpy(), reg=z["reg"].numpy(),
+                                    hm_hp=hm_hp, hp_offset=z["hp_offset"].numpy(), K=100, rep_mode=1)
+        t3 = time.perf_counter()
+        if workload == "full":
+            for b in range(FB):
+                for k in np.nonzero(d["scores"][b, :, 0] > 0.3)[0]:
+                    pts = np.hstack((d["kps_displacement_mean"][b, k].reshape(8, 2), d["kps_heatmap_mean"][b, k].reshape(8, 2)))
+                    pts = np.where(pts < -5000, pts, pts * 4.0).reshape(-1, 2)
+                    opnp.solve_cuboid_pnp(pts, d["obj_scale"][b, k].astype(np.float64), Kmat)
+        t4 = time.perf_counter()
+        return t2 - t1, t3 - t2, t4 - t3
+
+    one_batch(0)  # warm-up
+    rows, t0 = [], time.perf_counter()
+    while len(rows) < 2 or (time.perf_counter() - t0 < budget_s / 2 and len(rows) < 6):
+        rows.append(one_batch(1 + len(rows)))
+    med = lambda c: statistics.median(r[c] for r in rows) / FB
+    net, dec, pnp = med(0), med(1), med(2)
+    out["fair"] = {"value": round(1.0 / (net + dec + pnp), 4), "unit": "images/sec", "kind": "port", "cores": cores, "batch": FB,
+                   "value_network_decode_only": round(1.0 / (net + dec), 4),
+                   "stages_s_per_image": {"network (torch CPU convolutions + OpenMP im2col)": round(net, 4), "decode (numpy)": round(dec, 4),
+                                          "pnp (pure-Python float64 restatement)": round(pnp, 4)},
+                   "sample": "%d timed batches of %d images after 1 warm-up batch, median per stage" % (len(rows), FB)}
     return out
 
 
@@ -654,9 +781,11 @@ def compact_line(d):
         for k in ("drawn_heads", "network_heads"):  # decode_only
             if k in v:
                 o[k] = {"us_per_batch": v[k]["us_per_batch"], "roofline": roof(v[k]["roofline"], False)}
-        for k in ("detections_solved", "objects_rendered"):  # pnp_rendered
+        for k in ("detections_solved", "objects_rendered", "preprocess_ms_per_batch"):  # pnp_rendered / rendered_e2e / e2e_u8
             if k in v:
                 o[k] = v[k]
+        if "pcie_inclusive" in v:  # e2e_u8
+            o["pcie_inclusive"] = {k: v["pcie_inclusive"][k] for k in ("value", "ms_per_step")}
         if "host_tracker" in v:  # track_e2e
             o["host_tracker_frames_per_sec"] = v["host_tracker"]["frames_per_sec"]
         return o
@@ -670,6 +799,7 @@ def compact_line(d):
         out["cpu_baseline"]["sample"] = c["sample"][:160]
         if "fair" in c:
             out["cpu_baseline"]["fair_value"] = c["fair"]["value"]
+            out["cpu_baseline"]["fair_network_decode_only"] = c["fair"].get("value_network_decode_only")
         if "pnp_detections_per_image" in c:
             out["cpu_baseline"]["pnp_detections_per_image"] = c["pnp_detections_per_image"]
     else:
@@ -745,7 +875,7 @@ def main():
         return
 
     if dry:
-        pipe = DryPipeline(batch, rank)
+        pipe = DryPipeline(batch, rank, local)
     else:
         pipe = Pipeline(args.workload, batch, device, seed=317 + 1000 * rank, precision=args.precision,
                         serial_pnp=args.serial_pnp, gather=world > 1)
@@ -768,7 +898,7 @@ def main():
     value = world * batch * args.steps / dt
 
     if rank == 0:
-        roof = None if dry else roofline_object(prof, roles, sampled, batch, args.precision)
+        roof = None if dry else roofline_object(prof, roles, sampled, batch, args.precision, args.workload)
         if roof is not None and args.workload == "full":
             ms, n = pipe.pnp_stats()
             if ms:
@@ -794,12 +924,18 @@ def main():
             w = max(1, min(args.warmup, 3))   # hundred milliseconds either way)
             legs["configs1"] = run_leg("decode", device, args.precision, max(4, min(args.steps, 12)), w, barrier,
                                        not args.no_latency)
-            for name, fn in (("decode_only", lambda: decode_only_leg(device, args.precision)),
-                             ("pnp_rendered", lambda: pnp_rendered_leg(device))):
-                try:
-                    legs[name] = fn()
-                except Exception as e:
-                    legs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                legs["decode_only"] = decode_only_leg(device, args.precision)
+            except Exception as e:
+                legs["decode_only"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                legs["pnp_rendered"], legs["rendered_e2e"] = pnp_rendered_leg(device)
+            except Exception as e:
+                legs["pnp_rendered"] = legs["rendered_e2e"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                legs["e2e_u8"] = e2e_u8_leg(device, args.precision, k, w, barrier)
+            except Exception as e:
+                legs["e2e_u8"] = {"error": "%s: %s" % (type(e).__name__, e)}
             legs["exact_f32"] = run_leg("full", device, "f32", 4, 1, barrier, False)
             for name in ("hourglass", "track", "track_gru"):
                 legs[name] = run_leg(name, device, args.precision, k, w, barrier, False)
@@ -824,6 +960,7 @@ def main():
             "dtype": "f32" if args.precision == "f32" else "f32 via split-f16 (f16x3) MFMA, f32 accumulate",
             "data": "dry-run (stub pipeline, no device work)" if dry else "synthetic",
             "rccl_ranks": rccl_ranks,
+            **({"dry_run_devices": [int(v) for v in pipe.gathered[::batch, 0, 1].tolist()]} if dry and pipe.gathered is not None else {}),
             "config": {"workload": WORKLOAD_TEXT[args.workload] % batch, "global_batch": world * batch,
                        "per_gpu_batch": batch, "input": "512x512",
                        "parallelism": "batch-shard x%d (%s)" % (

@@ -332,7 +332,7 @@ size_t cp_pnp_ws_bytes(int N);
 int cp_launch_pnp(hipStream_t s, const float* pts, const float* scale, const double* cam, int N, int npts, double* out,
                   void* ws);
 
-int cp_launch_preprocess(const unsigned char* img, int H, int W, const double* trans6, const float* mean3,
+int cp_launch_preprocess(const unsigned char* img, int B, int H, int W, const double* trans6, const float* mean3,
                          const float* std3, float* out, int OH, int OW, hipStream_t s);
 int cp_launch_resize_u8(const unsigned char* img, int H, int W, int C, unsigned char* out, int OH, int OW, hipStream_t s);
 

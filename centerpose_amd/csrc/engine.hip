@@ -1858,7 +1858,14 @@ int cp_preprocess(cp_stream_t stream, const unsigned char* image_hwc_bgr, int H,
                   const float* mean3, const float* std3, float* out_chw, int out_h, int out_w) {
     if (!image_hwc_bgr || !trans6 || !mean3 || !std3 || !out_chw || H < 1 || W < 1 || out_h < 1 || out_w < 1)
         return fail(CP_ERR_INVALID, "bad argument");
-    return cp_launch_preprocess(image_hwc_bgr, H, W, trans6, mean3, std3, out_chw, out_h, out_w, (hipStream_t)stream);
+    return cp_launch_preprocess(image_hwc_bgr, 1, H, W, trans6, mean3, std3, out_chw, out_h, out_w, (hipStream_t)stream);
+}
+
+int cp_preprocess_batch(cp_stream_t stream, const unsigned char* images_bhwc_bgr, int B, int H, int W, const double* trans6,
+                        const float* mean3, const float* std3, float* out_bchw, int out_h, int out_w) {
+    if (!images_bhwc_bgr || !trans6 || !mean3 || !std3 || !out_bchw || B < 1 || B > 65535 || H < 1 || W < 1 || out_h < 1 || out_w < 1)
+        return fail(CP_ERR_INVALID, "bad argument");
+    return cp_launch_preprocess(images_bhwc_bgr, B, H, W, trans6, mean3, std3, out_bchw, out_h, out_w, (hipStream_t)stream);
 }
 
 int cp_resize_u8(cp_stream_t stream, const unsigned char* image_hwc, int H, int W, int C, unsigned char* out_hwc, int out_h,

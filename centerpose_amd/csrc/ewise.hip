@@ -399,6 +399,8 @@ __global__ void preprocess_kernel(const unsigned char* __restrict__ img, int H, 
                                   int OW, PreParams pp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= OH * OW) return;
+    img += (size_t)blockIdx.y * H * W * 3;  // frame blockIdx.y of a batch (cp_preprocess_batch: one transform for all)
+    out += (size_t)blockIdx.y * 3 * OH * OW;
     const int y = i / OW, x = i - y * OW;
     // rint() = lrint / cvRound: round half to even
     const long long adelta = (long long)rint(pp.m[0] * (double)x * 1024.0), bdelta = (long long)rint(pp.m[3] * (double)x * 1024.0);
@@ -598,7 +600,7 @@ int cp_launch_gn_finalize(const double* stats, float* mr, int n, double count, f
     return check();
 }
 
-int cp_launch_preprocess(const unsigned char* img, int H, int W, const double* trans6, const float* mean3,
+int cp_launch_preprocess(const unsigned char* img, int B, int H, int W, const double* trans6, const float* mean3,
                          const float* std3, float* out, int OH, int OW, hipStream_t s) {
     PreParams pp;
     // cv::invertAffineTransform (float64): warpAffine without WARP_INVERSE_MAP inverts the forward matrix first
@@ -612,7 +614,7 @@ int cp_launch_preprocess(const unsigned char* img, int H, int W, const double* t
         pp.mean[i] = (double)mean3[i];
         pp.std[i] = (double)std3[i];
     }
-    hipLaunchKernelGGL(preprocess_kernel, dim3((OH * OW + 255) / 256), dim3(256), 0, s, img, H, W, out, OH, OW, pp);
+    hipLaunchKernelGGL(preprocess_kernel, dim3((OH * OW + 255) / 256, B), dim3(256), 0, s, img, H, W, out, OH, OW, pp);
     return check();
 }
 

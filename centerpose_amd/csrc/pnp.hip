@@ -436,47 +436,7 @@ __global__ __launch_bounds__(64) void pnp_kernel(const float* __restrict__ pts, 
 // Rare branches (one lane per detection whose status is -2 or -3; everything else returns at once).  Plain loops
 // over small local arrays: these run for a handful of detections, if at all.
 // ---------------------------------------------------------------------------------------------------------------
-// cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (row-major, destroyed: eigenvalues end on the diagonal);
-// V (n x n, row-major) receives the eigenvectors as COLUMNS
-__device__ void jacobi_eig(double* A, int n, double* V) {
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) V[i * n + j] = i == j ? 1.0 : 0.0;
-    double prev_off = 0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0, dia = 0;
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) {
-                if (i == j) dia += A[i * n + j] * A[i * n + j];
-                else off += A[i * n + j] * A[i * n + j];
-            }
-        if (off <= 1e-34 * dia || off == 0.0) break;
-        if (sweep > 0 && off <= 1e-24 * dia && off >= 0.25 * prev_off) break;  // the rounding floor (see jacobi_eig16)
-        prev_off = off;
-        for (int p = 0; p < n - 1; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = A[p * n + q];
-                if (fabs(apq) < 1e-300) continue;
-                const double tau = (A[q * n + q] - A[p * n + p]) / (2 * apq);
-                const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1 + tau * tau));
-                const double c = 1 / sqrt(1 + t * t), sn = t * c;
-                for (int k = 0; k < n; ++k) {
-                    const double a = A[k * n + p], b = A[k * n + q];
-                    A[k * n + p] = c * a - sn * b;
-                    A[k * n + q] = sn * a + c * b;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double a = A[p * n + k], b = A[q * n + k];
-                    A[p * n + k] = c * a - sn * b;
-                    A[q * n + k] = sn * a + c * b;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double a = V[k * n + p], b = V[k * n + q];
-                    V[k * n + p] = c * a - sn * b;
-                    V[k * n + q] = sn * a + c * b;
-                }
-            }
-    }
-}
+// (jacobi_eig: the sequential cyclic Jacobi eigen-decomposition lives in pnp_linalg.h, where the host tests build it too)
 
 #ifdef CP_PNP_TIMING
 __device__ double g_pnp_t_jacobi;  // tuning build: shader clocks of the last EPnP eigen-decomposition (one detection at a time)
@@ -925,6 +885,11 @@ __global__ __launch_bounds__(16) void pnp_rare_kernel(const float* __restrict__ 
                                                       const double* __restrict__ camp, int N, int npts,
                                                       double* __restrict__ out, const int* __restrict__ rare) {
     __shared__ double w[RARE_WS];
+    // INVARIANT: the 16 lanes of this workgroup are one (partial) wavefront and run collect / epnp / planar_init in lock-step on
+    // the ONE shared work space w[] -- every lane computes the same values and stores them to the same words (including the
+    // read-modify-write accumulations), which is only sound inside a single wavefront.  Launch it with 16 threads, never more
+    // than 64 (__launch_bounds__(16) above; a larger block is refused here rather than computing garbage).
+    if (blockDim.x != 16) return;
     if ((int)blockIdx.x >= rare[0]) return;
     const int i = rare[1 + blockIdx.x], sub = threadIdx.x;
     double* o = out + (size_t)i * CP_PNP_STRIDE;

@@ -273,3 +273,50 @@ PNP_HD_INLINE void solve6(double (&A)[36], double (&b)[6], double (&x)[6]) {
         x[r] = (A[r * 6 + r] != 0.0) ? s / A[r * 6 + r] : 0.0;
     }
 }
+
+// cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (row-major, destroyed: eigenvalues end on the diagonal);
+// V (n x n, row-major) receives the eigenvectors as COLUMNS.  FLOOR_EXIT (the product's form): besides the plain test
+// (off-diagonal mass <= 1e-34 of the diagonal's) the sweeps stop at the ROUNDING FLOOR -- once the mass is below 1e-24 of the
+// diagonal's and a whole sweep no longer quarters it, the remaining rotations turn by angles below one ulp (rank-deficient
+// matrices such as EPnP's 12 x 12 never reach 1e-34 and used to run all 60 sweeps; profiles/NOTES.md round 4).  On
+// well-conditioned matrices both forms give the same eigen-pairs (tests/test_pnp_linalg_cpu.py compares them and numpy).
+template <bool FLOOR_EXIT = true>
+PNP_HD void jacobi_eig(double* A, int n, double* V) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = i == j ? 1.0 : 0.0;
+    double prev_off = 0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0, dia = 0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                if (i == j) dia += A[i * n + j] * A[i * n + j];
+                else off += A[i * n + j] * A[i * n + j];
+            }
+        if (off <= 1e-34 * dia || off == 0.0) break;
+        if (FLOOR_EXIT && sweep > 0 && off <= 1e-24 * dia && off >= 0.25 * prev_off) break;  // the rounding floor
+        prev_off = off;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * n + q];
+                if (fabs(apq) < 1e-300) continue;
+                const double tau = (A[q * n + q] - A[p * n + p]) / (2 * apq);
+                const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1 + tau * tau));
+                const double c = 1 / sqrt(1 + t * t), sn = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double a = A[k * n + p], b = A[k * n + q];
+                    A[k * n + p] = c * a - sn * b;
+                    A[k * n + q] = sn * a + c * b;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double a = A[p * n + k], b = A[q * n + k];
+                    A[p * n + k] = c * a - sn * b;
+                    A[q * n + k] = sn * a + c * b;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double a = V[k * n + p], b = V[k * n + q];
+                    V[k * n + p] = c * a - sn * b;
+                    V[k * n + q] = sn * a + c * b;
+                }
+            }
+    }
+}

@@ -88,6 +88,8 @@ def lib():
          c_void_p, c_void_p, c_void_p, c_size_t)
     _sig(L.cp_preprocess, c_int, c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_double),
          ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_void_p, c_int, c_int)
+    _sig(L.cp_preprocess_batch, c_int, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_double),
+         ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_void_p, c_int, c_int)
     _sig(L.cp_resize_u8, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int)
     _sig(L.cp_model_set_precision, c_int, c_void_p, c_int)
     _sig(L.cp_model_profile, c_int, c_void_p, c_int)
@@ -118,7 +120,7 @@ def exported_symbols():
             "cp_model_set_param", "cp_model_finalize", "cp_model_destroy", "cp_model_workspace_bytes",
             "cp_model_forward", "cp_model_forward_tap", "cp_conv2d_workspace_bytes", "cp_conv2d_nhwc",
             "cp_decode_workspace_bytes", "cp_decode", "cp_pnp_workspace_bytes", "cp_pnp_solve", "cp_model_profile", "cp_model_profile_read",
-            "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug", "cp_preprocess", "cp_postprocess_workspace_bytes", "cp_postprocess", "cp_render_gaussians",
+            "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug", "cp_preprocess", "cp_preprocess_batch", "cp_postprocess_workspace_bytes", "cp_postprocess", "cp_render_gaussians",
             "cp_model_profile_roles", "cp_role_name", "cp_pnp_from_post_workspace_bytes", "cp_pnp_from_post", "cp_resize_u8",
             "cp_abi_version", "cp_num_kernel_variants", "cp_num_roles", "cp_track_state_bytes", "cp_track_workspace_bytes",
             "cp_track_reset", "cp_track_step", "cp_track_status"]
@@ -248,6 +250,26 @@ def preprocess(image_u8_hwc, trans_input, mean, std, out_h, out_w):
                          f3(*[float(v) for v in np.asarray(mean).reshape(-1)]),
                          f3(*[float(v) for v in np.asarray(std).reshape(-1)]), _ptr(out), out_h, out_w)
     _check(rc, "cp_preprocess")
+    return out
+
+
+def preprocess_batch(images_u8_bhwc, trans_input, mean, std, out_h, out_w, out=None):
+    """`preprocess` for B frames of one size sharing the transform: uint8 [B,H,W,3] -> float32 [B,3,out_h,out_w], one launch."""
+    import numpy as np
+
+    L = lib()
+    t = images_u8_bhwc
+    if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous() and t.dim() == 4 and t.shape[3] == 3):
+        raise RuntimeError("preprocess_batch: images must be a contiguous uint8 device tensor [B,H,W,3]")
+    B, H, W = int(t.shape[0]), int(t.shape[1]), int(t.shape[2])
+    fwd = np.asarray(trans_input, np.float64).reshape(-1)
+    f3 = ctypes.c_float * 3
+    if out is None:
+        out = torch.empty(B, 3, out_h, out_w, device=t.device, dtype=torch.float32)
+    rc = L.cp_preprocess_batch(_stream(), _ptr(t), B, H, W, (ctypes.c_double * 6)(*fwd.tolist()),
+                               f3(*[float(v) for v in np.asarray(mean).reshape(-1)]),
+                               f3(*[float(v) for v in np.asarray(std).reshape(-1)]), _ptr(out), out_h, out_w)
+    _check(rc, "cp_preprocess_batch")
     return out
 
 
@@ -469,9 +491,12 @@ def track_vmeta(metas):
 class DeviceTracker(object):
     """CenterPoseTrack's per-video track tables on the device (cp_track_*): ``step`` consumes the outputs of
     ``postprocess`` / ``pnp_from_post`` of a frame of B videos, ``render`` draws the next frame's pre_hm / pre_hm_hp from
-    the tracks, ``read`` copies the current lists to the host.  Nothing synchronises except ``read``."""
+    the tracks, ``read`` copies the current lists to the host.  ``read`` synchronises; so does ``step`` once every
+    ``STATUS_EVERY`` frames, when it looks at the overflow counters (``check``) and raises if a frame needed more than ``cap``
+    tracks -- AFTER the device state has advanced by that frame.  Set ``STATUS_EVERY = 0`` (class or instance attribute) for a
+    loop that must never synchronise or that is being captured into a hipGraph, and poll ``dropped()`` / ``check()`` yourself."""
 
-    STATUS_EVERY = 64  # frames between two looks at the overflow counters in step() (each look synchronises the stream)
+    STATUS_EVERY = 64  # frames between two looks at the overflow counters in step() (each look synchronises the stream); 0 = never
 
     def __init__(self, B, params, vmeta, device, inp_h, inp_w):
         L = lib()
@@ -505,7 +530,7 @@ class DeviceTracker(object):
         _check(lib().cp_track_step(_stream(), ctypes.byref(self.P), _ptr(self.vmeta), _ptr(post), _ptr(count), _ptr(det_pnp),
                                    self.B, _ptr(self.state), _ptr(self.recs), _ptr(self.ws), self.ws.numel()), "cp_track_step")
         self.frames += 1
-        if self.frames % self.STATUS_EVERY == 0:  # the device-resident loop never calls read(): surface overflows here
+        if self.STATUS_EVERY and self.frames % self.STATUS_EVERY == 0:  # the device-resident loop never calls read(): surface overflows here
             self.check()
 
     def dropped(self):

@@ -73,11 +73,13 @@ class BatchedTracking(object):
             self._vmeta = np.asarray(_hip.track_vmeta(metas), np.float64)
             self.dev.vmeta.copy_(torch.from_numpy(self._vmeta).reshape(B, 16))
         else:
-            # the device keeps the per-video meta (trans_input, frame size, intrinsics) of the first frame: a video whose meta
-            # changes from frame to frame is not what it tracks
-            if not np.array_equal(np.asarray(_hip.track_vmeta(metas), np.float64), self._vmeta):
-                raise RuntimeError("device tracker: per-video meta (trans_input / size / camera) changed since the first frame; "
-                                   "reset() the tracker or use the host tracker")
+            # the device keeps the per-video meta (trans_input, frame size, intrinsics).  The reference hands the tracker the
+            # CURRENT frame's meta (base_detector.py:441 with --refined_Kalman, and pnp_shell uses the frame's meta), so a video
+            # whose meta changes from frame to frame is followed by re-uploading the rows (one small copy, no synchronisation).
+            vm = np.asarray(_hip.track_vmeta(metas), np.float64)
+            if not np.array_equal(vm, self._vmeta):
+                self._vmeta = vm
+                self.dev.vmeta.copy_(torch.from_numpy(vm).reshape(B, 16))
         if self.pre_images is None:
             self.pre_images = images
         pre_hm = pre_hm_hp = None
@@ -91,9 +93,13 @@ class BatchedTracking(object):
         finally:
             det._skip_host_dets = False
         rec, cnt, poses = det.post_pnp_device(metas)
-        self.dev.step(rec, cnt, poses)
-        self.pre_images = images
-        self.frames += 1
+        try:
+            self.dev.step(rec, cnt, poses)
+        finally:
+            # (DeviceTracker.step's periodic overflow check may raise AFTER the device has advanced: keep the host's view of
+            # the loop -- previous frame, frame count -- in step with the device before the exception travels on)
+            self.pre_images = images
+            self.frames += 1
         outs = None
         if read:
             outs = []

@@ -270,10 +270,15 @@ def make_state_dict(arch="dla_34", heads=None, tracking=False, seed=DEFAULT_SEED
     return sd
 
 
+def frames_u8(batch, seed=DEFAULT_SEED, h=512, w=512):
+    """[B,h,w,3] uint8 HWC (BGR) frames: the 8-bit images `frames` normalises (what cv2.imread hands BaseDetector.pre_process)."""
+    g = _gen(seed, "frames")
+    return torch.randint(0, 256, (batch, h, w, 3), generator=g, dtype=torch.uint8)
+
+
 def frames(batch, seed=DEFAULT_SEED, h=512, w=512, device="cpu"):
     """[B,3,h,w] float32: uint8 uniform noise, BGR mean/std normalisation (base_detector.py:132)."""
-    g = _gen(seed, "frames")
-    u8 = torch.randint(0, 256, (batch, h, w, 3), generator=g, dtype=torch.uint8)
+    u8 = frames_u8(batch, seed, h, w)
     x = (u8.float() / 255.0 - torch.tensor(MEAN)) / torch.tensor(STD)
     return x.permute(0, 3, 1, 2).contiguous().to(device)
 

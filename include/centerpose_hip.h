@@ -214,6 +214,10 @@ int cp_decode(cp_stream_t stream, int B, int H, int W, float* hm, const float* h
  * ------------------------------------------------------------------------------------------ */
 int cp_preprocess(cp_stream_t stream, const unsigned char* image_hwc_bgr, int H, int W, const double* trans6,
                   const float* mean3, const float* std3, float* out_chw, int out_h, int out_w);
+/* The same warp + normalise for B frames of one size that share the transform (fix_res batches, run_batch): images DEVICE
+ * uint8 [B,H,W,3] contiguous -> out DEVICE float32 [B,3,out_h,out_w]; one launch. */
+int cp_preprocess_batch(cp_stream_t stream, const unsigned char* images_bhwc_bgr, int B, int H, int W, const double* trans6,
+                        const float* mean3, const float* std3, float* out_bchw, int out_h, int out_w);
 int cp_resize_u8(cp_stream_t stream, const unsigned char* image_hwc, int H, int W, int C, unsigned char* out_hwc,
                  int out_h, int out_w);
 
@@ -333,7 +337,11 @@ typedef struct cp_track_params {
     double new_thresh, pre_thresh, R, conf_lo, conf_hi;
     int max_age, kalman, scale_pool, use_pnp, hps_uncertainty, show_axes, cat_rule, render_hm_mode, render_hmhp_mode, pre_hm,
         pre_hm_hp, K, cap;
-    int hungarian; /* 1: optimal assignment (tracker.py:154-170, scipy's rectangular LSAP) instead of the greedy walk */
+    int hungarian; /* 1: optimal assignment (tracker.py:154-170) instead of the greedy walk.  Restates scipy's rectangular LSAP
+                    * (shortest augmenting path) operation for operation; the reference calls sklearn 0.22's linear_assignment
+                    * (Munkres, tracker.py:157).  Both are optimal, but with many 1e18 "forbidden" entries the optimum is
+                    * degenerate and the two can undo different forbidden pairs: same matching cost, possibly another order of
+                    * the left-over detections and hence of new tracking ids / coasting tracks.  The goldens are scipy's. */
     int baseline;  /* 1: Tracker_baseline (--refined_Kalman, utils/tracker_baseline.py:14-310): only (x, y) of a vertex observed,
                       plain scale average, association on raw centres against velocity-advanced track centres */
 } cp_track_params;

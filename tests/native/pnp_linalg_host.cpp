@@ -27,4 +27,9 @@ void pnp_host_solve6(double* A, double* b, double* x) {
     solve6(Am, bm, xm);
     for (int i = 0; i < 6; ++i) x[i] = xm[i];
 }
+// symmetric n x n row-major (destroyed: eigenvalues on the diagonal), V: eigenvectors as columns; floor_exit = the product's form
+void pnp_host_jacobi_eig(double* A, int n, double* V, int floor_exit) {
+    if (floor_exit) jacobi_eig<true>(A, n, V);
+    else jacobi_eig<false>(A, n, V);
+}
 }

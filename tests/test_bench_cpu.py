@@ -33,7 +33,7 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     assert d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"] == 128
     assert "configs[2]" in d["config"]["workload"] and "x2" in d["config"]["parallelism"]
     assert d["value"] > 0 and abs(d["value"] - 128 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3
-    assert d["data"].startswith("dry-run")
+    assert d["data"].startswith("dry-run") and d["dry_run_devices"] == [0, 1]
 
 
 def test_bench_single_rank_dry_run_has_no_group():
@@ -47,6 +47,7 @@ def test_bench_eight_ranks_dress_rehearsal():
     d = _run(["--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1"])
     assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["config"]["global_batch"] == 512
     assert "x8" in d["config"]["parallelism"] and d["scaling"] == "weak"
+    assert d["dry_run_devices"] == list(range(8))   # rank r would bind device LOCAL_RANK = r (one GPU per rank)
     assert isinstance(d["cpu_baseline"], dict) and "skipped" in d["cpu_baseline"]
     assert "roofline" in d and "legs" in d
 
@@ -75,3 +76,23 @@ def test_compact_line_keeps_every_leg_inside_the_drivers_tail(record):
         if full["legs"][name].get("roofline"):
             assert leg["roofline"]["frac"] > 0, name
     assert line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and line["cpu_baseline"]["cores"] == full["cpu_baseline"]["cores"]
+
+
+def test_roofline_traffic_is_attached_only_to_the_profiled_workload():
+    """profiles/pmc_traffic.json holds the PMC passes of ONE workload at ONE batch (its _meta); round 4 printed its figure for
+    the head kernel under legs of other networks and batches.  Same workload / batch / precision -> the bytes; anything else ->
+    null plus a note."""
+    sys.path.insert(0, REPO)
+    import bench
+
+    with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
+        pmc = json.load(f)
+    meta = pmc["_meta"]
+    name = "halo16_head_f16x3_m128n128"
+    assert name in pmc and meta["workload"] == "full" and meta["batch"] == 64
+    prof = {name: dict(launches=2, ms=10.0, flops=4.0e12, bytes=8.0e8)}
+    r = bench.roofline_object(prof, {}, 2, 64, "f16x3", "full")
+    assert r["traffic"] == pmc[name]["hbm_bytes_per_launch"] and "traffic_note" not in r
+    for batch, wl, prec in ((16, "full", "f16x3"), (64, "track", "f16x3"), (64, "full", "f32"), (64, None, "f16x3")):
+        r = bench.roofline_object(prof, {}, 2, batch, prec, wl)
+        assert r["traffic"] is None and "traffic_note" in r, (batch, wl, prec)

@@ -151,6 +151,27 @@ def test_device_preprocess_matches_opencv_fixed_point_emulation(device):
         np.testing.assert_array_equal(got, cv.resize_linear_u8(img, (ow, oh)))
 
 
+def test_device_preprocess_batch_equals_per_frame_calls(device):
+    """cp_preprocess_batch (B frames of one size, one transform, one launch: the uint8 entry of run_batch and of bench.py's
+    e2e_u8 leg) is bit-identical to B cp_preprocess calls; synth.frames_u8 through an identity transform reproduces synth.frames
+    (the float32 tensors the network legs are fed) to the last float32 rounding of the normalisation."""
+    from centerpose_amd.lib.utils.image import get_affine_transform
+
+    rng = np.random.RandomState(5)
+    mean = np.array([0.408, 0.447, 0.470], np.float32)
+    std = np.array([0.289, 0.274, 0.278], np.float32)
+    imgs = torch.from_numpy(rng.randint(0, 256, (3, 240, 320, 3)).astype(np.uint8)).to(device)
+    trans = get_affine_transform(np.array([160.0, 120.0], np.float32), 320.0, 0, [256, 256])
+    out = hip.preprocess_batch(imgs, trans, mean, std, 256, 256)
+    for b in range(3):
+        assert torch.equal(out[b:b + 1], hip.preprocess(imgs[b].contiguous(), trans, mean, std, 256, 256)), b
+    u8 = synth.frames_u8(2, seed=9, h=128, w=128).to(device)
+    ident = get_affine_transform(np.array([64.0, 64.0], np.float32), 128.0, 0, [128, 128])
+    x = hip.preprocess_batch(u8, ident, synth.MEAN, synth.STD, 128, 128)
+    ref = synth.frames(2, seed=9, h=128, w=128).to(device)
+    assert float((x - ref).abs().max()) < 1e-6
+
+
 def test_device_postprocess_soft_nms_matches_reference_golden(device):
     """cp_postprocess (transform + threshold + Gaussian soft-NMS on the device) against the REFERENCE's own
     post_process + merge_outputs output on the same seeded detections (tests/golden/host_post.json)."""

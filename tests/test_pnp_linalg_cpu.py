@@ -23,7 +23,7 @@ def host():
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", out])
     lib = ctypes.CDLL(out)
     for f in (lib.pnp_host_smallest_eigvec12, lib.pnp_host_smallest_eigvec9, lib.pnp_host_solve6, lib.pnp_host_rodrigues,
-              lib.pnp_host_rodrigues_nojac, lib.pnp_host_polar3, lib.pnp_host_rot_to_rvec):
+              lib.pnp_host_rodrigues_nojac, lib.pnp_host_polar3, lib.pnp_host_rot_to_rvec, lib.pnp_host_jacobi_eig):
         f.restype = None
     return lib
 
@@ -193,3 +193,36 @@ def test_polar_factor_and_rotation_vector(host):
         r = np.zeros(3)
         host.pnp_host_rot_to_rvec(_ptr(R), _ptr(r))
         np.testing.assert_allclose(opnp.rodrigues_to_matrix(r), R.reshape(3, 3), atol=2e-7 if th > 3.1 else 1e-9)
+
+
+@pytest.mark.parametrize("n", [3, 12])
+def test_jacobi_eig_floor_exit_changes_nothing_on_well_conditioned_matrices(host, n):
+    """jacobi_eig (pnp_linalg.h; the 3 x 3 decompositions of the planar / EPnP branches run it on the device): the round-4 exit
+    at the rounding floor must be invisible where the plain 1e-34 test is reachable -- same eigenvalues and eigenvectors with
+    and without it, both equal to numpy's -- and must still return a valid decomposition of a rank-deficient matrix (EPnP's
+    12 x 12 of rank <= 11-ish, the case it was added for), where the plain form needs all 60 sweeps."""
+    rng = np.random.RandomState(n)
+
+    def run(A, floor):
+        a, V = np.array(A, np.float64).copy(), np.zeros((n, n))
+        host.pnp_host_jacobi_eig(a.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(n), V.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(floor))
+        return np.diag(a).copy(), V
+
+    for trial in range(20):
+        M = rng.randn(n + 4, n)
+        A = M.T @ M + 0.1 * np.eye(n)          # well conditioned, distinct eigenvalues
+        (w1, V1), (w0, V0) = run(A, 1), run(A, 0)
+        np.testing.assert_allclose(w1, w0, rtol=1e-13, atol=1e-13 * np.abs(w0).max())
+        ref = np.linalg.eigvalsh(A)
+        np.testing.assert_allclose(np.sort(w1), ref, rtol=1e-11, atol=1e-12 * ref.max())
+        for w, V in ((w1, V1), (w0, V0)):
+            np.testing.assert_allclose(V.T @ V, np.eye(n), atol=1e-12)
+            np.testing.assert_allclose(A @ V, V * w[None, :], atol=1e-10 * ref.max())
+        # the eigenvectors agree up to sign
+        np.testing.assert_allclose(np.abs(np.sum(V1 * V0, axis=0)), np.ones(n), atol=1e-10)
+    if n == 12:  # rank-deficient: the floor exit's own case
+        M = rng.randn(7, 12)
+        A = M.T @ M
+        w1, V1 = run(A, 1)
+        np.testing.assert_allclose(A @ V1, V1 * w1[None, :], atol=1e-9 * np.abs(w1).max())
+        assert np.sum(np.abs(w1) < 1e-9 * np.abs(w1).max()) == 5

@@ -10,6 +10,9 @@ import re
 import sys
 
 fetch_csv, write_csv, out = sys.argv[1], sys.argv[2], sys.argv[3]
+# what was profiled: bench.py attaches these figures only to a leg of the same workload / batch / precision
+meta = {"workload": sys.argv[4] if len(sys.argv) > 4 else "full", "batch": int(sys.argv[5]) if len(sys.argv) > 5 else 64,
+        "precision": sys.argv[6] if len(sys.argv) > 6 else "f16x3", "command": sys.argv[7] if len(sys.argv) > 7 else "bench.py"}
 
 
 def variant(kname):
@@ -71,5 +74,6 @@ for k in f:
     wb = (w[k][1] / w[k][0] * 1024) if k in w else 0.0
     res[k] = {"launches_sampled": f[k][0], "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
               "hbm_bytes_per_launch": round(fb + wb), "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE x1; KiB units"}
+res["_meta"] = meta
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print("wrote", out, len(res), "kernels")

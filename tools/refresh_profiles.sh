@@ -21,7 +21,7 @@ if [ "${1:-}" != "quick" ]; then
   timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python $R/bench.py --steps 3 --warmup 1 $B > $O/fetch.log 2>&1
   timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python $R/bench.py --steps 3 --warmup 1 $B > $O/write.log 2>&1
   python $R/tools/pmc_to_json.py $(find $O/fetch -name "*counter_collection.csv" | head -1) \
-         $(find $O/write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json
+         $(find $O/write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json full 64 f16x3 "bench.py --steps 3 --warmup 1 $B"
 fi
 cd $R
 rm -rf $O/kt $O/kt1 $O/fetch $O/write

@@ -1,10 +1,11 @@
 #!/bin/bash
-# Round-4 artefacts on the GPU box -> gpurun_out/r04/ (copied into profiles/r04_* afterwards):
+# A round's artefacts on the GPU box -> gpurun_out/<tag>/ (copied into profiles/<tag>_* afterwards):
 #   full GPU test suite, the default bench line (+ detail file), rocprofv3 kernel-trace stats of the bench command, the SQ
 #   counter passes (tools/pmc_sq.txt, one --pmc line per run) and the FETCH_SIZE / WRITE_SIZE passes, the DCN A/B per layer
-#   shape, the batch-1 frame trace, the PnP micro-benchmark.    usage: tools/refresh_r04.sh [quick]
+#   shape, the batch-1 frame trace, the PnP micro-benchmark.    usage: tools/refresh_round.sh <tag, e.g. r05> [quick]
 set -u
-R=$PWD; O=$R/gpurun_out/r04; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
+TAG=${1:?usage: tools/refresh_round.sh <tag> [quick]}; shift
+R=$PWD; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6 | tee $O/pytest_gpu.txt
 CP_BENCH_DETAIL=$O/bench_detail.json timeout 1200 python bench.py 2>$O/bench_default.err | tail -1 > $O/bench_default.json
 B="--no-cpu-baseline --no-latency --no-legs"
@@ -24,7 +25,7 @@ if [ "${1:-}" != "quick" ]; then
   timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python $R/bench.py --steps 3 --warmup 1 $B > $O/fetch.log 2>&1
   timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python $R/bench.py --steps 3 --warmup 1 $B > $O/write.log 2>&1
   python $R/tools/pmc_to_json.py $(find $O/fetch -name "*counter_collection.csv" | head -1) \
-         $(find $O/write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json
+         $(find $O/write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json full 64 f16x3 "bench.py --steps 3 --warmup 1 $B"
   rm -rf $O/sq1 $O/sq2 $O/sq3 $O/kt2 $O/fetch $O/write
   rm -rf /tmp/ab && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ab -- python $R/tools/dcn_ab.py --b 64 > $O/dcn_ab_run.txt 2>&1
   (cd $R && python tools/dcn_ab.py --parse /tmp/ab --b 64 > $O/dcn_ab.txt 2>&1)
