@@ -413,19 +413,34 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
         if (EPI == 1) asm volatile("" : "+v"(lane_e));
         if constexpr (EPI == 1) {
             // ---- fused prediction head (the arithmetic of igemm16.hip's FUSE epilogue on this kernel's pixel order) ----
+            // Round 5: every table of this epilogue (scale / shift, 1x1 fragments, w2_inv, bias, the output maps) sits behind a
+            // scalar buffer descriptor and is read 16 bytes at a time -- the per-lane part of an address is one small offset
+            // (half-wave x 16 B, or lane x 16 B), everything else scalar.  Before, each of the ~130 table reads and 32 stores of a
+            // tile was a 4-byte access with its own 64-bit address arithmetic (292 v_lshl_add_u64 + 236 v_add_u32 + 535 v_mov in
+            // the kernel: 2.4 non-MFMA VALU per MFMA, all of it issued while the wave's MFMAs stand still).  Heads that finish in
+            // the kernel (FT) have at most 16 final channels = accumulator rows r < 8 of the second product: the rest is padding
+            // and is no longer scaled, exchanged or summed.  Same operations on the same values in the same order: bit-identical.
             const int M = p.B * p.H * p.W;
             // head of this N tile (several heads in one launch: ConvParams::fuse_ngroups), its channel count and first plane
             const int hg = p.fuse_ngroups > 0 ? tn / p.fuse_gtiles : 0;
             const int c2 = p.fuse_ngroups > 0 ? p.fuse_gc2[hg] : p.fuse_c2;
             const int plane0 = p.fuse_ngroups > 0 ? p.fuse_gbase[hg] + (tn - hg * p.fuse_gtiles) * c2 : tn * p.fuse_c2;
-            const u32x4* w2h = reinterpret_cast<const u32x4*>(p.fuse_w2_hi) + (size_t)((tn * WN + wn) * 4) * 64 + lane_e;
-            const u32x4* w2l = reinterpret_cast<const u32x4*>(p.fuse_w2_lo) + (size_t)((tn * WN + wn) * 4) * 64 + lane_e;
+            constexpr int RN = FT ? 8 : 16;  // accumulator rows of the second product that hold real channels
+            const int h4e = lane_e >> 5;
+            const unsigned v16 = (unsigned)(h4e * 16), vlane = (unsigned)(lane_e * 16);
+            auto ld4so = [](__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) -> float4 {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
+                return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            };
+            const __amdgpu_buffer_rsrc_t r_w2h = make_rsrc(p.fuse_w2_hi, 0x7ffffff0u), r_w2l = make_rsrc(p.fuse_w2_lo, 0x7ffffff0u);
+            const int w2s = ((tn * WN + wn) * 4) * 1024;  // this N tile's four 1 KB fragments (scalar)
             h8 wh[2][2], wl[2][2];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    const u32x4 a = w2h[(j * 2 + ks) * 64], c = w2l[(j * 2 + ks) * 64];
+                    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r_w2h, (int)vlane, w2s + (j * 2 + ks) * 1024, 0);
+                    const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(r_w2l, (int)vlane, w2s + (j * 2 + ks) * 1024, 0);
                     wh[j][ks] = *reinterpret_cast<const h8*>(&a);
                     wl[j][ks] = *reinterpret_cast<const h8*>(&c);
                 }
@@ -436,18 +451,30 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
                 for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
             const bool relu = p.act == CP_ACT_RELU;
             float hmax = 0.f;
+            {
+                // accumulator r of a lane = hidden channel (r & 3) + 8 (r >> 2) + 4 h4 of the fragment: four groups of four
+                // consecutive channels -> one 16-byte read per group of the scale and of the shift table
+                const __amdgpu_buffer_rsrc_t r_sc = make_rsrc(p.scale, (unsigned)p.CoutPad * 4u), r_sh = make_rsrc(p.shift, (unsigned)p.CoutPad * 4u);
+                const int ch0 = (tn * BN + wn * 64) * 4;  // bytes (scalar)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < 2; ++j) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ch = tn * BN + wn * 64 + j * 32 + F::row(r, lane_e);
-                    const float sc = (p.scale ? p.scale[ch] : 1.f) * ainv, sh = p.shift ? p.shift[ch] : 0.f;
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 s4 = p.scale ? ld4so(r_sc, v16, ch0 + (j * 32 + 8 * g) * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+                        const float4 b4 = p.shift ? ld4so(r_sh, v16, ch0 + (j * 32 + 8 * g) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float se[4] = {s4.x, s4.y, s4.z, s4.w}, be[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        float x = acc[i][j][r] * sc + sh;
-                        if (relu) x = fmaxf(x, 0.f);
-                        acc[i][j][r] = x;
-                        hmax = fmaxf(hmax, fabsf(x));
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * g + e;
+                            const float sc = se[e] * ainv, sh = be[e];
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                float x = acc[i][j][r] * sc + sh;
+                                if (relu) x = fmaxf(x, 0.f);
+                                acc[i][j][r] = x;
+                                hmax = fmaxf(hmax, fabsf(x));
+                            }
+                        }
                     }
                 }
             }
@@ -479,26 +506,49 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
             }
             __syncthreads();  // the previous tile's partial maps have been read
             float* red = red_s;  // [wm][i][r][lane]
+            {
+                const __amdgpu_buffer_rsrc_t r_wi = make_rsrc(p.fuse_w2_inv, 0x7ffffff0u);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float wi = (p.fuse_w2_inv ? p.fuse_w2_inv[hg * 64 + F::row(r, lane_e)] : 1.f) * hinv;
-                acc2[0][r] *= wi;
-                acc2[1][r] *= wi;
+                for (int g = 0; g < RN / 4; ++g) {
+                    const float4 w4 = p.fuse_w2_inv ? ld4so(r_wi, v16, (hg * 64 + 8 * g) * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    const float we[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float wi = we[e] * hinv;
+                        acc2[0][4 * g + e] *= wi;
+                        acc2[1][4 * g + e] *= wi;
+                    }
+                }
             }
             if (wn == 1) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) red[((wm * 2 + i) * 16 + r) * 64 + lane_e] = acc2[i][r];
+                    for (int r = 0; r < RN; ++r) red[((wm * 2 + i) * 16 + r) * 64 + lane_e] = acc2[i][r];
             }
             __syncthreads();
             if (wn == 0) {
+                const int HW = p.H * p.W;
+                // the finished maps of head hg, image b: channel c of this lane's row group, pixel pix -> byte (c HW + pix) 4 of
+                // [c2][HW]; channels >= c2 fall outside the descriptor (and are skipped before the sigmoid anyway)
+                const __amdgpu_buffer_rsrc_t r_go = make_rsrc(FT ? p.fuse_gout[hg] + (size_t)b * c2 * HW : nullptr, (unsigned)(c2 * HW) * 4u);
+                const __amdgpu_buffer_rsrc_t r_gb = make_rsrc(FT ? p.fuse_gbias[hg] : nullptr, (unsigned)c2 * 4u);
+                float bias_e[RN] = {};
+                if (FT && t2 + 1 == ntl) {
+#pragma unroll
+                    for (int g = 0; g < RN / 4; ++g) {
+                        const float4 b4 = p.fuse_gbias[hg] ? ld4so(r_gb, v16, 8 * g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        bias_e[4 * g] = b4.x; bias_e[4 * g + 1] = b4.y; bias_e[4 * g + 2] = b4.z; bias_e[4 * g + 3] = b4.w;
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int ml = wm * 64 + i * 32 + (lane_e & 31);  // tile row -> patch pixel (ml / 16, ml % 16)
                     const int m = (b * p.H + ty0 + (ml >> 4)) * p.W + tx0 + (ml & 15);
+                    const int pix = (ty0 + (ml >> 4)) * p.W + tx0 + (ml & 15);
+                    const unsigned vout = (unsigned)((4 * h4e) * HW + pix) * 4u;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
+                    for (int r = 0; r < RN; ++r) {
                         const int c = F::row(r, lane_e);
                         const float v = acc2[i][r] + red[((wm * 2 + i) * 16 + r) * 64 + lane_e];
                         if (!FT) {
@@ -511,10 +561,9 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
                         const float vs = (t2 == 0 ? 0.f : *run) + v;
                         if (t2 + 1 < ntl) *run = vs;
                         else if (c < c2) {
-                            float y = vs + (p.fuse_gbias[hg] ? p.fuse_gbias[hg][c] : 0.f);
+                            float y = vs + bias_e[r];
                             if (p.fuse_gsig[hg]) y = 1.f / (1.f + expf(-y));
-                            const int HW = p.H * p.W, pix = (ty0 + (ml >> 4)) * p.W + tx0 + (ml & 15);
-                            p.fuse_gout[hg][((size_t)b * c2 + c) * HW + pix] = y;
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), r_go, (int)vout, ((r & 3) + 8 * (r >> 2)) * HW * 4, 0);
                         }
                     }
                 }
@@ -607,6 +656,9 @@ static bool halo16_fused_geometry(const ConvParams& p) {
 // fused prediction head on the halo-resident kernel (same operands as cp_launch_conv16_fused_head)
 bool cp_halo16_fused_head_supported(const ConvParams& p) {
     if (p.fuse_final && (p.fuse_ngroups < 1 || p.Cin != CK || p.fuse_gtiles != 2 || p.CoutPad != p.fuse_ngroups * 256)) return false;
+    if (p.fuse_final)  // the in-kernel finish keeps 16 final channels per head (accumulator rows r < 8 of the second product)
+        for (int g = 0; g < p.fuse_ngroups; ++g)
+            if (p.fuse_gc2[g] > 16) return false;
     return halo16_fused_geometry(p) && p.CoutPad % 128 == 0 && p.fuse_w2_hi && p.fuse_w2_lo && (p.fuse_out || p.fuse_final);
 }
 int cp_launch_halo16_fused_head(const ConvParams& p, hipStream_t stream) {
