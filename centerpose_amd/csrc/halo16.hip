@@ -15,6 +15,8 @@
 // order than igemm16p_kernel (results agree to float32 round-off, both inside the parity budget).
 // Requirements (else the launcher falls back to igemm16p_kernel): 3x3, stride 1, pad 1, one source, Cin % 64 == 0,
 // H % 8 == 0, W % 16 == 0, NHWC output, no split-K.
+#include <type_traits>
+
 #include "patch16_common.h"
 
 #ifdef CP_HALO_STAMP
@@ -467,19 +469,30 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
                         for (int e = 0; e < 4; ++e) {
                             const int r = 4 * g + e;
                             const float sc = se[e] * ainv, sh = be[e];
-#pragma unroll
-                            for (int i = 0; i < 2; ++i) {
-                                float x = acc[i][j][r] * sc + sh;
-                                if (relu) x = fmaxf(x, 0.f);
-                                acc[i][j][r] = x;
-                                hmax = fmaxf(hmax, fabsf(x));
-                            }
+                            float x0 = acc[0][j][r] * sc + sh, x1 = acc[1][j][r] * sc + sh;
+                            if (relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+                            acc[0][j][r] = x0;
+                            acc[1][j][r] = x1;
+                            hmax = fmaxf(fmaxf(hmax, fabsf(x0)), fabsf(x1));  // (one v_max3_f32)
                         }
                     }
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) hmax = fmaxf(hmax, __shfl_xor(hmax, o, 64));
+            // the wave's maximum without LDS round trips (six ds_bpermute + waits stood here): four DPP steps leave every row of 16
+            // lanes with its maximum, four v_readlane + scalar max finish it -- the result and the scale pair are wave-uniform
+            {
+                auto dppmax = [](float v, auto ctrl) {
+                    return fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(v), __float_as_uint(v), decltype(ctrl)::value, 0xf, 0xf, false)));
+                };
+                hmax = dppmax(hmax, std::integral_constant<int, 0xB1>());   // quad_perm [1,0,3,2]
+                hmax = dppmax(hmax, std::integral_constant<int, 0x4E>());   // quad_perm [2,3,0,1]
+                hmax = dppmax(hmax, std::integral_constant<int, 0x141>());  // row_half_mirror
+                hmax = dppmax(hmax, std::integral_constant<int, 0x140>());  // row_mirror
+                const unsigned hb = __float_as_uint(hmax);  // (non-negative floats order like their bit patterns)
+                const unsigned m01 = max((unsigned)__builtin_amdgcn_readlane((int)hb, 0), (unsigned)__builtin_amdgcn_readlane((int)hb, 16));
+                const unsigned m23 = max((unsigned)__builtin_amdgcn_readlane((int)hb, 32), (unsigned)__builtin_amdgcn_readlane((int)hb, 48));
+                hmax = __uint_as_float(max(m01, m23));
+            }
             float hfwd, hinv;
             cp_amax_to_scale(__float_as_uint(hmax), &hfwd, &hinv);
 #pragma unroll
