@@ -1,13 +1,15 @@
 #!/bin/bash
 # A/B of library builds on one GPU box: alternating short bench runs, per-kernel ms per step side by side.
-#   usage: tools/ab_bench.sh OUTDIR REPS LIB_SUFFIX...      ("" = the product library, "_x" = centerpose_amd/libcenterpose_hip_x.so)
+#   usage: tools/ab_bench.sh OUTDIR REPS VARIANT...   ("" = the product library, "_x" = centerpose_amd/libcenterpose_hip_x.so,
+#                                                      "@N" = the product library under cp_set_debug N: bench.py --dbg N)
 set -u
 R=$PWD; O=$1; REPS=$2; shift 2; mkdir -p $O; export TMPDIR=/tmp
 for rep in $(seq 1 $REPS); do
   for v in "$@"; do
-    n=${v:-_prod}
-    CP_BENCH_DETAIL=$O/detail$n.$rep.json CENTERPOSE_HIP_LIB=$R/centerpose_amd/libcenterpose_hip$v.so \
-      timeout 300 python bench.py --steps 20 --warmup 5 --no-legs --no-cpu-baseline --no-latency > $O/line$n.$rep.json 2>/dev/null
+    n=${v:-_prod}; lib=$v; dbg=0
+    case "$v" in @*) lib=""; dbg=${v#@};; esac
+    CP_BENCH_DETAIL=$O/detail$n.$rep.json CENTERPOSE_HIP_LIB=$R/centerpose_amd/libcenterpose_hip$lib.so \
+      timeout 300 python bench.py --steps 20 --warmup 5 --no-legs --no-cpu-baseline --no-latency --dbg $dbg > $O/line$n.$rep.json 2>/dev/null
   done
 done
 python - $O $REPS "$@" <<'PY'
