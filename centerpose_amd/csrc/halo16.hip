@@ -517,8 +517,12 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
                     }
                 }
             }
-            __syncthreads();  // the previous tile's partial maps have been read
-            float* red = red_s;  // [wm][i][r][lane]
+            // exchange buffer of the two hidden halves' partial maps, [wm][i][r][lane].  FT (8 real rows): two half-size buffers
+            // used alternately, so ONE barrier per tile orders everything -- tile t + 2 re-uses tile t's buffer, and tile t's
+            // readers have arrived at tile t + 1's barrier by then.  Slab form: one buffer, a barrier in front as well.
+            if (!FT) __syncthreads();  // the previous tile's partial maps have been read
+            float* red = FT ? red_s + ((hw * ntl + t2) & 1) * (2 * 2 * 8 * 64) : red_s;
+            constexpr int RS = FT ? 8 : 16;  // rows per (wm, i) block of `red`
             {
                 const __amdgpu_buffer_rsrc_t r_wi = make_rsrc(p.fuse_w2_inv, 0x7ffffff0u);
 #pragma unroll
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < RN; ++r) red[((wm * 2 + i) * 16 + r) * 64 + lane_e] = acc2[i][r];
+                    for (int r = 0; r < RN; ++r) red[((wm * 2 + i) * RS + r) * 64 + lane_e] = acc2[i][r];
             }
             __syncthreads();
             if (wn == 0) {
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
 #pragma unroll
                     for (int r = 0; r < RN; ++r) {
                         const int c = F::row(r, lane_e);
-                        const float v = acc2[i][r] + red[((wm * 2 + i) * 16 + r) * 64 + lane_e];
+                        const float v = acc2[i][r] + red[((wm * 2 + i) * RS + r) * 64 + lane_e];
                         if (!FT) {
                             if (c < c2) p.fuse_out[((size_t)plane0 + c) * M + m] = v;
                             continue;
