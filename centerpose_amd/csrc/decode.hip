@@ -7,7 +7,7 @@
 //   peaks_kernel   one workgroup (1024 lanes = 16 wavefronts) per (image, map): the map is read once (coalesced
 //                  16-byte loads, optional in-place sigmoid) into LDS, NMS from LDS, then an exact radix select of
 //                  the K largest (value desc, index asc) on register-resident keys -- over the positive keys only
-//                  when they fill the top K -- and a 128-wide bitonic sort of the winners in LDS.
+//                  when they fill the top K -- and a rank sort of the winners in LDS.
 //   assoc_kernel   one workgroup per (image, joint): candidate table in LDS, one lane per detection
 //                  scans the K candidates (float ops in the reference's order, no FMA contraction so
 //                  argmin / threshold decisions match the CPU bit for bit).
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(PK_THREADS) void peaks_kernel(float* __restrict__ h
     __shared__ int hist[256];
     __shared__ int scan_sh[34];
     __shared__ int sel[2];  // digit, need
-    __shared__ unsigned long long list[128];
+    __shared__ unsigned long long list[128], sorted[128];
     __shared__ int cnt;
     const int tid = threadIdx.x;
 
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(PK_THREADS) void peaks_kernel(float* __restrict__ h
     int total_eq;
     block_sum2(my_eq, 0, scan_sh, &total_eq, &dummy);
     if (tid == 0) cnt = 0;
-    if (tid < 128) list[tid] = 0ull;
+    if (tid < 128) list[tid] = sorted[tid] = 0ull;
     __syncthreads();
     const bool all_eq = total_eq <= need;  // no tie at the threshold: every equal key is taken, no ranking needed
     int taken_before = 0;                  // equal keys in lower-indexed groups (pixel order: group, lane, element)
@@ -250,25 +250,19 @@ __global__ __launch_bounds__(PK_THREADS) void peaks_kernel(float* __restrict__ h
         }
     }
     __syncthreads();
-    // ---- bitonic sort (descending) of 128 64-bit keys ----
-    for (int k2 = 2; k2 <= 128; k2 <<= 1) {
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            if (tid < 128) {
-                const int ixj = tid ^ j;
-                if (ixj > tid) {
-                    const unsigned long long a = list[tid], c = list[ixj];
-                    const bool desc = ((tid & k2) == 0);
-                    if (desc ? (a < c) : (a > c)) {
-                        list[tid] = c;
-                        list[ixj] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
+    // ---- order the (at most 128, pairwise different) winners, largest first: every key counts the keys above it and goes to
+    //      that position.  128 broadcast LDS reads per lane and ONE barrier where the bitonic network of rounds 1-4 took 28
+    //      barriers of a 16-wave workgroup (a fifth of the kernel at batch 1).  Empty slots (0) all land behind the winners. ----
+    if (tid < 128) {
+        const unsigned long long mine = list[tid];
+        int rank = 0;
+#pragma unroll 16
+        for (int j = 0; j < 128; ++j) rank += list[j] > mine ? 1 : 0;
+        sorted[mine ? rank : 127] = mine;  // (K <= 128: when 128 real keys exist there is no empty slot to collide with rank 127)
     }
+    __syncthreads();
     if (tid < K) {
-        const unsigned long long e = list[tid];
+        const unsigned long long e = sorted[tid];
         const size_t o = ((size_t)b * nm + mi) * K + tid;
         pk_score[o] = ord2f((uint32_t)(e >> 32));
         pk_ind[o] = (int)(0xffffffffu - (uint32_t)(e & 0xffffffffull));
