@@ -35,12 +35,14 @@ namespace {
 
 constexpr int TH = 8, TW = 16, PW = TW + 2, PH = TH + 2, NPIX = PH * PW;  // 180 patch pixels
 constexpr int CK = 64;                                                    // channels per staged chunk
-constexpr int PROW = CK;                                                  // halfs per patch pixel and plane (128 B)
+constexpr int PROW = CK + 8;                                              // halfs per patch pixel and plane: 128 B of data + 16 B pad
 
-// chunk c (8 halfs) of patch pixel q sits at position c ^ (q & 7): lanes of a fragment read consecutive pixels, so a
-// ds_read_b128 group of 8 lanes covers all 8 sixteen-byte slots of the 128-byte row (conflict-free), and the staging
-// writes of 8 lanes (one pixel, 8 chunks) do too
-__device__ __forceinline__ int pswz(int q) { return q & 7; }
+// Pixel pitch 144 B = 9 sixteen-byte bank groups (round 5; rounds 2-4: 128 B with the chunk index XOR-ed by the pixel number).
+// Lanes of a fragment read consecutive pixels at the same chunk: 9 is odd, so the 16 lanes of a ds_read_b128 group start in 16
+// different bank groups -- conflict-free without a swizzle, and therefore every fragment address of a tile is ONE per-lane base
+// (pixel of the fragment row, k half) plus a compile-time offset (tap, channel chunk).  With the XOR each of the 72 (pixel, chunk)
+// combinations of a tile needed its own ~3 VALU of address arithmetic, which the compiler hoists in front of every tile's K loop:
+// 270 of the ~850 non-MFMA VALU per hidden tile of the fused heads (SQ_INSTS_VALU, profiles/r05_pmc_sq_counters.txt).
 
 // BDIRECT: the weight fragments of the 32-wide N tile come from global memory / L2 straight into the MFMA operand
 // registers, two K tiles ahead, out of the fragment-ordered copy of the weights (ConvParams::w16f_*, one coalesced 1 KB
@@ -67,7 +69,8 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
     __shared__ __attribute__((aligned(16))) _Float16 patch_lo[NPIX * PROW];
     __shared__ __attribute__((aligned(16))) _Float16 bt[BDIRECT ? 1 : 2][BDIRECT ? 8 : 2 * B_SZ];  // [buffer][hi | lo]
     __shared__ float red_s[EPI == 1 ? 2 * 2 * 16 * 64 : 1];  // fused head: the second hidden half's partial maps [wm][i][r][lane]
-    __shared__ float sum_s[EPI == 1 ? 2 * 2 * 16 * 64 : 1];  // fuse_final: the maps summed over the tiles walked so far
+                                                              // (FT: two buffers of 8 rows, used alternately)
+    __shared__ float sum_s[(EPI == 1 && FT) ? 2 * 2 * 8 * 64 : 1];  // fuse_final: the maps summed over the tiles walked so far (8 real rows)
 
     const int tid = threadIdx.x, lane = tid & 63;
     HALO_STAMP(0);  // start
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
                 if (q < NPIX) {
                     const float4 v = sv[s];
                     const Split2 h0 = split2(v.x * afwd, v.y * afwd), h1 = split2(v.z * afwd, v.w * afwd);
-                    const int col = ((((c4c >> 1) ^ pswz(q)) << 1) | (c4c & 1)) * 4;  // halfs
+                    const int col = c4c * 4;  // halfs
                     *reinterpret_cast<u32x2*>(patch_hi + q * PROW + col) = u32x2{h0.hi, h1.hi};
                     *reinterpret_cast<u32x2*>(patch_lo + q * PROW + col) = u32x2{h0.lo, h1.lo};
                 }
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
                         const int q = q0[i] + dq;
-                        const int o = q * PROW + ((c8 ^ pswz(q)) * 8);
+                        const int o = q * PROW + c8 * 8;
                         ah[i] = *reinterpret_cast<const h8*>(patch_hi + o);
                         al[i] = *reinterpret_cast<const h8*>(patch_lo + o);
                     }
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
                         const int q = q0[i] + dq;
-                        const int o = q * PROW + ((c8 ^ pswz(q)) * 8);
+                        const int o = q * PROW + c8 * 8;
                         pah[set][i] = *reinterpret_cast<const h8*>(patch_hi + o);
                         pal[set][i] = *reinterpret_cast<const h8*>(patch_lo + o);
                     }
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
                         }
                         // head_reduce_grouped_kernel's arithmetic: tiles summed in index order from 0, + bias, sigmoid
                         // (the running sum lives in LDS, each lane its own word: 32 registers less across the K loop)
-                        float* run = sum_s + ((wm * 2 + i) * 16 + r) * 64 + lane_e;
+                        float* run = sum_s + ((wm * 2 + i) * 8 + r) * 64 + lane_e;
                         const float vs = (t2 == 0 ? 0.f : *run) + v;
                         if (t2 + 1 < ntl) *run = vs;
                         else if (c < c2) {

@@ -30,6 +30,7 @@ if [ "${1:-}" != "quick" ]; then
   rm -rf /tmp/ab && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ab -- python $R/tools/dcn_ab.py --b 64 > $O/dcn_ab_run.txt 2>&1
   (cd $R && python tools/dcn_ab.py --parse /tmp/ab --b 64 > $O/dcn_ab.txt 2>&1)
   (cd $R && timeout 300 python tools/pnp_bench.py > $O/pnp_bench.txt 2>&1)
+  (cd $R && hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize tools/probe/pk_opsel_lds_hazard.hip -o /tmp/hz 2>/dev/null && timeout 120 /tmp/hz 20000 > $O/pk_opsel_lds_hazard.txt 2>&1)
   (cd $R && timeout 400 bash tools/frame_trace.sh dla_34 > /dev/null 2>&1; cp gpurun_out/frame_trace_dla_34.txt $O/ 2>/dev/null)
 fi
 cd $R
