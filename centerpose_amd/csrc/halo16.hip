@@ -168,14 +168,15 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
     // hand-pipelined K loop (BDIRECT): weight fragments WD K steps ahead in WS = WD + 1 register sets, A fragments AD steps ahead in
     // AS = AD + 1 sets; both set counts divide the 36 steps of a chunk, so the rotation is the same in every chunk.  WD keeps the
     // weights' lead at 18 .. 24 MFMAs (an L2 round trip under load), AD the A fragments' at >= 6 (an LDS round trip)
-    // Measured per tile shape (profiles/r05_halo16_pipe_ab.txt, same box, alternating runs): the 128-wide plain tile -2.1 %, the
-    // 32-wide tile (offset convolutions) -1.5 %, the 64-wide tile +5 % and the fused heads +5.6 % (their walk is at the register
-    // limit: the extra A set spills) -- so PIPE is on for the first two only.  The gain is small because these kernels are bound
-    // by the matrix pipe at the clock the power limit leaves, not by exposed latency.
+    // Measured per tile shape (profiles/r05_halo16_pipe_ab.txt, same box, alternating runs).  With the XOR-swizzled patch image
+    // (rounds 2-4) the pipelined loop paid only where registers were left: 128-wide plain tile -2.1 %, 32-wide tile -1.5 %, but
+    // 64-wide tile +5 % and fused heads +5.6 % (their extra A set spilled).  With the padded image (no address registers: 176 ..
+    // 201 VGPRs instead of 256) it pays everywhere: heads -2.6 %, 64-wide tile -3 %, the rest -0.5 % -- so it is the loop of every
+    // BDIRECT kernel.  A third workgroup per CU for the 128-wide plain tile (168 registers) measured +-0 and is not used.
 #ifdef CP_HALO_OLDK
     constexpr bool PIPE = false;
 #else
-    constexpr bool PIPE = BDIRECT && EPI == 0 && MT * NT != 2;
+    constexpr bool PIPE = BDIRECT;
 #endif
     constexpr int WD = MT * NT >= 4 ? 2 : MT * NT >= 2 ? 3 : 5, WS = WD + 1;
     constexpr int AD = MT * NT >= 2 ? 1 : 2, AS = AD + 1;
