@@ -243,12 +243,15 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
     for (int hw = 0; hw < nwalk; ++hw)
 #pragma unroll
     for (int t2 = 0; t2 < ntl; ++t2) {
+        // (FT && PIPE: one chunk per tile -- the first K step's MFMAs take a literal zero as C instead: no 64 v_mov per tile)
+        if (!(FT && PIPE)) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+                for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < F::NACC; ++r) acc[i][j][r] = 0.f;
+                    for (int r = 0; r < F::NACC; ++r) acc[i][j][r] = 0.f;
+        }
 
         // ---- fragment geometry: row m of the tile = pixel (m / 16, m % 16); lane reads rows lcol + 32 i + 32 MT wm ----
         // (derived from a lane id the compiler cannot see through, once per hidden tile: otherwise the unrolled walk shares the
@@ -367,12 +370,15 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
                     const u32x4 (&fh)[NT] = pwh[st % WS];
                     const u32x4 (&fl)[NT] = pwl[st % WS];
                     // (fused head: transposed product -- rows = output channels, columns = pixels)
+                    const acc_t zero_c = {};
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = EPI == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&fh[j]), al[i], acc[i][j], 0, 0, 0)
-                                                 : __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], *reinterpret_cast<const h8*>(&fh[j]), acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NT; ++j) {
+                            const acc_t c_in = (FT && st == 0) ? zero_c : acc[i][j];
+                            acc[i][j] = EPI == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&fh[j]), al[i], c_in, 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], *reinterpret_cast<const h8*>(&fh[j]), c_in, 0, 0, 0);
+                        }
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -450,11 +456,7 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
                     wh[j][ks] = *reinterpret_cast<const h8*>(&a);
                     wl[j][ks] = *reinterpret_cast<const h8*>(&c);
                 }
-            acc_t acc2[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
+            acc_t acc2[2];  // (started by a literal-zero C in the first product below)
             const bool relu = p.act == CP_ACT_RELU;
             float hmax = 0.f;
             {
@@ -462,25 +464,32 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
                 // consecutive channels -> one 16-byte read per group of the scale and of the shift table
                 const __amdgpu_buffer_rsrc_t r_sc = make_rsrc(p.scale, (unsigned)p.CoutPad * 4u), r_sh = make_rsrc(p.shift, (unsigned)p.CoutPad * 4u);
                 const int ch0 = (tn * BN + wn * 64) * 4;  // bytes (scalar)
+                // (the activation is decided once per tile, not per element: as `if (relu) x = max(x, 0)` inside the loops it compiled
+                // to a v_max + v_cndmask pair per accumulator)
+                auto scale_shift = [&](auto relu_c) {
+                    constexpr bool RELU = decltype(relu_c)::value;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < 2; ++j) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 s4 = p.scale ? ld4so(r_sc, v16, ch0 + (j * 32 + 8 * g) * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
-                        const float4 b4 = p.shift ? ld4so(r_sh, v16, ch0 + (j * 32 + 8 * g) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        const float se[4] = {s4.x, s4.y, s4.z, s4.w}, be[4] = {b4.x, b4.y, b4.z, b4.w};
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 s4 = p.scale ? ld4so(r_sc, v16, ch0 + (j * 32 + 8 * g) * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+                            const float4 b4 = p.shift ? ld4so(r_sh, v16, ch0 + (j * 32 + 8 * g) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            const float se[4] = {s4.x, s4.y, s4.z, s4.w}, be[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int r = 4 * g + e;
-                            const float sc = se[e] * ainv, sh = be[e];
-                            float x0 = acc[0][j][r] * sc + sh, x1 = acc[1][j][r] * sc + sh;
-                            if (relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
-                            acc[0][j][r] = x0;
-                            acc[1][j][r] = x1;
-                            hmax = fmaxf(fmaxf(hmax, fabsf(x0)), fabsf(x1));  // (one v_max3_f32)
+                            for (int e = 0; e < 4; ++e) {
+                                const int r = 4 * g + e;
+                                const float sc = se[e] * ainv, sh = be[e];
+                                float x0 = acc[0][j][r] * sc + sh, x1 = acc[1][j][r] * sc + sh;
+                                if (RELU) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+                                acc[0][j][r] = x0;
+                                acc[1][j][r] = x1;
+                                hmax = fmaxf(fmaxf(hmax, fabsf(x0)), fabsf(x1));  // (one v_max3_f32)
+                            }
                         }
                     }
-                }
+                };
+                if (relu) scale_shift(std::true_type());
+                else scale_shift(std::false_type());
             }
             // the wave's maximum without LDS round trips (six ds_bpermute + waits stood here): four DPP steps leave every row of 16
             // lanes with its maximum, four v_readlane + scalar max finish it -- the result and the scale pair are wave-uniform
@@ -515,7 +524,8 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
                         }
                         const u32x4 vh = {hh[0], hh[1], hh[2], hh[3]}, vl = {hl[0], hl[1], hl[2], hl[3]};
                         const h8 bhh = *reinterpret_cast<const h8*>(&vh), bhl = *reinterpret_cast<const h8*>(&vl);
-                        acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j][ks], bhh, acc2[i], 0, 0, 0);
+                        const acc_t zero_c2 = {};
+                        acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j][ks], bhh, (j == 0 && ks == 0) ? zero_c2 : acc2[i], 0, 0, 0);
                         acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j][ks], bhl, acc2[i], 0, 0, 0);
                         acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j][ks], bhh, acc2[i], 0, 0, 0);
                     }
