@@ -197,9 +197,8 @@ __global__ __launch_bounds__(256, (BDIRECT && EPI == 0 && MT * NT <= 2) ? 3 : 2)
     // ---- stage the halo patch of one 64-channel chunk: float32 global -> hi / lo binary16 planes (called per chunk; fused heads
     // that walk several tiles: once) ----
     auto stage_chunk = [&](int ch) {
-        // all loads of a round are issued before the first conversion: one HBM round trip per round instead of one per
-        // slot (the round size is what the register file leaves: 6 slots next to 128 accumulators' worth of state)
-        constexpr int SR = (BDIRECT || MT * NT >= 4) ? 6 : 12;
+        // all loads of a chunk are issued before the first conversion: one HBM round trip per chunk
+        constexpr int SR = 12;  // (rounds 2-4: two rounds of 6 where the XOR-swizzled image left no registers; one round now: offset convolutions -2.4 %)
         // the thread id is rebuilt per chunk (not held in a vector register across the K loop)
         int lane_c = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         asm volatile("" : "+v"(lane_c));
