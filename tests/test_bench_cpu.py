@@ -52,7 +52,7 @@ def test_bench_eight_ranks_dress_rehearsal():
     assert "roofline" in d and "legs" in d
 
 
-@pytest.mark.parametrize("record", ["r03_bench_default.json", "r04_bench_detail.json"])
+@pytest.mark.parametrize("record", ["r03_bench_default.json", "r04_bench_detail.json", "r05_bench_detail.json"])
 def test_compact_line_keeps_every_leg_inside_the_drivers_tail(record):
     """The driver stores an 8 KB tail of stdout: the round-3 line was longer and lost four legs.  The compact form of that very
     record (profiles/r03_bench_default.json, a full round-3 line) and of the round-4 full record (the detail file, with the
@@ -65,7 +65,7 @@ def test_compact_line_keeps_every_leg_inside_the_drivers_tail(record):
     full = json.loads(text if text.startswith("{\n") else text.splitlines()[-1])   # (the detail file is pretty-printed)
     line = bench.compact_line(full)
     text = json.dumps(line)
-    assert len(text) < 6000, len(text)
+    assert len(text) < 8000, len(text)   # (the driver keeps an 8 KB tail; round 5's line with the e2e_u8 / rendered_e2e legs: 4.7 KB)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config"):
         assert k in line
