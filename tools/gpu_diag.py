@@ -1,6 +1,6 @@
-"""GPU diagnostic sweep (test infrastructure, not collected by pytest): runs every kernel family against the CPU oracle and prints one
+"""GPU diagnostic sweep (test infrastructure: imports the oracle; a tool, not a pytest module): runs every kernel family against the CPU oracle and prints one
 line per case without stopping at the first mismatch.  Usage on the GPU box:
-    python tests/gpu_diag.py [--full | --f16x3 | --decode-only | --pnp-only]      (output is also what gpurun shows in its tail)
+    python tools/gpu_diag.py [--full | --f16x3 | --decode-only | --pnp-only]      (output is also what gpurun shows in its tail)
 """
 import os
 import sys
