@@ -442,10 +442,66 @@ __global__ void splitk_epilogue_kernel(const ConvParams p) {
     }
     if (p.out_amax) cp_amax_commit(p.out_amax, amax);
 }
+
+// The same for NHWC outputs with whole channel quads (every split-K layer of the networks): one lane = four consecutive
+// channels of a pixel, ALL slab reads (<= 32 slices x 16 bytes) in flight at once behind one buffer descriptor (slices beyond
+// splitk read out of range = exact zeros), then the sum in slice order -- one memory round trip.  The element-wise form above
+// keeps 8 four-byte loads in flight and walks 32 slices in four dependent rounds: 6.5 us per launch, 48 launches = 0.31 ms of a
+// 1.43 ms batch-1 frame (profiles/r05_frame_trace_dla_34.txt).  Same additions in the same order: bit-identical.
+typedef uint32_t sk_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void splitk_epilogue4_kernel(const ConvParams p) {
+    const int M = p.B * p.Ho * p.Wo, C4 = p.Cout >> 2;
+    const int total = M * C4;
+    float afwd = 1.f, ainv = 1.f, amax = 0.f;
+    const AmaxRaw amax_raw = conv_in_scale_issue(p);
+    bool have_scale = false;
+    const unsigned slab = (unsigned)M * (unsigned)p.CoutPad * 4u;  // bytes per slice
+    const __amdgpu_buffer_rsrc_t rp = make_rsrc(p.partial, slab * (unsigned)p.splitk);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int m = i / C4, n = (i - m * C4) << 2;
+        const unsigned off = ((unsigned)m * (unsigned)p.CoutPad + (unsigned)n) * 4u;
+        sk_u32x4 v[32];
+#pragma unroll
+        for (int z = 0; z < 32; ++z) v[z] = __builtin_amdgcn_raw_buffer_load_b128(rp, (int)off, (int)((unsigned)z * slab), 0);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int z = 0; z < 32; ++z) {
+            a0 += __uint_as_float(v[z].x); a1 += __uint_as_float(v[z].y); a2 += __uint_as_float(v[z].z); a3 += __uint_as_float(v[z].w);
+        }
+        const float4 sc = p.scale ? *reinterpret_cast<const float4*>(p.scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 sh = p.shift ? *reinterpret_cast<const float4*>(p.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 rs = p.res ? *reinterpret_cast<const float4*>(p.res + (size_t)m * p.res_ld + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!have_scale) {
+            conv_in_scale_finish(p, amax_raw, &afwd, &ainv);
+            have_scale = true;
+        }
+        float y[4] = {a0 * (sc.x * ainv) + sh.x, a1 * (sc.y * ainv) + sh.y, a2 * (sc.z * ainv) + sh.z, a3 * (sc.w * ainv) + sh.w};
+        const float re[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (p.res) y[e] += re[e];
+            if (p.act == CP_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
+            else if (p.act == CP_ACT_SIGMOID || (p.act == CP_ACT_SIGMOID_FROM && n + e >= p.act_from)) y[e] = 1.f / (1.f + expf(-y[e]));
+            amax = fmaxf(amax, fabsf(y[e]));
+        }
+        *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + p.coff + n) = make_float4(y[0], y[1], y[2], y[3]);
+    }
+    if (p.out_amax) cp_amax_commit(p.out_amax, amax);
+}
 }  // namespace
 
 int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream) {
     const size_t total = (size_t)p.B * p.Ho * p.Wo * p.Cout;
+    const size_t slab_bytes = (size_t)p.B * p.Ho * p.Wo * p.CoutPad * 4;
+    const bool quad = p.store == CP_STORE_NHWC && p.Cout % 4 == 0 && p.CoutPad % 4 == 0 && p.ldo % 4 == 0 && p.coff % 4 == 0 &&
+                      (!p.res || p.res_ld % 4 == 0) && p.splitk <= 32 && slab_bytes * 32 < (size_t)0xf0000000u &&
+                      total / 4 < (size_t)0x7fffffff && !(p.dbg & 8);  // (cp_set_debug 8: the element-wise form, A/B)
+    if (quad) {
+        int g = (int)((total / 4 + 255) / 256);
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(splitk_epilogue4_kernel, dim3(g), dim3(256), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+    }
     int g = (int)((total + 255) / 256);
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(g), dim3(256), 0, stream, p);
