@@ -386,6 +386,25 @@ __global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel
 #if CP_EXP & 256
 __device__ unsigned long long g_cp_clk[2];  // shader-clock / 100 MHz-clock ticks of workgroup 0 (tuning: actual frequency)
 #endif
+#if CP_EXP & 512
+// tuning build 512: 100 MHz-clock stamps of workgroup (0, 0) of the last 64 igemm16p_kernel launches at their phase boundaries
+// (tools/probe/small_launch_timeline.py): [launch % 64][0 .. 8] stamps, [9 .. 15] Cin, Cout, M, splitk, K tiles of the slice, PD, shader clocks entry -> end
+__device__ unsigned long long g_cp_tl[64 * 16 + 1];
+#define CP_TL_INIT() unsigned tl_slot = 0; if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) \
+    tl_slot = (unsigned)(atomicAdd(&g_cp_tl[64 * 16], 1ull) & 63ull); \
+    const unsigned long long tl_c0 = clock64()
+#define CP_TL(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_cp_tl[tl_slot * 16 + (i)] = wall_clock64(); } while (0)
+#define CP_TL_VAL(i, v) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_cp_tl[tl_slot * 16 + (i)] = (unsigned long long)(v); } while (0)
+#define CP_TL_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+extern "C" int cp_debug_read_tl(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cp_tl), sizeof(unsigned long long) * (64 * 16 + 1)) == hipSuccess ? 0 : -1;
+}
+#else
+#define CP_TL_INIT() do { } while (0)
+#define CP_TL_VAL(i, v) do { } while (0)
+#define CP_TL(i) do { } while (0)
+#define CP_TL_DRAIN() do { } while (0)
+#endif
 // FUSE (128x128 tiles only): fused prediction head.  The main MFMAs run with swapped operands, so a wave's accumulators
 // hold hidden^T -- rows = 32 hidden channels of a fragment spread over (register, lane half), columns = 32 pixels over
 // the lanes.  That is exactly the B-operand shape of a second MFMA whose k runs over hidden channels: 8 consecutive
@@ -423,6 +442,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
 #if CP_EXP & 256
     const unsigned long long clk0 = clock64(), wclk0 = wall_clock64();
 #endif
+    CP_TL_INIT();
+    CP_TL(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = tid >> 6;
@@ -634,6 +655,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
     h8 f0ah[MT], f0al[MT], f0bh[NT], f0bl[NT], f1ah[MT], f1al[MT], f1bh[NT], f1bl[NT];
 
     // one iteration: `cur` = t & 1; the register set holds tile t+1 (stored in phase 1, refilled with tile t+2 in phase 2)
+    // (Four register sets = four K tiles in flight for the batch-1 launches were measured in round 5 and not kept: the K loop
+    // of such a launch is a single wave per SIMD issuing ~100 instructions per tile in order, not a memory round trip per
+    // tile -- profiles/r05_small_launch_timeline.txt, NOTES.)
     auto iteration = [&](int cur) {
         // ---------------- phase 1 ----------------
         constexpr int P1 = NR + 4 * A_SLOTS + 2 * B_SLOTS;
@@ -689,15 +713,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
     };
 
     // ---- prologue: tile 0 in buffer 0, tile 1 in the register set ----
+    CP_TL_VAL(9, p.Cin); CP_TL_VAL(10, p.Cout); CP_TL_VAL(11, M); CP_TL_VAL(12, p.splitk); CP_TL_VAL(13, n); CP_TL_VAL(14, 1);
+    CP_TL(1);
     issue_tile(ga, gbh, gbl);
+    CP_TL(2);
     if (!GNIN) conv_in_scale_finish(p, amax_raw, &afwd, &ainv);
+    CP_TL(3);
+    CP_TL_DRAIN();
+    CP_TL(4);
     store_all(0, ga, gbh, gbl, 2);
     issue_tile(ga, gbh, gbl);
     __syncthreads();
+    CP_TL(5);
 #pragma unroll
     for (int r = 0; r < NR; ++r) read_frag(0, 0, r, f0ah, f0al, f0bh, f0bl);
 
     for (int t = 0; t < n; ++t) iteration(t & 1);
+    CP_TL(6);
     if ((CP_EXP & 16) && acc[0][0][0] != 12345.f) return;
     if constexpr (FUSE) {
         const int g = lane >> 5;
@@ -848,6 +880,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
     }
     if (p.splitk > 1) igemm_store_partial<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane, blockIdx.y);
     else igemm_epilogue<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane, ainv);
+    CP_TL(7);
+    CP_TL_DRAIN();
+    CP_TL(8);
+    CP_TL_VAL(15, clock64() - tl_c0);
 #if CP_EXP & 256
     if (blockIdx.x == 4000 && threadIdx.x == 0) {
         g_cp_clk[0] = clock64() - clk0;
