@@ -627,12 +627,12 @@ def _many_launches(f, n):
     ("igemm16p stride 2 (64->128 @128^2)", 32, 128, 64, 128, 3, 2, False, 200),
     ("pw16 1x1 (128->128 @64^2)", 64, 64, 128, 128, 1, 1, False, 200),
     ("pw16 1x1 (512->256 @16^2... Root)", 64, 16, 512, 256, 1, 1, True, 200),
-    ("lowc level0 3x3 (16->16 @512^2)", 8, 512, 16, 16, 3, 1, False, 100),
-    ("lowc level1 3x3 stride 2 (16->32)", 8, 512, 16, 32, 3, 2, False, 100),
+    ("exact-f32 igemm, level0's shape (16->16 @512^2; Cin 16 is not a split-f16 shape of the unit-test entry)", 8, 512, 16, 16, 3, 1, False, 100),
+    ("exact-f32 igemm, level1's shape (16->32 stride 2)", 8, 512, 16, 32, 3, 2, False, 100),
 ])
 def test_conv_kernels_are_stable_over_many_launches(device, f16x3, name, B, H, Cin, Cout, k, stride, res, n):
-    """(The 7x7 stem reads the NCHW frames and has no stand-alone entry: it runs 60 times per architecture in
-    test_backbone_at_bench_batch_every_image_every_launch.)
+    """(The first three layers' lowc kernels have no stand-alone entry: test_first_layers_are_stable_over_many_launches below, and
+    60 forwards per architecture in test_backbone_at_bench_batch_every_image_every_launch.)
     Every hot-path convolution kernel family at a launch with more workgroups than the chip holds at once, n launches: each must
     be bit-identical to the first (no launch-to-launch variation), and the first must agree with a float64 convolution of two
     sampled images (the first and the LAST of the batch -- the last workgroups of the launch) to the f16x3 error bound."""
@@ -656,6 +656,22 @@ def test_conv_kernels_are_stable_over_many_launches(device, f16x3, name, B, H, C
         ref = ref.clamp_min(0.0)
         got = first[b:b + 1].permute(0, 3, 1, 2).double().cpu()
         assert float((got - ref).abs().max()) < 3e-5 * max(1.0, float(ref.abs().max())), (name, b)
+
+
+def test_first_layers_are_stable_over_many_launches(device):
+    """lowc.hip (7x7 stem, level0, level1 -- 8 % of the step) at launches larger than the chip: the level1 activation of a batch of
+    16 frames (tap), 100 forwards, odd ones with the batch in reversed image order: per image bit-identical to the first forward."""
+    heads = synth.HEADS_POSE
+    model = hip.HipModel("dla_34", heads, synth.make_state_dict("dla_34", heads), precision="f16x3")
+    x = synth.frames(16, seed=5).to(device)
+    xr = x.flip(0).contiguous()
+    _, first = model.forward(x, tap="base.level1")
+    first = first.clone()
+    assert first.shape == (16, 32, 256, 256) and float(first.abs().max()) > 0
+    for it in range(100):
+        _, t = model.forward(xr if it % 2 else x, tap="base.level1")
+        t = t.flip(0) if it % 2 else t
+        assert torch.equal(t, first), it
 
 
 @pytest.mark.parametrize("arch,B", [("dla_34", 1), ("dlav1_34", 2), ("hourglass", 1)])
