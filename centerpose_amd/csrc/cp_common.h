@@ -190,7 +190,7 @@ int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream);
 // K steps (of 16 for the f32 kernels, 32 for f16x3) and output tiles of the launch cp_launch_conv[16] would make
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 38
+#define CP_NUM_CONV_VARIANTS 39
 #define CP_VARIANT_GRU 26
 // split-f16 ("f16x3") implicit GEMM (igemm16.hip)
 bool cp_conv16_supported(const ConvParams& p);
@@ -212,10 +212,12 @@ int cp_launch_pw16(const ConvParams& p, hipStream_t stream);
 bool cp_dcn16p_supported(const ConvParams& p);
 int cp_dcn16p_blocks(const ConvParams& p);
 int cp_launch_dcn16p(const ConvParams& p, hipStream_t stream);
+bool cp_dcn16p_wide(const ConvParams& p);  // the launch takes the 128-wide N tile (NT = 4)
 // dcn16s.hip: the same gather as a persistent kernel with the halo streamed by LDS-DMA into two 16-channel buffers
 // (launches with several (patch, N tile) items per resident workgroup)
 #define CP_VARIANT_DCN16S 36
 #define CP_VARIANT_M64N64 37  // igemm16p on 64 x 64 tiles (small launches)
+#define CP_VARIANT_DCN16PW 38  // dcn16p on the 128-wide N tile
 bool cp_dcn16s_supported(const ConvParams& p);
 int cp_dcn16s_items(const ConvParams& p);
 int cp_launch_dcn16s(const ConvParams& p, hipStream_t stream);

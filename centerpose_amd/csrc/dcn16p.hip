@@ -366,18 +366,33 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
 
     // ---- weight fragments: (n tile j of 32, K step g of 16) = 1 KB in lane order at ((j G + g) 64 + lane) 16 B ----
     const int G = p.Kpad16 / 16, gpt = p.Cin / 16;  // K steps per weight row / per tap
+    const int nch_w = p.Cin / CKC;
     unsigned b_voff[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) b_voff[j] = (unsigned)(((tn * NT + j) * G) * 1024 + lane * 16);
     // step u of chunk ch = (tap u / 2, 16-channel half u % 2): K step g = tap * (Cin / 16) + 2 ch + (u % 2)
-    u32x4 wbh[3][NT], wbl[3][NT];  // register set u % 3 (18 steps per chunk keep the rotation consistent)
-    auto issue_b = [&](int set, int g) {
+    // A weight register set holds the fragments of NW = 2 N tiles of one K step.  NT = 2: one set per step, set u % 3.  NT = 4 (the
+    // 128-wide N tile, round 5): a step is NH = 2 half-steps -- the same A fragment against N tiles {0, 1}, then {2, 3} -- and the
+    // sets rotate per half-step, so the weights' lead (two half-steps = 12 MFMAs) and their registers are those of the 64-wide kernel
+    // while the gather, the blend and the split of a step are done once for twice the outputs.  (18 NH half-steps per chunk keep the
+    // rotation consistent across chunks.)
+    constexpr int NW = 2, NH = NT / NW, NHS = NSTEP * NH;
+    static_assert(NT % NW == 0 && NHS % 3 == 0, "weight set rotation");
+    u32x4 wbh[3][NW], wbl[3][NW];
+    auto issue_b = [&](int set, int g, int h) {
         if (ABL && (abl & 8)) return;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            wbh[set][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wh, (int)b_voff[j], g * 1024, 0);
-            wbl[set][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)b_voff[j], g * 1024, 0);
+        for (int j = 0; j < NW; ++j) {
+            wbh[set][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wh, (int)b_voff[h * NW + j], g * 1024, 0);
+            wbl[set][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)b_voff[h * NW + j], g * 1024, 0);
         }
+    };
+    // half-step s of chunk ch (s may run into the next chunk): K step u = s / NH = (tap u / 2, 16-channel half u % 2), N-tile pair s % NH
+    auto issue_hs = [&](int s, int ch) {
+        if (s >= NHS) { s -= NHS; ++ch; }
+        if (ch >= nch_w) return;
+        const int u = s / NH;
+        issue_b(s % 3, (u >> 1) * gpt + 2 * ch + (u & 1), s % NH);
     };
 
     acc_t acc[1][NT];
@@ -388,10 +403,11 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     const int nch = p.Cin / CKC;
 
     // blend + split of one gathered K step, then its 3 NT MFMAs
-    // `mid` runs between the blend and the MFMAs: the refill of the weight set the PREVIOUS step consumed (two steps ahead; round 4
-    // moved it here from behind the MFMAs on a suspicion that round 5 cleared -- tools/probe/mfma_war_probe.hip finds no
-    // write-after-read hazard on MFMA operands -- and it measured the same in both places).
-    auto mma_step = [&](const float4 (&r)[4][2], const f32x2 (&w)[2], const u32x4 (&bh)[NT], const u32x4 (&bl)[NT], auto&& mid) {
+    // `mid(h)` runs between the blend and the MFMAs of half-step h: the refill of the weight set the PREVIOUS half-step consumed (two
+    // half-steps ahead; round 4 moved it here from behind the MFMAs on a suspicion that round 5 cleared -- tools/probe/
+    // mfma_war_probe.hip finds no write-after-read hazard on MFMA operands -- and it measured the same in both places) and, in
+    // the 128-wide kernel, the gather of the next step into the registers the blend has just freed.
+    auto mma_step = [&](const float4 (&r)[4][2], const f32x2 (&w)[2], int s0, auto&& mid) {
         // fma(w4, v4, fma(w3, v3, fma(w2, v2, w1 * v1))) per channel (dcn16.hip's order), two per v_pk_fma_f32
         uint32_t hi[4], lo[4];
         if (ABL && (abl & 2)) {
@@ -417,27 +433,32 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
         }
         const u32x4 ahv = {hi[0], hi[1], hi[2], hi[3]}, alv = {lo[0], lo[1], lo[2], lo[3]};
         const h8 ah = *reinterpret_cast<const h8*>(&ahv), al = *reinterpret_cast<const h8*>(&alv);
-        __builtin_amdgcn_sched_barrier(0);
-        mid();
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const u32x4 (&bh)[NW] = wbh[(s0 + h) % 3];
+            const u32x4 (&bl)[NW] = wbl[(s0 + h) % 3];
+            __builtin_amdgcn_sched_barrier(0);
+            mid(h);
+            __builtin_amdgcn_sched_barrier(0);
 #if CP_DCN_EXP & 64
-        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
 #endif
-        if (ABL && (abl & 4)) {  // keep the operands alive without the matrix pipe
+            if (ABL && (abl & 4)) {  // keep the operands alive without the matrix pipe
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[0][j][0] += __uint_as_float(ahv.x ^ alv.y ^ bh[j].x ^ bl[j].y);
-            return;
+                for (int j = 0; j < NW; ++j) acc[0][h * NW + j][0] += __uint_as_float(ahv.x ^ alv.y ^ bh[j].x ^ bl[j].y);
+                continue;
+            }
+            // same term order as igemm16.hip (lo*hi, hi*lo, hi*hi)
+#pragma unroll
+            for (int j = 0; j < NW; ++j)
+                acc[0][h * NW + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, *reinterpret_cast<const h8*>(&bh[j]), acc[0][h * NW + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NW; ++j)
+                acc[0][h * NW + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, *reinterpret_cast<const h8*>(&bl[j]), acc[0][h * NW + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NW; ++j)
+                acc[0][h * NW + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, *reinterpret_cast<const h8*>(&bh[j]), acc[0][h * NW + j], 0, 0, 0);
         }
-        // same term order as igemm16.hip (lo*hi, hi*lo, hi*hi)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, *reinterpret_cast<const h8*>(&bh[j]), acc[0][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, *reinterpret_cast<const h8*>(&bl[j]), acc[0][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, *reinterpret_cast<const h8*>(&bh[j]), acc[0][j], 0, 0, 0);
     };
 
     if (!slow) {
@@ -474,9 +495,9 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
                 *reinterpret_cast<float4*>(patch + (NPIX + e) * PSTR + (tid & 7) * 16) = o;
             }
         };
-        // weights of steps 0 and 1 in flight before the first chunk is staged (step u refills set (u + 2) % 3 with step u + 2)
-        issue_b(0, 0 * gpt + 0);
-        issue_b(1, 0 * gpt + 1);
+        // weights of half-steps 0 and 1 in flight before the first chunk is staged (half-step s refills set (s + 2) % 3 with s + 2)
+        issue_hs(0, 0);
+        issue_hs(1, 0);
         for (int ch = 0; ch < nch; ++ch) {
             DCN_STAMP(4 + 24 * ch);  // chunk start
             if (ch > 0) __syncthreads();  // every wave is done with the previous chunk's patch
@@ -516,10 +537,14 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
             }
             __syncthreads();
             DCN_STAMP(6 + 24 * ch);  // chunk staged
-            float4 raw[2][4][2];
+            // NT = 2: two gather register sets, step u + 1 requested before the blend of step u.  NT = 4: ONE set (the accumulators
+            // took the other's 32 registers): step u + 1 is requested right after the blend of step u has consumed it, in front of
+            // that step's 12 MFMAs, which cover the LDS round trip
+            constexpr int RS = NT >= 4 ? 1 : 2;
+            float4 raw[RS][4][2];
             if (ABL) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < RS; ++i)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) raw[i][c][0] = raw[i][c][1] = make_float4(1.f, 2.f, 3.f, 4.f);
             }
@@ -528,15 +553,15 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
             for (int u = 0; u < NSTEP; ++u) {
                 // the order of the three phases is pinned (sched_barrier): left alone, the scheduler sinks every load to
                 // just above its first use -- no prefetch, a full LDS / L2 round trip exposed per step
-                if (u + 1 < NSTEP) gather(raw[(u + 1) & 1], addr[(u + 1) >> 1] + ((u + 1) & 1) * 64);
+                if (RS == 2 && u + 1 < NSTEP) gather(raw[(u + 1) % RS], addr[(u + 1) >> 1] + ((u + 1) & 1) * 64);
                 __builtin_amdgcn_sched_barrier(0);
 #if CP_DCN_EXP & 1024
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-                mma_step(raw[u & 1], bw[u >> 1], wbh[u % 3], wbl[u % 3], [&]() {
-                    // the set step u - 1 consumed takes step u + 2 (of this chunk or the next)
-                    const int u2 = u + 2 < NSTEP ? u + 2 : u + 2 - NSTEP, ch2 = u + 2 < NSTEP ? ch : ch + 1;
-                    if (ch2 < nch) issue_b((u + 2) % 3, (u2 >> 1) * gpt + 2 * ch2 + (u2 & 1));
+                mma_step(raw[u % RS], bw[u >> 1], u * NH, [&](int h) {
+                    if (RS == 1 && h == 0 && u + 1 < NSTEP) gather(raw[0], addr[(u + 1) >> 1] + ((u + 1) & 1) * 64);
+                    // the set half-step s - 1 consumed takes half-step s + 2 (of this chunk or the next)
+                    issue_hs(u * NH + h + 2, ch);
                 });
                 __builtin_amdgcn_sched_barrier(0);
                 if ((CP_DCN_EXP & 16) || u == NSTEP - 1) DCN_STAMP(7 + 24 * ch + ((CP_DCN_EXP & 16) ? u : 0));  // per step (16) / chunk done
@@ -576,8 +601,8 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
                 bw[t][1] = f32x2{w3, w4};
             }
         }
-        issue_b(0, 0);
-        issue_b(1, 1);
+        issue_hs(0, 0);
+        issue_hs(1, 0);
         for (int ch = 0; ch < nch; ++ch) {
 #pragma unroll
             for (int u = 0; u < NSTEP; ++u) {
@@ -591,10 +616,7 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
                     r[c][0] = buf_ld4s(r_x, (unsigned)gi, so);
                     r[c][1] = buf_ld4s(r_x, (unsigned)gi + 16u, so);
                 }
-                mma_step(r, bw[t], wbh[u % 3], wbl[u % 3], [&]() {
-                    const int u2 = u + 2 < NSTEP ? u + 2 : u + 2 - NSTEP, ch2 = u + 2 < NSTEP ? ch : ch + 1;
-                    if (ch2 < nch) issue_b((u + 2) % 3, (u2 >> 1) * gpt + 2 * ch2 + (u2 & 1));
-                });
+                mma_step(r, bw[t], u * NH, [&](int h) { issue_hs(u * NH + h + 2, ch); });
                 __builtin_amdgcn_sched_barrier(0);  // keep the loads of later steps below: the register file is full
             }
         }
@@ -705,10 +727,13 @@ template <int NT>
 int launch_dcn16p(const ConvParams& p, hipStream_t stream) {
     constexpr int BN = 32 * NT;
     const int tiles_m = p.B * (p.H / TH) * (p.W / TW), tiles_n = p.CoutPad / BN;
-    if ((unsigned)p.dbg >> 25)
-        hipLaunchKernelGGL((dcn16p_kernel<NT, true>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m, tiles_n);
-    else
-        hipLaunchKernelGGL((dcn16p_kernel<NT>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m, tiles_n);
+    if constexpr (NT == 2) {  // (the timing ablations exist for the 64-wide kernel only)
+        if ((unsigned)p.dbg >> 25) {
+            hipLaunchKernelGGL((dcn16p_kernel<NT, true>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m, tiles_n);
+            return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL((dcn16p_kernel<NT>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m, tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
@@ -727,8 +752,18 @@ bool cp_dcn16p_supported(const ConvParams& p) {
 
 int cp_dcn16p_blocks(const ConvParams& p) { return p.B * (p.H / TH) * (p.W / TW) * (p.CoutPad / 64); }
 
+// The 128-wide N tile (NT = 4: gather, blend and split once per 128 outputs instead of once per 64) for layers with whole
+// 128-channel tiles whose launch still gives every CU a workgroup (measured at B = 64, profiles/r05_dcn_wide_ab.txt: 128 -> 128
+// @64^2 379 -> 262 us, 256 -> 128 @32^2 171 -> 131, 256 -> 256 @32^2 364 -> 258, and 512 -> 256 @16^2 -- 256 workgroups -- 160 ->
+// 151).  cp_set_debug 524288: never (A/B runs, tests).
+bool cp_dcn16p_wide(const ConvParams& p) {
+    return cp_dcn16p_supported(p) && p.CoutPad % 128 == 0 && !(p.dbg & 524288) && !((unsigned)p.dbg >> 25) &&
+           ((p.dbg & 65536) || p.B * (p.H / TH) * (p.W / TW) * (p.CoutPad / 128) >= 256);  // (65536: launches of any size, tests)
+}
+
 int cp_launch_dcn16p(const ConvParams& p, hipStream_t stream) {
     if (!cp_dcn16p_supported(p)) return CP_ERR_INVALID;
+    if (cp_dcn16p_wide(p)) return launch_dcn16p<4>(p, stream);
     return launch_dcn16p<2>(p, stream);
 }
 

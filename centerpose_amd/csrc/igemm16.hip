@@ -1055,6 +1055,7 @@ static bool dcn16p_wanted(const ConvParams& p) {
 // cp_set_debug: 1048576 = never, 2097152 = every eligible launch (tests, A/B runs).
 static bool dcn16s_wanted(const ConvParams& p) {
     if ((p.dbg & 1048576) || !dcn16p_wanted(p) || !cp_dcn16s_supported(p)) return false;
+    if (cp_dcn16p_wide(p) && !(p.dbg & 2097152)) return false;  // 128 output channels per tile: the 128-wide patch kernel (round 5)
     return (p.dbg & 2097152) || cp_dcn16s_items(p) >= 4096;
 }
 
@@ -1126,7 +1127,7 @@ int cp_launch_conv16(const ConvParams& p, hipStream_t stream) {
 // kernel-variant ids continue after the exact-f32 ones (cp_conv_variant): 14.. = split-f16 instantiations
 int cp_conv16_variant(const ConvParams& p) {
     const int bn = conv16_tile_n(p);
-    if (p.offmask) return dcn16s_wanted(p) ? CP_VARIANT_DCN16S : dcn16p_wanted(p) ? CP_VARIANT_DCN16P : bn == 128 ? 18 : 17;
+    if (p.offmask) return dcn16s_wanted(p) ? CP_VARIANT_DCN16S : dcn16p_wanted(p) ? (cp_dcn16p_wide(p) ? CP_VARIANT_DCN16PW : CP_VARIANT_DCN16P) : bn == 128 ? 18 : 17;
     const int t = bn == 32 ? 0 : bn == 64 ? 1 : 2;
     if (bn == 64 && p.tile_m == 64) return CP_VARIANT_M64N64;
     if (halo16_wanted(p, bn)) return 27 + t;

@@ -137,7 +137,7 @@ int cp_model_set_precision(cp_model* m, int precision);
  * pair.  cp_model_profile_read drains them: out[v*4 + 0..3] = {launches, total milliseconds, total
  * algorithmic FLOPs (2*M*Cout*KH*KW*Cin), total algorithmic bytes (input + output + weights
  * [+ offsets/mask] [+ residual], float32)} per kernel variant v in [0, CP_NUM_KERNEL_VARIANTS). */
-#define CP_NUM_KERNEL_VARIANTS 38
+#define CP_NUM_KERNEL_VARIANTS 39
 int cp_num_kernel_variants(void); /* the value the LIBRARY was built with: size cp_model_profile_read's buffer from it */
 int cp_model_profile(cp_model* m, int enable);
 int cp_model_profile_read(cp_model* m, double* out, int num_variants);

@@ -304,11 +304,19 @@ def test_dcn_patch_resident_vs_oracle_and_gather_kernel(device, B, C, Co, H, W, 
             old = hip.dcn_v2_forward(*args).cpu()
         finally:
             hip.lib().cp_set_debug(0)
+        hip.lib().cp_set_debug(65536 | 524288)   # never the 128-wide N tile
+        try:
+            narrow = hip.dcn_v2_forward(*args).cpu()
+        finally:
+            hip.lib().cp_set_debug(0)
     finally:
         hip.set_default_precision("f32")
     assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-5
     assert float((out - old).abs().max() / ref.abs().max()) < 2e-6
     assert C == 32 or not torch.equal(out, old)   # two different kernels really ran (one 32-channel chunk: same order)
+    # layers with whole 128-channel tiles take the 128-wide N tile (gather / blend / split once per 128 outputs, round 5): every
+    # output sums the same products in the same order as on the 64-wide tile
+    assert torch.equal(out, narrow)
 
 
 @pytest.mark.parametrize("B,C,Co,H,W,std,grid8", [
@@ -357,10 +365,12 @@ def test_dcn_streamed_persistent_vs_oracle_and_gather_kernel(device, B, C, Co, H
 
 @pytest.mark.parametrize("C,Co,HW", [(64, 64, 128), (128, 128, 64)])
 def test_dcn_at_bench_batch_size_independent_properties(device, C, Co, HW):
-    """The two DCNv2 shapes the persistent kernel takes in the benchmark, at the benchmark's batch (B = 64: 8192 / 4096 items,
-    where no CPU oracle finishes in seconds) through properties that do not depend on the size:
-      * the launch really goes to dcn16s by default, and it agrees with dcn16p (cp_set_debug 1048576) and with the gather kernel
-        dcn16 (32768) to summation-order round-off;
+    """The two heaviest DCNv2 shapes of the benchmark, at the benchmark's batch (B = 64: 8192 / 4096 patches, where no CPU oracle
+    finishes in seconds) through properties that do not depend on the size:
+      * the launch really goes to the kernel the dispatcher means -- the persistent dcn16s for 64 -> 64, dcn16p on the 128-wide N
+        tile for 128 -> 128 -- and it agrees with the other patch kernel (cp_set_debug 1048576 resp. 65536 | 2097152) and with the
+        gather kernel dcn16 (32768) to summation-order round-off; the 128-wide tile equals the 64-wide one (524288 | 1048576) bit
+        for bit;
       * homogeneity: without a bias f(4 x) == 4 f(x) bit for bit -- every operand is pre-scaled by exact powers of two
         (profiles/NOTES.md 3.1), so a power-of-two input scale must come out as exactly that scale;
       * additivity in the input for fixed offsets / masks: f(x1 + x2) - f(x1) - f(x2) + f(0) == 0 to round-off;
@@ -379,7 +389,7 @@ def test_dcn_at_bench_batch_size_independent_properties(device, C, Co, HW):
         f = lambda x, m=mask: hip.dcn_v2_forward(x, w, b, off, m, *tail)
         y1 = f(x1)
         scale = float(y1.abs().max())
-        for dbg in (1048576, 32768):
+        for dbg in ((1048576 if Co % 128 else 65536 | 2097152), 32768):
             hip.lib().cp_set_debug(dbg)
             try:
                 other = f(x1)
@@ -387,6 +397,12 @@ def test_dcn_at_bench_batch_size_independent_properties(device, C, Co, HW):
                 hip.lib().cp_set_debug(0)
             assert not torch.equal(other, y1), dbg            # a different kernel ran
             assert float((other - y1).abs().max()) / scale < 2e-6, dbg
+        if Co % 128 == 0:
+            hip.lib().cp_set_debug(524288 | 1048576)
+            try:
+                assert torch.equal(f(x1), y1)
+            finally:
+                hip.lib().cp_set_debug(0)
         bias = b.view(1, Co, 1, 1)
         # (without a bias the property is exact: the products, their sums and the epilogue's power-of-two scales carry the factor 4
         # through unchanged; with one, fl(4 X + b) - b and 4 (fl(X + b) - b) differ by the roundings of the additions: a few ulp)

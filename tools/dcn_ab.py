@@ -1,4 +1,5 @@
-"""A/B of the DCNv2 main kernels per layer shape of dla_34 at batch B: dcn16p (patch-resident) vs dcn16s (persistent, streamed).
+"""A/B of the DCNv2 main kernels per layer shape of dla_34 at batch B: dcn16p (patch-resident, 64-wide N tile), dcn16pw (the same on
+the 128-wide N tile where the layer has whole 128-channel tiles) and dcn16s (persistent, streamed).
 Run under rocprofv3 --kernel-trace; `--parse DIR` then prints the average kernel duration per (shape, kernel) from the trace.
 usage: rocprofv3 --kernel-trace --output-format csv -d OUT -- python tools/dcn_ab.py [--b 64] [--n 5] ; python tools/dcn_ab.py --parse OUT"""
 import argparse
@@ -9,7 +10,7 @@ import sys
 
 SHAPES = [  # (Cin, Cout, HW, count in the network)
     (64, 64, 128, 5), (128, 64, 64, 4), (128, 128, 64, 2), (256, 128, 32, 2), (256, 256, 32, 1), (256, 64, 32, 1), (512, 256, 16, 1)]
-MODES = [("dcn16p", 1048576), ("dcn16s", 2097152)]
+MODES = [("dcn16p", 1048576 | 524288), ("dcn16pw", 1048576), ("dcn16s", 2097152)]  # (dcn16pw: the 128-wide N tile where Cout % 128 == 0)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--b", type=int, default=64)
@@ -17,7 +18,7 @@ ap.add_argument("--n", type=int, default=5)
 ap.add_argument("--std", type=float, default=1.5)
 ap.add_argument("--parse", default=None)
 ap.add_argument("--nshapes", type=int, default=7)
-ap.add_argument("--only", default=None, help="dcn16p | dcn16s")
+ap.add_argument("--only", default=None, help="dcn16p | dcn16pw | dcn16s")
 a = ap.parse_args()
 SHAPES = SHAPES[:a.nshapes]
 if a.only:
@@ -34,7 +35,7 @@ if a.parse:
         for m, _ in MODES:
             grp = rows[i:i + 2 + a.n]
             i += 2 + a.n
-            names = {("dcn16s" if "dcn16s" in r["Kernel_Name"] else "dcn16p") for r in grp}
+            names = {("dcn16s" if "dcn16s" in r["Kernel_Name"] else "dcn16pw" if "dcn16p_kernel<4" in r["Kernel_Name"] else "dcn16p") for r in grp}
             d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in grp[2:]]
             avg = sum(d) / max(1, len(d))
             tot[m] += avg * cnt
@@ -65,4 +66,4 @@ for (ci, co, hw, cnt) in SHAPES:
         outs.append(y)
     hip.lib().cp_set_debug(0)
     err = float((outs[0] - outs[-1]).abs().max() / outs[0].abs().max())
-    print("%d->%d @%d: max |dcn16p - dcn16s| / max = %.2e" % (ci, co, hw, err), flush=True)
+    print("%d->%d @%d: max |dcn16p - dcn16s| / max = %.2e; 128-wide == 64-wide: %s" % (ci, co, hw, err, bool(torch.equal(outs[0], outs[1])) if len(outs) > 2 else "-"), flush=True)

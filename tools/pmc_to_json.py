@@ -35,6 +35,8 @@ def variant(kname):
         return "dcn_igemm16_f16x3_m%dn%d" % (32 * mt * wm, 32 * nt * wn)
     if "gn_final_kernel" in kname:
         return "gn_final_f32_valu"
+    if "dcn16p_kernel<4" in kname:
+        return "dcn16p_f16x3_p128n128"
     if "dcn16p_kernel" in kname:
         return "dcn16p_f16x3_p128n64"
     if "dcn16s_kernel" in kname:
