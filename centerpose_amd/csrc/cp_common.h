@@ -205,7 +205,7 @@ int cp_launch_halo16_gru(const ConvParams& p, hipStream_t stream);
 int cp_launch_halo16(const ConvParams& p, int bn, hipStream_t stream);
 // fused DCNv2 gather + contraction (dcn16.hip); bn = N tile (64 / 128), variant = alternative wave count (tuning)
 int cp_launch_dcn16(const ConvParams& p, int bn, int variant, hipStream_t stream);
-// dcn16p.hip: patch-resident DCNv2 (gather from an LDS-staged halo); N tile 64
+// dcn16p.hip: patch-resident DCNv2 (gather from an LDS-staged halo); N tile 64, or 128 where cp_dcn16p_wide says so
 // pw16.hip: 1x1 / stride-1 layers (incl. virtual concats) as a register-only stream, weight fragments from w16f_*
 bool cp_pw16_supported(const ConvParams& p);
 int cp_launch_pw16(const ConvParams& p, hipStream_t stream);

@@ -15,7 +15,9 @@
 //     address register per (lane, tap) and every corner / K step / quad is an immediate offset.
 //   * A lane gathers exactly its MFMA A-fragment (pixel = lane % 32, 8 consecutive channels = 2 quads per corner),
 //     blends in float32 (plain v_fma_f32: the packed form measured 4 % slower), splits to binary16 hi / lo in registers: the A tile never exists in LDS.
-//     Each wave owns 32 pixels x the whole 64-wide N tile, so nothing is gathered twice inside a block.
+//     Each wave owns 32 pixels x the whole N tile, so nothing is gathered twice inside a block.  The N tile is 64 wide (NT = 2)
+//     or -- round 5, layers with whole 128-channel tiles -- 128 wide (NT = 4): the same gather / blend / split then feeds twice
+//     the MFMAs (see the weight-set comment in the kernel and cp_dcn16p_wide).
 //   * The weight fragments come straight from global memory / L2 in MFMA operand order (ConvParams::w16f_*: one
 //     coalesced 1 KB load per fragment, cp_launch_frag16_repack), three K steps ahead.  With neither operand staged
 //     through a shared tile the K loop has NO barrier inside a chunk: the four waves of a block drift apart and one
