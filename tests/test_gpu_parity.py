@@ -626,6 +626,74 @@ def test_backbone_at_bench_batch_every_image_every_launch(device, arch, B, reps)
             assert float((z8[k] - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())), (k, b0)
 
 
+# the three legs of the driver's bench line that are not BASELINE configs[1] / configs[2]: what each must have launched at ITS benchmarked
+# size (other kernels than at the 128^2 goldens: dcn16s from 4096 patches, the 128-wide DCN tile, the walk over all twelve heads)
+_LEG_VARIANTS = {
+    "hourglass": ("halo16_head_f16x3", "halo16_f16x3_m128n128", "igemm16_f16x3", "pw16_f16x3"),
+    # (B = 16: 2048 patches of 8 x 16 -- below dcn16s's 4096-item threshold, so both N tiles of dcn16p carry the DCN layers, and
+    # exactly the count from which a workgroup of the head launch walks every head of its patch)
+    "track": tuple(v for v in _HOT_VARIANTS if v != "dcn16s_f16x3") + ("dcn16p_f16x3_p128n64", "dcn16p_f16x3_p128n128"),
+    "track_gru": tuple(v for v in _HOT_VARIANTS if v not in ("dcn16s_f16x3", "halo16_head_f16x3")) +
+                 ("dcn16p_f16x3_p128n64", "dcn16p_f16x3_p128n128", "halo16_gru_f16x3", "gn_final"),
+}
+
+
+@pytest.mark.parametrize("leg,pick", [("hourglass", 5), ("track", 11), ("track_gru", 6)])
+def test_timed_legs_at_bench_size_vs_oracle_every_image_every_launch(device, leg, pick):
+    """The legs `hourglass` (BASELINE configs[4] as the reference defines it: 2-stack hourglass, 512^2, B = 8), `track` (dla_34,
+    CenterPoseTrack inputs, B = 16) and `track_gru` (configs[4] as the reference can run it: dlav1_34 + ConvGRU, all three pre_*
+    inputs, B = 16) are timed in the driver's bench line; this is their parity AT THE BENCHMARKED SIZE, on the very pipeline
+    object bench.py times (same seeds, same inputs, f16x3):
+    (1) one image of the batch against the CPU oracle (large_hourglass.py:266-287, pose_dla_dcn.py:312-318,545-555 restated in
+        oracle/) at the north-star gates: 1e-3 on post-sigmoid heat-maps, 1e-3 relative on every regression head, ALL heads;
+    (2) 20 forwards, odd ones with the batch (and every pre_* input) in reversed image order: every head of every image
+        bit-identical to the first forward (each image is computed by the first workgroups of a launch one way round and by the
+        last the other way);
+    (3) the launch profile lists the kernels this size really selects."""
+    import bench
+    from oracle import hourglass as oh
+
+    B = bench.DEFAULT_BATCH[leg]
+    pipe = bench.Pipeline(leg, B, device, seed=317, precision="f16x3")
+    model, x, extra, heads = pipe.model, pipe.x, pipe.extra, pipe.heads
+    assert x.shape == (B, 3, 512, 512) and (set(extra) == {"pre_img", "pre_hm", "pre_hm_hp"}) == (leg != "hourglass")
+    model.profile(True)
+    z0 = {k: v.clone() for k, v in model(x, sigmoid_hm=True, **extra).items()}
+    torch.cuda.synchronize()
+    ran = model.profile_read()
+    model.profile(False)
+    for want in _LEG_VARIANTS[leg]:
+        assert any(name.startswith(want) for name in ran), (leg, want, sorted(ran))
+    assert set(z0) == set(heads) and len(heads) == (7 if leg == "hourglass" else 11)
+    # (1) oracle, one image
+    sd = synth.make_state_dict(pipe.arch, heads, pipe.track)
+    xi = x[pick:pick + 1].cpu()
+    if leg == "hourglass":
+        zo = oh.hourglass_forward(sd, xi, heads)
+    else:
+        zo = ob.dlaseg_forward(sd, xi, heads, arch=pipe.arch.split("_")[0], tracking_task=True,
+                               **{k: v[pick:pick + 1].cpu() for k, v in extra.items()})
+    for k in heads:
+        got = z0[k][pick:pick + 1].cpu()
+        assert torch.isfinite(z0[k]).all(), k
+        if k in ("hm", "hm_hp"):
+            assert float((got - torch.sigmoid(zo[k])).abs().max()) < 1e-3, (leg, k)
+        else:
+            assert float((got - zo[k]).abs().max()) < 1e-3 * max(1.0, float(zo[k].abs().max())), (leg, k)
+    # (2) every image, every launch, both image orders
+    xr = x.flip(0).contiguous()
+    er = {k: v.flip(0).contiguous() for k, v in extra.items()}
+    nbad = {}
+    for it in range(1, 20):
+        z = model(xr, sigmoid_hm=True, **er) if it & 1 else model(x, sigmoid_hm=True, **extra)
+        for k in heads:
+            zk = z[k].flip(0) if it & 1 else z[k]
+            if not torch.equal(zk, z0[k]):
+                d = (zk - z0[k]).abs().amax(dim=(1, 2, 3))
+                nbad.setdefault(k, []).append((it, [int(i) for i in d.nonzero().flatten().tolist()], float(d.max())))
+    assert not nbad, (leg, nbad)
+
+
 def _many_launches(f, n):
     first, nbad = None, 0
     for _ in range(n):
