@@ -110,15 +110,52 @@ def respawn_under_torchrun(args):
     return subprocess.call(cmd, env=env)
 
 
+class GatherTimer(object):
+    """Time of the per-step detection all-gather on THIS rank (N > 1): HIP events on the stream the collective is issued on
+    (device tensors), time.perf_counter around the blocking call otherwise (dry run over gloo).  Reported next to the step as
+    the MAX over ranks of the per-rank mean, with the bytes a rank receives."""
+
+    def __init__(self, device):
+        self.device, self.pairs, self.host_s, self.bytes_out = device, [], [], 0
+
+    def __call__(self, det):
+        if self.device is None:
+            t0 = time.perf_counter()
+            out = cpd.allgather_detections(det)
+            self.host_s.append(time.perf_counter() - t0)
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = cpd.allgather_detections(det)
+            e1.record()
+            self.pairs.append((e0, e1))
+        self.bytes_out = out.numel() * out.element_size()
+        return out
+
+    def reset(self):
+        self.pairs, self.host_s = [], []
+
+    def mean_ms(self):
+        if self.device is not None:
+            torch.cuda.synchronize()
+            ts = [a.elapsed_time(b) for a, b in self.pairs]
+        else:
+            ts = [t * 1e3 for t in self.host_s]
+        return sum(ts) / len(ts) if ts else None
+
+
 class Pipeline(object):
     """frames -> heads -> detections [-> poses], all on device."""
 
     def __init__(self, workload, batch, device, seed, precision="f32", serial_pnp=False, gather=False):
+        """``seed``: seed of this rank's FIRST image; image i of the shard is drawn from chunk seed ``seed + 8 * (i // 8)``, so that
+        with seed = 317 + shard start (main) global image g is the same frame whatever the number of ranks."""
         from centerpose_amd import hip, synth
 
         self.hip = hip
         self.serial_pnp = serial_pnp
         self.gather = gather
+        self.gather_timer = GatherTimer(device) if gather else None
         self.workload = workload
         self.arch = "dlav1_34" if workload in ("decode", "track_gru") else "hourglass" if workload == "hourglass" else "dla_34"
         self.track = workload in ("track", "track_gru")
@@ -160,7 +197,7 @@ class Pipeline(object):
         if self.workload in ("decode", "hourglass"):
             # backbone + sigmoid + decode in one library call (hipGraph replay when graph=True)
             det = self.model.detect(x, K=100, rep_mode=1, fit_gaussian=False, balance=2.0, graph=graph)[1]
-            return cpd.allgather_detections(det) if self.gather else det
+            return self.gather_timer(det) if self.gather else det
         if self.workload == "full":
             det = self.model.detect(x, K=100, rep_mode=1, fit_gaussian=False, balance=2.0, graph=graph)[1]
         else:
@@ -169,7 +206,7 @@ class Pipeline(object):
                                  z["scale_uncertainty"], z["reg"], z["hp_offset"], z["tracking"], z["tracking_hp"],
                                  K=100, rep_mode=1, fit_gaussian=True, balance=2.0)
             # the tracker of every video needs all detections: one RCCL all-gather of the fixed-size records
-            return cpd.allgather_detections(det)
+            return self.gather_timer(det) if self.gather else cpd.allgather_detections(det)
         # configs[2]: post-process + soft-NMS (cp_postprocess), PnP input assembly for rep_mode 1 and the batched solve
         # (cp_pnp_from_post) -- library launches only, no torch indexing and no host synchronisation inside the step.
         # The solve (a few dozen latency-bound float64 wavefronts) is queued on hip.PoseStage's side stream and runs under
@@ -185,7 +222,7 @@ class Pipeline(object):
             post, cnt, poses, done = stage.submit(det, self.meta[:n], self.cam[:n], 0.3, nms=True, rep_mode=1)
         self.last = (cnt, poses)
         if self.gather:  # BASELINE configs[3]: every rank sees every image's detections
-            return cpd.allgather_detections(det), poses
+            return self.gather_timer(det), poses
         return det, poses
 
     def pnp_stats(self):
@@ -200,19 +237,24 @@ class Pipeline(object):
 
 
 class DryPipeline(object):
-    """--dry-run: no device, no library; fixed-size records tagged with the rank (field 0) and with the device index the rank
-    would bind (field 1 = LOCAL_RANK) so the gather and the rank -> device mapping can be checked."""
+    """--dry-run: no device, no library; fixed-size records tagged with the rank (field 0), the device index the rank would bind
+    (field 1 = LOCAL_RANK), the GLOBAL image index of the record's image (field 2 = shard start + i, the shard being
+    distributed.shard_range of the global batch) and its slot (field 3), so that the gather order (rank, image, slot), the
+    rank -> device mapping and the tiling of [0, global batch) by the shards can be checked."""
 
-    def __init__(self, batch, rank, local=0):
+    def __init__(self, batch, rank, local=0, start=0, workload="full"):
         self.batch, self.rank = batch, rank
-        self.arch, self.track, self.workload = "dla_34", False, "full"
+        self.arch, self.track, self.workload = "dla_34", workload in ("track", "track_gru"), workload
         self.det = torch.full((batch, 100, 118), float(rank), dtype=torch.float32)
         self.det[:, :, 1] = float(local)
+        self.det[:, :, 2] = torch.arange(start, start + batch, dtype=torch.float32).view(batch, 1)
+        self.det[:, :, 3] = torch.arange(100, dtype=torch.float32).view(1, 100)
         self.gathered = None
+        self.gather_timer = GatherTimer(None)
 
     def step(self, x=None, graph=False):
         time.sleep(0.002)
-        self.gathered = cpd.allgather_detections(self.det)
+        self.gathered = self.gather_timer(self.det)
         return self.gathered
 
 
@@ -223,6 +265,8 @@ def timed_region(pipe, steps, warmup, barrier, profile=True):
     every = 4 if steps >= 8 else 1
     sampled = 0
     barrier()
+    if getattr(pipe, "gather_timer", None) is not None:
+        pipe.gather_timer.reset()  # the warm-up steps' collectives (communicator bring-up) are not the steady state
     t0 = time.perf_counter()
     for i in range(steps):
         if profile:
@@ -314,6 +358,23 @@ def roofline_object(prof, roles, sampled, batch, precision, workload=None):
             # HBM-side bytes per launch from the rocprofv3 PMC passes of profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
             roof["traffic"] = t["hbm_bytes_per_launch"]
             roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `%s`)" % meta.get("command", "bench.py")
+            if "dcn" in roof:
+                # the DCN pair's counter bytes per step: every DCN main kernel that ran + the offset convolutions (N = 32 halo tile),
+                # each kernel's PMC bytes per launch x its launches per step in THIS run
+                tot, main, missing = 0.0, 0.0, []
+                for k, v in prof.items():
+                    if k.startswith(("dcn16", "dcn_igemm16")) or k == "halo16_f16x3_m128n32":
+                        if k in pmc:
+                            b = pmc[k]["hbm_bytes_per_launch"] * (v["launches"] / sampled)
+                            tot += b
+                            main += b if k != "halo16_f16x3_m128n32" else 0.0
+                        else:
+                            missing.append(k)
+                if tot > 0 and not missing:
+                    # (the algorithmic figure counts a layer's input once; the offset convolution is a second kernel over it)
+                    roof["dcn"]["traffic"] = round(tot)
+                    roof["dcn"]["traffic_over_algorithmic"] = round(tot / (DCN_MB_PER_IMG * 1e6 * batch), 3)
+                    roof["dcn"]["traffic_main_kernels"] = round(main)
         else:
             roof["traffic_note"] = "no PMC pass of this workload / batch under profiles/ (pmc_traffic.json profiled %s at batch %s)" % (
                 meta.get("workload"), meta.get("batch"))
@@ -494,15 +555,14 @@ def e2e_u8_leg(device, precision, steps, warmup, barrier, batch=64):
     u8_dev = u8_host.to(device)
     for _ in range(warmup):
         step(u8_dev)
-    dt = None
-    for _ in range(2):  # two timed passes of `steps`, the faster one reported: a leg's fresh pipeline showed one slow step in ten
-        barrier()       # on some runs (21.1 vs 18.8 ms per step with the PCIe copy added), and this figure is compared with the next
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step(u8_dev)
-        barrier()
-        d = time.perf_counter() - t0
-        dt = d if dt is None else min(dt, d)
+    # ONE timed pass of `steps`, the protocol of the headline, of every other leg and of pcie_inclusive below (round 5 reported the
+    # faster of two passes here, which biased the comparison with them)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(u8_dev)
+    barrier()
+    dt = time.perf_counter() - t0
     pre_ms = _event_ms(lambda: hip.preprocess_batch(u8_dev, trans, synth.MEAN, synth.STD, 512, 512, out=xbuf), 20)
     # PCIe-inclusive: batch i + 1 crosses the bus on the copy stream while batch i computes
     cur, cs = torch.cuda.current_stream(), torch.cuda.Stream(device=device)
@@ -534,7 +594,7 @@ def e2e_u8_leg(device, precision, steps, warmup, barrier, batch=64):
     out = {"workload": "uint8 HWC frames (B = %d, 512 x 512) -> cp_preprocess_batch -> the headline chain (network, decode, "
                        "post-process, PnP)" % batch, "precision": precision,
            "value": round(batch * steps / dt, 2), "unit": "images/sec", "steps": steps, "warmup": warmup,
-           "timed_passes": 2, "ms_per_step": round(dt / steps * 1e3, 3), "preprocess_ms_per_batch": round(pre_ms, 3),
+           "timed_passes": 1, "ms_per_step": round(dt / steps * 1e3, 3), "preprocess_ms_per_batch": round(pre_ms, 3),
            "preprocess_gbps": round(batch * (512 * 512 * 3 + 512 * 512 * 12) / 1e6 / pre_ms, 1),
            "pcie_inclusive": {"value": round(batch * steps / dt_pcie, 2), "unit": "images/sec", "ms_per_step": round(dt_pcie / steps * 1e3, 3),
                               "host_mb_per_step": round(u8_host.numel() / 1e6, 1),
@@ -767,7 +827,7 @@ def compact_line(d):
             keep += ("avg_launch_us", "launches_per_step", "flops_per_launch", "algorithmic_bytes_per_launch", "share_of_conv_time",
                      "conv_ms_per_step", "timed_steps_sampled")
         o = {k: r[k] for k in keep if k in r}
-        sub = {"dcn": ("ms_per_step", "main_ms", "offset_conv_ms", "hbm_gbps", "frac_hbm", "tflops"),
+        sub = {"dcn": ("ms_per_step", "main_ms", "offset_conv_ms", "hbm_gbps", "frac_hbm", "tflops", "traffic", "traffic_over_algorithmic", "traffic_main_kernels"),
                "conv1x1": ("tflops", "mfma_utilisation", "algorithmic_gbps"), "decode": ("us_per_step", "hbm_gbps"),
                "pnp": ("ms_per_batch_on_side_stream", "detections_last_batch")}
         for name, ks in sub.items():
@@ -877,15 +937,20 @@ def main():
         print(json.dumps(leg), flush=True)
         return
 
+    # this rank's contiguous shard of the global batch (BASELINE configs[3]: 512 = 8 x 64); frames are seeded by GLOBAL image
+    # index, so image g is the same frame at every N
+    g0, g1 = cpd.shard_range(world * batch, rank, world)
+    assert g1 - g0 == batch
     if dry:
-        pipe = DryPipeline(batch, rank, local)
+        pipe = DryPipeline(batch, rank, local, start=g0, workload=args.workload)
     else:
-        pipe = Pipeline(args.workload, batch, device, seed=317 + 1000 * rank, precision=args.precision,
+        pipe = Pipeline(args.workload, batch, device, seed=317 + g0, precision=args.precision,
                         serial_pnp=args.serial_pnp, gather=world > 1)
         side = torch.cuda.Stream(device=device)  # a non-default stream (hipGraph capture needs one)
         torch.cuda.set_stream(side)
     dt, prof, roles, sampled = timed_region(pipe, args.steps, args.warmup, barrier, profile=not dry)
     rccl_ranks = 1
+    allgather = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device if (device is not None and backend == "nccl") else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -897,6 +962,25 @@ def main():
         if got != [float(r) for r in range(world)]:
             raise SystemExit("bench.py: all-gather returned %r, expected ranks 0..%d in order" % (got, world - 1))
         rccl_ranks = dist.get_world_size()
+        # the per-step collective next to the step: MAX over ranks of each rank's mean (HIP events on its launch stream)
+        gm = pipe.gather_timer.mean_ms() if getattr(pipe, "gather_timer", None) is not None else None
+        tg = torch.tensor([gm if gm is not None else -1.0], dtype=torch.float64, device=t.device)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        if float(tg.item()) >= 0:
+            nbytes = pipe.gather_timer.bytes_out
+            allgather = {"ms_per_step_max_over_ranks": round(float(tg.item()), 4), "ms_per_step_rank0": round(gm, 4),
+                         "bytes_received_per_rank": nbytes, "gbps_per_rank": round(nbytes / 1e9 / (float(tg.item()) * 1e-3), 2)
+                         if float(tg.item()) > 0 else None,
+                         "timer": "HIP events on the launch stream" if not dry else "perf_counter around the blocking gloo call"}
+        if dry and pipe.gathered is not None:
+            # the shards tile [0, global batch) exactly, and the records arrive in (rank, image, slot) order
+            gi = pipe.gathered[:, 0, 2].to(torch.int64).tolist()
+            if gi != list(range(world * batch)):
+                raise SystemExit("bench.py: shards do not tile [0, %d): %r ..." % (world * batch, gi[:8]))
+            rk = pipe.gathered[:, 0, 0].to(torch.int64).tolist()
+            if rk != [g // batch for g in range(world * batch)] or \
+               not bool((pipe.gathered[:, :, 3] == torch.arange(100, dtype=torch.float32).view(1, 100)).all()):
+                raise SystemExit("bench.py: gathered records are not in (rank, image, slot) order")
     ms_per_step = dt / args.steps * 1e3
     value = world * batch * args.steps / dt
 
@@ -963,6 +1047,9 @@ def main():
             "dtype": "f32" if args.precision == "f32" else "f32 via split-f16 (f16x3) MFMA, f32 accumulate",
             "data": "dry-run (stub pipeline, no device work)" if dry else "synthetic",
             "rccl_ranks": rccl_ranks,
+            **({"allgather": allgather} if allgather is not None else {}),
+            **({"dry_run_global_images": [int(pipe.gathered[0, 0, 2]), int(pipe.gathered[-1, 0, 2]), int(pipe.gathered.shape[0])]}
+               if dry and pipe.gathered is not None else {}),
             **({"dry_run_devices": [int(v) for v in pipe.gathered[::batch, 0, 1].tolist()]} if dry and pipe.gathered is not None else {}),
             "config": {"workload": WORKLOAD_TEXT[args.workload] % batch, "global_batch": world * batch,
                        "per_gpu_batch": batch, "input": "512x512",

@@ -9,6 +9,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The kernels of this library rely on the raw-buffer range check of the gfx9 / CDNA family as gfx950 implements it: a lane whose
+// (voffset + soffset [+ immediate]) lies beyond the descriptor's num_records reads 0 -- per dword for a 16-byte access that
+// straddles the end -- and its stores / LDS-DMA writes are dropped (zeros land in LDS).  Out-of-picture halo pixels, padded
+// weight / bias rows, missing split-K slices (igemm.hip: splitk_epilogue4_kernel) and "invalid corner" gathers are all
+// expressed that way (OOB / OOB_BASE in igemm16_common.h) instead of as branches.  Other architectures check differently
+// (gfx10+ exclude soffset in some modes): refuse to build device code for anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "centerpose_amd device code is written for gfx950 only (raw-buffer range-check semantics, MFMA shapes, LDS-DMA)"
+#endif
+
 #define CP_OK 0
 #define CP_ERR_INVALID (-1)
 #define CP_ERR_LAUNCH (-2)

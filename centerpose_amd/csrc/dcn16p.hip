@@ -39,28 +39,7 @@
 
 #include "patch16_common.h"
 
-#ifndef CP_DCN_EXP
-#define CP_DCN_EXP 0
-#endif
-#if CP_DCN_EXP & 8
-// tuning build 8: shader-clock stamps of one wave of one mid-launch block at its phase boundaries (tools/dcn_timeline.py)
-__device__ unsigned long long g_dcn_clk[64];
-#define DCN_STAMP(i) do { if (blockIdx.x == 4001 && threadIdx.x == 0) g_dcn_clk[i] = clock64(); } while (0)
-extern "C" int cp_debug_read_dcn_clk(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dcn_clk), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
-}
-#else
-#define DCN_STAMP(i) do { } while (0)
-#endif
 
-#if CP_DCN_EXP & (32 | 262144)
-// tuning build 32 / 262144 (at the end of the kernel): every lane re-derives its 9 taps' set-up from a fresh copy of the record after the half-wave exchange and
-// logs disagreements (tools/probe/dcn16p_race.py --chk): [0] = count, then 8 words per entry
-__device__ unsigned g_dcn_chk[8 + 64 * 8];
-extern "C" int cp_debug_read_dcn_chk(unsigned* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dcn_chk), sizeof(unsigned) * (8 + 64 * 8)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 namespace {
 
@@ -94,10 +73,7 @@ __device__ __forceinline__ void both_halves5(const uint32_t (&v)[5], uint32_t (&
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// ABL: timing ablations for tuning (cp_set_debug bits 25..29, tools/dcn_bench.py --dbg; results are wrong when set):
-//   1 << 25 no gather reads (registers reused), 1 << 26 no blend / split arithmetic, 1 << 27 no MFMAs,
-//   1 << 28 no weight-fragment loads, 1 << 29 no staging loads / stores (the patch keeps its zeros)
-template <int NT, bool ABL = false>
+template <int NT>
 __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     typedef Frag<32> F;
     typedef F::acc_t acc_t;
@@ -106,16 +82,9 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     __shared__ int exc_goff[ECAP];  // that corner's byte offset into the input tensor (may be "before" it: see validity)
     __shared__ __attribute__((aligned(16))) float exc_w[ECAP][4];  // its four corner weights
     __shared__ int exc_count;
-#if CP_DCN_EXP & 4096
-    __shared__ int lds_ballast[12 * 1024];
-    if (p.dbg == 0x7fffffff) lds_ballast[threadIdx.x] = 1;
-#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    DCN_STAMP(0);
     const int lrow = lane >> 5, lcol = lane & 31;
-    const int abl = ABL ? __builtin_amdgcn_readfirstlane((int)((unsigned)p.dbg >> 25)) : 0;  // bit 5 (1 << 30): variant only;
-                                                                   // bit 6 (1 << 31): no epilogue stores
     const int tile = tile_of_block(tiles_m, tiles_n);
     const int tn = tile % tiles_n;
     int tm = tile / tiles_n;
@@ -123,21 +92,11 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     const int tx0 = (tm % txs) * TW;
     tm /= txs;
     const int ty0 = (tm % tys) * TH, b = tm / tys;
-    // EARLY (tuning build 128): every prologue load -- record, first chunk, activation scale -- in flight before anything waits.
-    // OFF since round 4: it measured +-0 (the CU's fill rate bounds the prologue, profiles/NOTES.md round 3).  It is also the
-    // configuration in which, WITH the SLP vectorizer on, hipcc folds the set-up's two sums into a packed add with a set op_sel
-    // bit, which this part computes wrongly in lanes 48-63 beside another wave's MFMAs (root cause of round 4's "rare
-    // corruption": tools/probe/pk_opsel_lds_hazard.hip, NOTES round 5; the library is built without the vectorizer and
-    // tests/test_host_cpu.py checks the disassembly for such ops).
-    constexpr bool EARLY = (CP_DCN_EXP & 128) != 0;
     float afwd, ainv;
-    if (!EARLY || (CP_DCN_EXP & 131072)) {
-        conv_in_scale(p, &afwd, &ainv);
-        // wave-uniform: keep both in scalar registers (the vector file is full)
-        afwd = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(afwd)));
-        ainv = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ainv)));
-    }
-    DCN_STAMP(1);  // after the activation-scale read
+    conv_in_scale(p, &afwd, &ainv);
+    // wave-uniform: keep both in scalar registers (the vector file is full)
+    afwd = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(afwd)));
+    ainv = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ainv)));
     const unsigned img_px = (unsigned)p.B * p.H * p.W;
     const __amdgpu_buffer_rsrc_t r_x = make_rsrc(p.src[0], img_px * (unsigned)p.Cin * 4u);
     const __amdgpu_buffer_rsrc_t r_om = make_rsrc(p.offmask, img_px * 128u);
@@ -154,8 +113,6 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     if (tid == 0) exc_count = 0;
     // the spare pixels start as zeros: an exception sample reads its blended value with weights (1, 0, 0, 0), and the three
     // zero-weight "corners" next to it must never be NaN / Inf bit patterns left behind by an earlier kernel
-    const int ablo = ABL ? __builtin_amdgcn_readfirstlane(p.dbg & 7) : 0;  // 1 no record loads, 2 no set-up math, 4 no zeroing
-    if (!(ABL && (ablo & 4)))
     for (int i = tid; i < (NPIX_ALL - NPIX) * (PSTR / 16); i += 256)
         *reinterpret_cast<float4*>(patch + NPIX * PSTR + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
     // ---- this lane's pixel: fragment row lane % 32 of wave w -> patch rows 2 w, 2 w + 1 in the permuted order of
@@ -166,116 +123,28 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     const unsigned rec = (unsigned)((b * p.H + y) * p.W + x) * 128u;  // the pixel's offset / mask record (32 floats)
     // this lane's share of the record: taps 5 lrow .. 5 lrow + 4 (slot 4 of the upper half is a dummy, tap "9")
     float od[12], omk[5];
-    if (ABL && (ablo & 1)) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) od[i] = 0.25f * (float)((lane + i) & 3);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) omk[i] = 0.5f;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#if CP_DCN_EXP & 524288
-            if (i == 1) {  // the upper half's second quad spans bytes 56 .. 71 of the record: two 8-byte loads instead of one that
-                           // straddles the 64-byte boundary
-                const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(r_om, (int)(rec + (unsigned)lrow * 40u + 16u), 0, 0);
-                const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(r_om, (int)(rec + (unsigned)lrow * 40u + 24u), 0, 0);
-                od[4] = __uint_as_float(a.x); od[5] = __uint_as_float(a.y); od[6] = __uint_as_float(c.x); od[7] = __uint_as_float(c.y);
-                continue;
-            }
-#endif
-            const float4 v = buf_ld4(r_om, rec + (unsigned)lrow * 40u + 16u * i);
-            od[4 * i] = v.x; od[4 * i + 1] = v.y; od[4 * i + 2] = v.z; od[4 * i + 3] = v.w;
-        }
+    for (int i = 0; i < 3; ++i) {
+        const float4 v = buf_ld4(r_om, rec + (unsigned)lrow * 40u + 16u * i);
+        od[4 * i] = v.x; od[4 * i + 1] = v.y; od[4 * i + 2] = v.z; od[4 * i + 3] = v.w;
+    }
+    {
         const float4 v = buf_ld4(r_om, rec + 72u + (unsigned)lrow * 20u);
         omk[0] = v.x; omk[1] = v.y; omk[2] = v.z; omk[3] = v.w;
         omk[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_om, (int)(rec + 88u + (unsigned)lrow * 20u), 0, 0));
     }
-    // EARLY: every global load of the prologue is in flight before anything waits -- the offset / mask record above, the
-    // whole first chunk of the patch (14 rows per thread; the register file is still empty here) and the activation
-    // scale (scalar loads): one exposed memory round trip instead of four in a row (scale, record, two staging rounds:
-    // 15.5 k of a block's 46.6 k clocks, profiles/r03_dcn_timeline.txt)
-    float4 sv0[EARLY ? PH : 1];
-    if (EARLY) {
-#pragma unroll
-        for (int s = 0; s < PH; ++s) {
-            const bool row_ok = (unsigned)(ty0 - HALO + s) < (unsigned)p.H;
-            sv0[s] = buf_ld4s(r_x, (row_ok && col_ok) ? (unsigned)(st_base + (s - HALO) * rowb) : OOB, 0);
-        }
-        DCN_STAMP(50);  // all prologue loads issued
-        if (!(CP_DCN_EXP & 131072)) {
-        conv_in_scale(p, &afwd, &ainv);
-        afwd = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(afwd)));
-        ainv = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ainv)));
-        }
-#if CP_DCN_EXP & 16384
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-        DCN_STAMP(51);  // activation scale arrived (scalar loads)
-        // park the rows right away (this is the one wait of the prologue; the record arrived with them): the 56 registers
-        // are free again before the set-up below needs the file
-#pragma unroll
-        for (int s = 0; s < PH; ++s)
-            if (spx < PW) *reinterpret_cast<float4*>(patch + st_lds + s * (PW * PSTR)) = sv0[s];
-        DCN_STAMP(52);  // rows arrived and parked (this wave)
-    }
     __syncthreads();  // exc_count = 0 is visible
-#if CP_DCN_EXP & 8192
-    __syncthreads();
-#endif
-    DCN_STAMP(2);  // zeroing done, record loads issued, first barrier passed
 
     // ---- bilinear set-up (dcn_v2_im2col_cuda.cu:25-54, 150-187): 5 tap slots per lane, then both halves swap ----
     uint32_t sq[5], sw[5][4];  // patch pixel of corner (h_lo, w_lo); corner weights x mask x activation pre-scale
     const float fy0 = (float)(y - 1), fx0 = (float)(x - 1);
-    if (ABL && (ablo & 2)) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            sq[j] = (uint32_t)((2 * wid + 3) * PW + 3 + (lcol & 15) + j);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) sw[j][c] = __float_as_uint(od[2 * j] + omk[j]);
-        }
-    } else
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         // tap 5 lrow + j = (kh, kw): lower half (0,0) (0,1) (0,2) (1,0) (1,1); upper half (1,2) (2,0) (2,1) (2,2) (-)
         const float khf = lrow ? (float)((5 + j) / 3) : (float)(j / 3);
         const float kwf = lrow ? (float)((5 + j) % 3) : (float)(j % 3);
-#if CP_DCN_EXP & (4194304 | 8388608 | 16777216 | 33554432 | 67108864)
-        // tuning builds for the round-5 investigation (profiles/NOTES.md): with the EARLY prologue the SLP vectorizer turns the two
-        // sums into ONE packed add written over its own cross-swizzled source,
-        //     v_pk_add_f32 v[10:11], v[14:15], v[10:11] op_sel:[0,1] op_sel_hi:[1,0]     ({w_im, h_im} = {wb, hb} + {dx, dy}),
-        // and that build computes a wrong w_im in lanes 48-63 of some wave in every second launch.  Variants, everything else left
-        // to the vectorizer: 4194304 two plain v_add_f32; 8388608 / 16777216 the packed form by hand with one / four wait
-        // states behind it; 33554432 swizzled but with a separate destination; 67108864 in place but without the swizzle
-        float h_im, w_im;
-        {
-            const float hb = fy0 + khf, wb = fx0 + kwf;
-            const f32x2 base = {wb, hb};
-#if CP_DCN_EXP & 4194304
-            asm volatile("v_add_f32 %0, %2, %3\n\tv_add_f32 %1, %4, %5" : "=&v"(h_im), "=&v"(w_im) : "v"(hb), "v"(od[2 * j]), "v"(wb), "v"(od[2 * j + 1]));
-#elif CP_DCN_EXP & 33554432
-            const f32x2 pr = {od[2 * j], od[2 * j + 1]};
-            f32x2 o;
-            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]\n\ts_nop 0" : "=&v"(o) : "v"(base), "v"(pr));
-            w_im = o.x; h_im = o.y;
-#elif CP_DCN_EXP & 67108864
-            f32x2 o = {od[2 * j + 1], od[2 * j]};
-            asm volatile("v_pk_add_f32 %0, %1, %0\n\ts_nop 0" : "+v"(o) : "v"(base));
-            w_im = o.x; h_im = o.y;
-#else
-            f32x2 pr = {od[2 * j], od[2 * j + 1]};
-#if CP_DCN_EXP & 16777216
-            asm volatile("v_pk_add_f32 %0, %1, %0 op_sel:[0,1] op_sel_hi:[1,0]\n\ts_nop 3" : "+v"(pr) : "v"(base));
-#else
-            asm volatile("v_pk_add_f32 %0, %1, %0 op_sel:[0,1] op_sel_hi:[1,0]\n\ts_nop 0" : "+v"(pr) : "v"(base));
-#endif
-            w_im = pr.x; h_im = pr.y;
-#endif
-        }
-#else
         float h_im = (fy0 + khf) + od[2 * j];
         float w_im = (fx0 + kwf) + od[2 * j + 1];
-#endif
         const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W && !(lrow && j == 4);
         h_im = valid ? h_im : 0.f;  // keeps the arithmetic below finite; its weights are zeroed through the mask
         w_im = valid ? w_im : 0.f;
@@ -322,46 +191,7 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
             if (j < 4) bw[5 + j][c >> 1][c & 1] = __uint_as_float(hi[1 + c]);
         }
     }
-#if CP_DCN_EXP & 32
-    {
-        float o9[28];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const float4 v = buf_ld4(r_om, rec + 16u * i);
-            o9[4 * i] = v.x; o9[4 * i + 1] = v.y; o9[4 * i + 2] = v.z; o9[4 * i + 3] = v.w;
-        }
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            float h_im = (fy0 + (float)(t / 3)) + o9[2 * t];
-            float w_im = (fx0 + (float)(t % 3)) + o9[2 * t + 1];
-            const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W;
-            h_im = valid ? h_im : 0.f;
-            w_im = valid ? w_im : 0.f;
-            const float mk = valid ? o9[18 + t] * afwd : 0.f;
-            const float fh = floorf(h_im), fw = floorf(w_im);
-            const int h_lo = (int)fh, w_lo = (int)fw;
-            const float lh = h_im - fh, lw = w_im - fw;
-            const float hh = 1.f - lh, hw = 1.f - lw;
-            const float e1 = hh * hw * mk, e2 = hh * lw * mk, e3 = lh * hw * mk, e4 = lh * lw * mk;
-            const int qy = h_lo - (ty0 - HALO), qx = w_lo - (tx0 - HALO);
-            const bool inp = (unsigned)qy <= (unsigned)(PH - 2) && (unsigned)qx <= (unsigned)(PW - 2);
-            const int ea = (inp ? qy * PW + qx : 0) * PSTR + lrow * 32;
-            bool bad;
-            if (valid && !inp) bad = !(addr[t] >= NPIX * PSTR || exc_count > ECAP);  // filed as an exception (or overflow)
-            else bad = addr[t] != ea || bw[t][0].x != e1 || bw[t][0].y != e2 || bw[t][1].x != e3 || bw[t][1].y != e4;
-            if (bad) {
-                const unsigned k = atomicAdd(&g_dcn_chk[0], 1u);
-                if (k < 64) {
-                    unsigned* o = g_dcn_chk + 8 + 8 * k;
-                    o[0] = blockIdx.x; o[1] = tid; o[2] = t; o[3] = (unsigned)addr[t]; o[4] = (unsigned)ea;
-                    o[5] = __float_as_uint(bw[t][0].x); o[6] = __float_as_uint(e1); o[7] = (unsigned)(valid ? 1 : 0) | (inp ? 2 : 0);
-                }
-            }
-        }
-    }
-#endif
     __syncthreads();
-    DCN_STAMP(3);  // records arrived, set-up done, second barrier passed
     const int nexc_all = __builtin_amdgcn_readfirstlane(exc_count);  // scalar: the mode branches below stay uniform
     const bool slow = nexc_all > ECAP;                               // block-uniform
     const int nexc = nexc_all < ECAP ? nexc_all : ECAP;
@@ -382,7 +212,6 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     static_assert(NT % NW == 0 && NHS % 3 == 0, "weight set rotation");
     u32x4 wbh[3][NW], wbl[3][NW];
     auto issue_b = [&](int set, int g, int h) {
-        if (ABL && (abl & 8)) return;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             wbh[set][j] = __builtin_amdgcn_raw_buffer_load_b128(r_wh, (int)b_voff[h * NW + j], g * 1024, 0);
@@ -412,13 +241,6 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     auto mma_step = [&](const float4 (&r)[4][2], const f32x2 (&w)[2], int s0, auto&& mid) {
         // fma(w4, v4, fma(w3, v3, fma(w2, v2, w1 * v1))) per channel (dcn16.hip's order), two per v_pk_fma_f32
         uint32_t hi[4], lo[4];
-        if (ABL && (abl & 2)) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                hi[q] = __float_as_uint(r[0][q >> 1].x) ^ __float_as_uint(r[3][q >> 1].y);
-                lo[q] = __float_as_uint(r[1][q >> 1].z) ^ __float_as_uint(r[2][q >> 1].w);
-            }
-        } else
 #pragma unroll
         for (int hq = 0; hq < 2; ++hq) {
             const float4 v1 = r[0][hq], v2 = r[1][hq], v3 = r[2][hq], v4 = r[3][hq];
@@ -442,14 +264,6 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
             __builtin_amdgcn_sched_barrier(0);
             mid(h);
             __builtin_amdgcn_sched_barrier(0);
-#if CP_DCN_EXP & 64
-            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-#endif
-            if (ABL && (abl & 4)) {  // keep the operands alive without the matrix pipe
-#pragma unroll
-                for (int j = 0; j < NW; ++j) acc[0][h * NW + j][0] += __uint_as_float(ahv.x ^ alv.y ^ bh[j].x ^ bl[j].y);
-                continue;
-            }
             // same term order as igemm16.hip (lo*hi, hi*lo, hi*hi)
 #pragma unroll
             for (int j = 0; j < NW; ++j)
@@ -466,7 +280,6 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
     if (!slow) {
         // ================= fast mode: every sample is in LDS =================
         auto gather = [&](float4 (&r)[4][2], int a) {  // a: addr[tap] + 64 (K step % 2)
-            if (ABL && (abl & 1)) return;
             const unsigned char* ap = patch + a;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -501,10 +314,8 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
         issue_hs(0, 0);
         issue_hs(1, 0);
         for (int ch = 0; ch < nch; ++ch) {
-            DCN_STAMP(4 + 24 * ch);  // chunk start
             if (ch > 0) __syncthreads();  // every wave is done with the previous chunk's patch
-            DCN_STAMP(5 + 24 * ch);
-            if (!(ABL && (abl & 16))) {
+            {
                 const int csoff = ch * (CKC * 4);
                 int sb = st_base;
                 asm volatile("" : "+v"(sb));  // per chunk: keeps the 14 row offsets from being hoisted into 14 registers
@@ -514,10 +325,6 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
                 };
                 // two rounds of 7 rows: half the registers in flight (one round of 14 measured the same)
                 constexpr int H1 = PH / 2;
-                if (EARLY && ch == 0) {
-                    // the rows were requested and parked at the top of the kernel: only the exception samples are left
-                    stage_exceptions(csoff);
-                } else {
                 {
                     float4 sv[H1];
 #pragma unroll
@@ -535,21 +342,13 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
                     for (int s = H1; s < PH; ++s)
                         if (spx < PW) *reinterpret_cast<float4*>(patch + st_lds + s * (PW * PSTR)) = sv[s - H1];
                 }
-                }
             }
             __syncthreads();
-            DCN_STAMP(6 + 24 * ch);  // chunk staged
             // NT = 2: two gather register sets, step u + 1 requested before the blend of step u.  NT = 4: ONE set (the accumulators
             // took the other's 32 registers): step u + 1 is requested right after the blend of step u has consumed it, in front of
             // that step's 12 MFMAs, which cover the LDS round trip
             constexpr int RS = NT >= 4 ? 1 : 2;
             float4 raw[RS][4][2];
-            if (ABL) {
-#pragma unroll
-                for (int i = 0; i < RS; ++i)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) raw[i][c][0] = raw[i][c][1] = make_float4(1.f, 2.f, 3.f, 4.f);
-            }
             gather(raw[0], addr[0]);
 #pragma unroll
             for (int u = 0; u < NSTEP; ++u) {
@@ -557,16 +356,12 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
                 // just above its first use -- no prefetch, a full LDS / L2 round trip exposed per step
                 if (RS == 2 && u + 1 < NSTEP) gather(raw[(u + 1) % RS], addr[(u + 1) >> 1] + ((u + 1) & 1) * 64);
                 __builtin_amdgcn_sched_barrier(0);
-#if CP_DCN_EXP & 1024
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
                 mma_step(raw[u % RS], bw[u >> 1], u * NH, [&](int h) {
                     if (RS == 1 && h == 0 && u + 1 < NSTEP) gather(raw[0], addr[(u + 1) >> 1] + ((u + 1) & 1) * 64);
                     // the set half-step s - 1 consumed takes half-step s + 2 (of this chunk or the next)
                     issue_hs(u * NH + h + 2, ch);
                 });
                 __builtin_amdgcn_sched_barrier(0);
-                if ((CP_DCN_EXP & 16) || u == NSTEP - 1) DCN_STAMP(7 + 24 * ch + ((CP_DCN_EXP & 16) ? u : 0));  // per step (16) / chunk done
             }
         }
     } else {
@@ -623,93 +418,7 @@ __global__ __launch_bounds__(256, 2) void dcn16p_kernel(const ConvParams p, cons
             }
         }
     }
-    DCN_STAMP(60);  // K loop done
-    if (ABL && (abl & 64)) {  // keep the accumulators alive: one conditional store that never happens
-        float sacc = 0.f;
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < F::NACC; ++r) sacc += acc[0][j][r];
-        if (sacc == 1.2345e-30f) p.out[0] = sacc;
-        return;
-    }
-#if CP_DCN_EXP & 2048
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#endif
     patch_epilogue<1, NT, 4, 1, true>(p, acc, b, ty0, tx0, tn, wid, 0, lane, ainv);
-    DCN_STAMP(61);  // epilogue stores issued
-#if CP_DCN_EXP & 262144
-    if (!slow) {
-        float o9[28];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const float4 v = buf_ld4(r_om, rec + 16u * i);
-            o9[4 * i] = v.x; o9[4 * i + 1] = v.y; o9[4 * i + 2] = v.z; o9[4 * i + 3] = v.w;
-        }
-        // the set-up of one tap from (h_im, w_im, mask): corner address and the four weights; false if it is an exception sample
-        auto derive = [&](float h_im, float w_im, float m, int* ea, float (&e)[4]) -> bool {
-            const bool valid = h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W;
-            h_im = valid ? h_im : 0.f;
-            w_im = valid ? w_im : 0.f;
-            const float mk = valid ? m * afwd : 0.f;
-            const float fh = floorf(h_im), fw = floorf(w_im);
-            const int h_lo = (int)fh, w_lo = (int)fw;
-            const float lh = h_im - fh, lw = w_im - fw;
-            const float hh = 1.f - lh, hw = 1.f - lw;
-            e[0] = hh * hw * mk; e[1] = hh * lw * mk; e[2] = lh * hw * mk; e[3] = lh * lw * mk;
-            const int qy = h_lo - (ty0 - HALO), qx = w_lo - (tx0 - HALO);
-            const bool inp = (unsigned)qy <= (unsigned)(PH - 2) && (unsigned)qx <= (unsigned)(PW - 2);
-            *ea = (inp ? qy * PW + qx : 0) * PSTR + lrow * 32;
-            return !(valid && !inp);
-        };
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float hb = fy0 + (float)(t / 3), wb = fx0 + (float)(t % 3);
-            const float dy = o9[2 * t], dx = o9[2 * t + 1];
-            const float h_im = hb + dy, w_im = wb + dx;
-            int ea;
-            float e[4];
-            bool bad;
-            if (!derive(h_im, w_im, o9[18 + t], &ea, e)) bad = !(addr[t] >= NPIX * PSTR || slow);  // filed as an exception (or overflow)
-            else bad = addr[t] != ea || bw[t][0].x != e[0] || bw[t][0].y != e[1] || bw[t][1].x != e[2] || bw[t][1].y != e[3];
-            if (bad) {
-                // which wrong operand reproduces the held set-up?  The two sums are one packed add {w_im, h_im} = {wb, hb} + {dx, dy}
-                // written over its own swizzled source {dy, dx}.  Candidates (bit in the log word):
-                //   1  h_im = hb + w_im          (high pass read the low word after the low pass had written it)
-                //   2  w_im = wb + dy            (low pass read the low source word: its op_sel dropped)
-                //   4  w_im = wb + h_im          (low pass read the high word after the high pass had written it)
-                //   8  w_im = wb + dx of tap t - 1,  16  w_im = wb + dx of tap t + 1   (a neighbouring slot's operand)
-                //   32 w_im = wb + (dx + dy)     (both source words added)
-                const float cand_h[6] = {hb + w_im, h_im, h_im, h_im, h_im, h_im};
-                const float cand_w[6] = {w_im, wb + dy, wb + h_im, wb + o9[2 * (t > 0 ? t - 1 : 0) + 1], wb + o9[2 * (t < 8 ? t + 1 : 8) + 1],
-                                         wb + (dx + dy)};
-                unsigned match = 0;
-                int eb = 0;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    float g[4];
-                    int ec;
-                    const bool plain = derive(cand_h[c], cand_w[c], o9[18 + t], &ec, g);
-                    const bool m = plain ? (addr[t] == ec && bw[t][0].x == g[0] && bw[t][0].y == g[1] && bw[t][1].x == g[2] &&
-                                            bw[t][1].y == g[3])
-                                         : addr[t] >= NPIX * PSTR;
-                    if (m) match |= 1u << c;
-                    if (c == 1) eb = ec;
-                }
-                const unsigned k = atomicAdd(&g_dcn_chk[0], 1u);
-#pragma unroll
-                for (int c = 0; c < 6; ++c)
-                    if (match & (1u << c)) atomicAdd(&g_dcn_chk[1 + c], 1u);
-                if (k < 64) {
-                    unsigned* o = g_dcn_chk + 8 + 8 * k;
-                    o[0] = blockIdx.x; o[1] = (unsigned)tid | (match << 16); o[2] = t; o[3] = (unsigned)addr[t]; o[4] = (unsigned)ea;
-                    o[5] = __float_as_uint(bw[t][0].x); o[6] = __float_as_uint(e[0]); o[7] = (unsigned)eb;
-                }
-            }
-        }
-    }
-#endif
-
 }
 
 // [CoutPad][Kpad16] binary16 -> MFMA B-operand order: fragment (n tile j of 32, K step g of 16) = 64 lanes x 16 bytes,
@@ -729,12 +438,6 @@ template <int NT>
 int launch_dcn16p(const ConvParams& p, hipStream_t stream) {
     constexpr int BN = 32 * NT;
     const int tiles_m = p.B * (p.H / TH) * (p.W / TW), tiles_n = p.CoutPad / BN;
-    if constexpr (NT == 2) {  // (the timing ablations exist for the 64-wide kernel only)
-        if ((unsigned)p.dbg >> 25) {
-            hipLaunchKernelGGL((dcn16p_kernel<NT, true>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m, tiles_n);
-            return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
-        }
-    }
     hipLaunchKernelGGL((dcn16p_kernel<NT>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, p, tiles_m, tiles_n);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
@@ -759,7 +462,7 @@ int cp_dcn16p_blocks(const ConvParams& p) { return p.B * (p.H / TH) * (p.W / TW)
 // @64^2 379 -> 262 us, 256 -> 128 @32^2 171 -> 131, 256 -> 256 @32^2 364 -> 258, and 512 -> 256 @16^2 -- 256 workgroups -- 160 ->
 // 151).  cp_set_debug 524288: never (A/B runs, tests).
 bool cp_dcn16p_wide(const ConvParams& p) {
-    return cp_dcn16p_supported(p) && p.CoutPad % 128 == 0 && !(p.dbg & 524288) && !((unsigned)p.dbg >> 25) &&
+    return cp_dcn16p_supported(p) && p.CoutPad % 128 == 0 && !(p.dbg & 524288) &&
            ((p.dbg & 65536) || p.B * (p.H / TH) * (p.W / TW) * (p.CoutPad / 128) >= 256);  // (65536: launches of any size, tests)
 }
 

@@ -28,23 +28,6 @@
 
 #include "patch16_common.h"
 
-// Tuning builds (make variant ... DEFS=-DCP_DCN_EXP=n; timing only, results wrong): 1 << 20 no halo / corner DMA, 1 << 21 no
-// weight-fragment loads, 1 << 22 no epilogue stores, 1 << 23 no gather reads, 1 << 24 no MFMAs, 1 << 25 no blend arithmetic
-#ifndef CP_DCN_EXP
-#define CP_DCN_EXP 0
-#endif
-
-#if CP_DCN_EXP & 8
-// tuning build 8: shader-clock stamps of wave 0 of one mid-launch workgroup during its fourth item (tools/dcn16s_timeline.py)
-__device__ unsigned long long g_dcn16s_clk[64];
-#define S_STAMP(i) do { if (blockIdx.x == 203 && threadIdx.x == 0 && item_no == 3) g_dcn16s_clk[i] = clock64(); } while (0)
-extern "C" int cp_debug_read_dcn16s_clk(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dcn16s_clk), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
-}
-#else
-#define S_STAMP(i) do { } while (0)
-#endif
-
 namespace {
 
 constexpr int S_TH = PATCH_TH, S_TW = PATCH_TW, S_HALO = 4;
@@ -91,7 +74,6 @@ __device__ __forceinline__ void s_both_halves5(const uint32_t (&v)[5], uint32_t 
 // s_waitcnt vmcnt, visibility to other waves = a barrier after that.  s_nop 4: the operands may come straight from
 // v_readfirstlane / v_cmp (VALU-written SGPRs read by VMEM); s_nop 0: M0 written by SALU, read by the DMA.
 __device__ __forceinline__ void s_dma16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned lds_addr) {
-    if (CP_DCN_EXP & (1 << 20)) return;
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :
                  : "s"(lds_addr), "v"(voff), "s"(r), "s"(soff)
@@ -194,7 +176,6 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
     //      register sets, K step s of an item uses set s % 3 (9 steps per chunk keep the rotation aligned) ----
     u32x4 wbh[3][NT], wbl[3][NT];
     auto issue_b = [&](int set, int tn, int g) {
-        if ((CP_DCN_EXP & (1 << 21)) && g >= 0) return;
         const unsigned b_lane = (unsigned)(lane * 16);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -204,12 +185,6 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
         }
     };
 
-    if (CP_DCN_EXP & (1 << 21)) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) wbh[k][j] = wbl[k][j] = u32x4{0x3c003c00u + (unsigned)lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-    }
     // the epilogue's per-channel scale / shift of N tile tn, once per workgroup (again only if a later item has another tn)
     auto write_scsh = [&](int tn) {
         if (tid < 32 * NT) {
@@ -242,8 +217,6 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
 
     float amax = 0.f;
     int parity = 0;  // patch parity: which exception counter this item uses
-    int item_no = 0;
-    (void)item_no;
     const int act = p.act;
 
     for (;;) {
@@ -251,7 +224,6 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
         const bool has_next = it_next < it_end;
         const SItem nxt = s_item(has_next ? it_next : it, tiles_n, txs, tys);
         int* const ecnt = reinterpret_cast<int*>(smem + S_ECNT);
-        S_STAMP(0);
 
         // ---- bilinear set-up (dcn_v2_im2col_cuda.cu:25-54, 150-187): 5 tap slots per lane, then both halves swap ----
         const int ln0 = s_opaque(lane), lrow = ln0 >> 5, q8 = (ln0 >> 2) & 7;
@@ -312,9 +284,7 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
                 if (j < 4) bw[5 + j][c >> 1][c & 1] = __uint_as_float(hi[1 + c]);
             }
         }
-        S_STAMP(1);
         __syncthreads();  // the exception list is complete
-        S_STAMP(2);
         const int nexc_all = __builtin_amdgcn_readfirstlane(ecnt[parity]);
         const bool slow = nexc_all > S_ECAP;  // block-uniform
         const int nexc = nexc_all < S_ECAP ? nexc_all : S_ECAP;
@@ -333,13 +303,6 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
         auto mma_step = [&](const float4 (&r)[4][2], const s_f32x2 (&w)[2], const u32x4 (&bh)[NT], const u32x4 (&bl)[NT],
                             auto&& mid) {
             uint32_t hi[4], lo[4];
-            if (CP_DCN_EXP & (1 << 25)) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    hi[q] = __float_as_uint(r[0][q >> 1].x) ^ __float_as_uint(r[3][q >> 1].y) ^ __float_as_uint(w[0].x);
-                    lo[q] = __float_as_uint(r[1][q >> 1].z) ^ __float_as_uint(r[2][q >> 1].w) ^ __float_as_uint(w[1].y);
-                }
-            } else
 #pragma unroll
             for (int hq = 0; hq < 2; ++hq) {
                 const float4 v1 = r[0][hq], v2 = r[1][hq], v3 = r[2][hq], v4 = r[3][hq];
@@ -357,14 +320,6 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
             __builtin_amdgcn_sched_barrier(0);
             mid();
             __builtin_amdgcn_sched_barrier(0);
-#if defined(CP_DCN_EXP) && (CP_DCN_EXP & 64)
-            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // tuning build: slower K steps (tools/probe/dcn16p_race.py)
-#endif
-            if (CP_DCN_EXP & (1 << 24)) {  // keep the operands alive without the matrix pipe
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j][0] += __uint_as_float(ahv.x ^ alv.y ^ bh[j].x ^ bl[j].y);
-                return;
-            }
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&bh[j]), al, acc[j], 0, 0, 0);
@@ -435,9 +390,7 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 blend_corners(0);
             }
-            S_STAMP(3);
             __syncthreads();
-            S_STAMP(4);
 
             // One K step of the software pipeline (all of it one wave's instruction stream, written slot by slot): the six MFMAs of
             // step t, each followed by an eighth-of-a-step of the NEXT step's blend (8 VALU) and two of the memory instructions that
@@ -454,19 +407,11 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
                 } else if (has_next) {
                     issue_halo(nxt, 0, PAR ^ 1);
                 }
-                S_STAMP(5 + 4 * ch);
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned char* base = smem + PAR * S_BUFB;
                 float4 raw[2][4][2];
-                if (CP_DCN_EXP & (1 << 23)) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) raw[i][c][0] = raw[i][c][1] = make_float4(1.f, 2.f, 3.f, 4.f + (float)addr[c]);
-                }
                 // corner c (0 .. 3), both quads of this lane's channel half
                 auto gather_c = [&](float4 (&r)[4][2], int a, int c) {
-                    if (CP_DCN_EXP & (1 << 23)) return;
                     const unsigned char* ap = base + a + (c >> 1) * S_ROWB + (c & 1) * S_PXB;
                     r[c][0] = *reinterpret_cast<const float4*>(ap);
                     r[c][1] = *reinterpret_cast<const float4*>(ap + 16);
@@ -476,15 +421,6 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
                 // blend of quad hq in three pieces of 8 VALU: fma(w4, v4, fma(w3, v3, fma(w2, v2, w1 * v1))), then the hi / lo split
                 auto blend_piece = [&](const float4 (&r)[4][2], const s_f32x2 (&w)[2], uint32_t (&hi)[4], uint32_t (&lo)[4], int hq,
                                        int piece) {
-                    if (CP_DCN_EXP & (1 << 25)) {
-                        if (piece == 2) {
-                            hi[2 * hq] = __float_as_uint(r[0][hq].x) ^ __float_as_uint(w[0].x);
-                            hi[2 * hq + 1] = __float_as_uint(r[3][hq].y);
-                            lo[2 * hq] = __float_as_uint(r[1][hq].z) ^ __float_as_uint(w[1].y);
-                            lo[2 * hq + 1] = __float_as_uint(r[2][hq].w);
-                        }
-                        return;
-                    }
                     if (piece == 0) {
                         const float4 v1 = r[0][hq], v2 = r[1][hq];
                         o[0] = fmaf(w[0].y, v2.x, w[0].x * v1.x);
@@ -508,10 +444,6 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
                     const u32x4 ahv = {hi[0], hi[1], hi[2], hi[3]}, alv = {lo[0], lo[1], lo[2], lo[3]};
                     const h8 ah = *reinterpret_cast<const h8*>(&ahv), al = *reinterpret_cast<const h8*>(&alv);
                     const int j = k % NT, term = k / NT;
-                    if (CP_DCN_EXP & (1 << 24)) {
-                        acc[j][term] += __uint_as_float(ahv.x ^ alv.y ^ bh[j].x ^ bl[j].y);
-                        return;
-                    }
                     const h8 a = term == 0 ? al : ah;
                     const h8 b = *reinterpret_cast<const h8*>(term == 1 ? &bl[j] : &bh[j]);
                     // weights as the first operand: the accumulators hold the TRANSPOSED tile (rows = output channels, columns =
@@ -543,15 +475,12 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
                 // ---- chunk boundary: this wave's DMA pieces have landed once at most the 2 x 2 NT weight loads issued after
                 //      them (steps 7 and 8: the next chunk's first two steps) are outstanding; its exceptions' corners are
                 //      blended into the other buffer; one barrier ----
-                S_STAMP(6 + 4 * ch);
                 if (!last || has_next) {
                     if (NT == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 if (!last) blend_corners(PAR ^ 1);
-                S_STAMP(7 + 4 * ch);
                 __syncthreads();
-                S_STAMP(8 + 4 * ch);
             };
             for (int ch = 0; ch < nch; ch += 2) {
                 chunk(std::integral_constant<int, 0>(), ch);
@@ -612,7 +541,6 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
         }
 
         // =============================== patch boundary ===============================
-        S_STAMP(40);
         if (has_next) load_record(nxt);  // arrives under the epilogue's stores
         {
             // transposed tile: accumulator 4 g + i of N tile j in lane (pixel = lane % 32, half h4) = output channel
@@ -648,12 +576,9 @@ __global__ __launch_bounds__(256, 2) void dcn16s_kernel(const ConvParams p, cons
 #pragma unroll
                     for (int i = 0; i < 4; ++i) amax = fmaxf(amax, n_ok ? fabsf(v[i]) : 0.f);
                     const u32x4 pk4 = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                    if (!(CP_DCN_EXP & (1 << 22)) || v[0] == 1.2345e-30f)
-                        __builtin_amdgcn_raw_buffer_store_b128(pk4, ro, (int)(n_ok ? vpix + (unsigned)n0 * 4u : 0x80000000u), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(pk4, ro, (int)(n_ok ? vpix + (unsigned)n0 * 4u : 0x80000000u), 0, 0);
                 }
         }
-        S_STAMP(41);
-        ++item_no;
         if (!has_next) break;
         if (nxt.tn != cur.tn) {  // (block-uniform, rare: the grid stride is usually a multiple of the N tile count)
             __syncthreads();

@@ -8,6 +8,7 @@
 //   DLAUp :437-443, IDAUp :411-417, DeformConv :386-389 (DCN: DCNv2/dcn_v2.py:118-128),
 //   DLASeg.forward :523-570, ConvGRU convGRU.py:72-94, GroupNorm GN.py:4-9.
 #include "../../include/centerpose_hip.h"
+#include "../../include/centerpose_hip_testing.h"
 #undef CP_OK
 #undef CP_ERR_INVALID
 #undef CP_ERR_LAUNCH
@@ -133,7 +134,7 @@ int g_default_precision = CP_PREC_F32;
 // split-K policy: launches with fewer output tiles than kSplitTiles (and >= 8 K steps) are cut into K slices until
 // about kSplitTarget workgroups exist
 constexpr int kSplitTiles = 128, kSplitTarget = 384;  // (384 / 512 measured: B=32 equal, hourglass B=1 latency +7 %)
-int g_dbg = 0;  // cp_set_debug (A/B switches for tests and tuning): 8 split-K epilogue element-wise (not the quad form), 1 grouped heads write slabs + reduction launch, 2 grouped heads one workgroup per head (not per patch), 16 small launches on 128-row tiles, 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel, 256 unfused ConvGRU step, 512 no activation |max| tracking / pre-scale, 1024 previous DCN loop, 2048 alternative DCN wave counts, 4096 / 8192 halo kernel never / everywhere, 16384 LDS-staged weights in the N=32 halo kernel, 32768 / 65536 patch-resident DCN never / everywhere, 524288 patch-resident DCN never on the 128-wide N tile, 131072 GroupNorm'd heads' 1x1 on the matrix cores, 4194304 1x1 layers on the LDS-staged loop instead of pw16.hip, 8388608 cp_dcnv2_forward always on the generic kernel, 16777216 fused heads one launch per head instead of one grouped launch
+int g_dbg = 0;  // cp_set_debug (include/centerpose_hip_testing.h: kernel SELECTION switches for the parity tests and A/B runs; every choice computes the layer correctly): 8 split-K epilogue element-wise (not the quad form), 1 grouped heads write slabs + reduction launch, 2 grouped heads one workgroup per head (not per patch), 16 small launches on 128-row tiles, 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel, 256 unfused ConvGRU step, 512 no activation |max| tracking / pre-scale, 1024 previous DCN loop, 2048 alternative DCN wave counts, 4096 / 8192 halo kernel never / everywhere, 16384 LDS-staged weights in the N=32 halo kernel, 32768 / 65536 patch-resident DCN never / everywhere, 524288 patch-resident DCN never on the 128-wide N tile, 131072 GroupNorm'd heads' 1x1 on the matrix cores, 4194304 1x1 layers on the LDS-staged loop instead of pw16.hip, 8388608 cp_dcnv2_forward always on the generic kernel, 16777216 fused heads one launch per head instead of one grouped launch
 
 struct DeformW {
     ConvW offset;  // conv_offset_mask (27 -> 32 padded), shift = bias
@@ -1967,6 +1968,31 @@ int cp_track_step(cp_stream_t stream, const cp_track_params* params, const doubl
     const int rc = cp_launch_track_step((hipStream_t)stream, P, vmeta, post, count, P.use_pnp ? det_pnp : nullptr, B, P.K,
                                         state, render_recs, workspace);
     return rc == CP_OK ? CP_OK : fail(rc, "cp_track_step: launch failed");
+}
+
+int cp_linear_assignment(const double* cost, int n_rows, int n_cols, int solver, int* match_out) {
+    if (n_rows < 0 || n_cols < 0 || (n_rows > 0 && !match_out) || (n_rows > 0 && n_cols > 0 && !cost) || (solver != 1 && solver != 2))
+        return fail(CP_ERR_INVALID, "cp_linear_assignment: bad argument (solver: 1 Munkres, 2 scipy LSAP)");
+    const size_t ls = (size_t)(n_rows > n_cols ? n_rows : n_cols) + 1;
+    auto c = [&](int i, int j) -> double { return cost[(size_t)i * n_cols + j]; };
+    try {
+        if (solver == 2) {
+            std::vector<double> u(ls), v(ls), spc(ls);
+            std::vector<int> path(ls), c4r(ls), r4c(ls), rem(ls);
+            std::vector<unsigned char> sr(ls), sc(ls);
+            const TrkLsapWork W = {u.data(), v.data(), spc.data(), path.data(), c4r.data(), r4c.data(), rem.data(), sr.data(), sc.data()};
+            trk_lsap(c, n_rows, n_cols, match_out, W);
+        } else {
+            std::vector<double> C((size_t)n_rows * n_cols + 1);
+            std::vector<unsigned char> marked((size_t)n_rows * n_cols + 1), ru(ls), cu(ls);
+            std::vector<int> path(2 * ((size_t)n_rows + n_cols) + 2);
+            const TrkMunkresWork W = {C.data(), marked.data(), ru.data(), cu.data(), path.data()};
+            trk_munkres(c, n_rows, n_cols, match_out, W);
+        }
+    } catch (const std::bad_alloc&) {
+        return fail(CP_ERR_ALLOC, "cp_linear_assignment: out of host memory");
+    }
+    return CP_OK;
 }
 
 // Sticky per-video overflow counters of the device tracker (list entries dropped because a frame needed more than `cap`

@@ -445,7 +445,9 @@ __global__ void splitk_epilogue_kernel(const ConvParams p) {
 
 // The same for NHWC outputs with whole channel quads (every split-K layer of the networks): one lane = four consecutive
 // channels of a pixel, ALL slab reads (<= 32 slices x 16 bytes) in flight at once behind one buffer descriptor (slices beyond
-// splitk read out of range = exact zeros), then the sum in slice order -- one memory round trip.  The element-wise form above
+// splitk read out of range = exact zeros: the descriptor's num_records check includes soffset on gfx9-family parts, which
+// cp_common.h's architecture guard pins; a uniform `z < splitk` guard per load was tried instead and costs 76 scalar
+// branches + 39 spilled SGPRs in a kernel that is one memory round trip long), then the sum in slice order.  The element-wise form above
 // keeps 8 four-byte loads in flight and walks 32 slices in four dependent rounds: 6.5 us per launch, 48 launches = 0.31 ms of a
 // 1.43 ms batch-1 frame (profiles/r05_frame_trace_dla_34.txt).  Same additions in the same order: bit-identical.
 typedef uint32_t sk_u32x4 __attribute__((ext_vector_type(4)));

@@ -24,13 +24,6 @@ namespace {
 
 // PF2: two register sets for the global->LDS staging, i.e. tile t+2 is in flight while tile t is multiplied (a
 // 32-deep K-step is only ~770 MFMA cycles per wave, shorter than an L2 round trip under load).
-// tuning ablation switches (cp_set_debug) are compiled in only with -DCP_TUNE_DBG: as run-time branches they split
-// the fused steady-state block and cost ~5%
-#ifdef CP_TUNE_DBG
-#define CP_DBG(p) ((p).dbg)
-#else
-#define CP_DBG(p) 0
-#endif
 template <int MT, int NT, int WM, int WN, bool DCN, bool MULTISRC, bool PF2>
 __global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel(const ConvParams p, const int tiles_m, const int tiles_n) {
     typedef Frag<32> F;
@@ -121,14 +114,10 @@ __global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel
         b_off[j] = (unsigned)(((size_t)(tn * BN + f / 4) * p.Kpad16 + (f % 4) * 8 + (size_t)kt0 * BK16) * 2);
     }
 
-    bool dbg_first = true;
     auto load_tile = [&](float4* a_reg, u32x4* bh_reg, u32x4* bl_reg) {
-        const bool skipA = (CP_DBG(p) & 1) && !dbg_first, skipB = (CP_DBG(p) & 2) && !dbg_first;
-        dbg_first = false;
 #pragma unroll
         for (int j = 0; j < B_SLOTS; ++j) {
             const int f = tid + j * NT16;
-            if (skipB) break;
             if (B_CHUNKS % NT16 == 0 || f < B_CHUNKS) {
                 bh_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(r_wh, (int)b_off[j], 0, 0);
                 bl_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(r_wl, (int)b_off[j], 0, 0);
@@ -146,8 +135,7 @@ __global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel
             const int tap_pix = u_kh * p.W + u_kw;
             const int coff = u_cs + k4 * 4;
             const unsigned bit = 1u << u_tap;
-            if (skipA) {
-            } else if (MULTISRC) {
+            if (MULTISRC) {
 #pragma unroll
                 for (int j = 0; j < A_SLOTS; ++j) {
                     const unsigned off = (unsigned)((a_pix0[j] + tap_pix) * sc + coff) * 4u;
@@ -222,10 +210,7 @@ __global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel
         }
     };
 
-    bool dbg_first_store = true;
     auto store_tile = [&](int buf, const float4* a_reg, const u32x4* bh_reg, const u32x4* bl_reg) {
-        if ((CP_DBG(p) & 4) && !dbg_first_store) return;
-        dbg_first_store = false;
         _Float16* Ah = buf ? lds1 : lds0;
         _Float16* Al = Ah + A_SZ;
         _Float16* Bh = Al + A_SZ;
@@ -262,7 +247,6 @@ __global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel
     const int lcol = lane & 31;
 
     auto mma_tile = [&](int buf) {
-        if (CP_DBG(p) & 8) return;
         // fragment rows are (tile base, a multiple of 32) + lcol, so the swizzle only depends on lcol
         const _Float16* base = buf ? lds1 : lds0;
         const _Float16* Ah = base + (wm * (MT * 32) + lcol) * LDH;
@@ -378,33 +362,6 @@ __global__ __launch_bounds__(NT16, (DCN && NT == 1) ? 3 : 2) void igemm16_kernel
 //   sit between MFMAs instead of after them, and there is one barrier per tile.  Tiles past the end of K are loaded with out-of-range offsets (zeros, no memory traffic) and stored
 //   into a buffer nobody reads, which keeps the loop body branch-free.
 // ---------------------------------------------------------------------------------------------------------------
-// build-time ablations for tuning (make EXP=<bitmask>; timing only, results are wrong): 1 no global loads in the
-// loop, 2 no conversion / LDS stores in the loop, 4 no barrier in the loop, 8 no MFMA, 16 no epilogue
-#ifndef CP_EXP
-#define CP_EXP 0
-#endif
-#if CP_EXP & 256
-__device__ unsigned long long g_cp_clk[2];  // shader-clock / 100 MHz-clock ticks of workgroup 0 (tuning: actual frequency)
-#endif
-#if CP_EXP & 512
-// tuning build 512: 100 MHz-clock stamps of workgroup (0, 0) of the last 64 igemm16p_kernel launches at their phase boundaries
-// (tools/probe/small_launch_timeline.py): [launch % 64][0 .. 8] stamps, [9 .. 15] Cin, Cout, M, splitk, K tiles of the slice, PD, shader clocks entry -> end
-__device__ unsigned long long g_cp_tl[64 * 16 + 1];
-#define CP_TL_INIT() unsigned tl_slot = 0; if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) \
-    tl_slot = (unsigned)(atomicAdd(&g_cp_tl[64 * 16], 1ull) & 63ull); \
-    const unsigned long long tl_c0 = clock64()
-#define CP_TL(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_cp_tl[tl_slot * 16 + (i)] = wall_clock64(); } while (0)
-#define CP_TL_VAL(i, v) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_cp_tl[tl_slot * 16 + (i)] = (unsigned long long)(v); } while (0)
-#define CP_TL_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
-extern "C" int cp_debug_read_tl(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cp_tl), sizeof(unsigned long long) * (64 * 16 + 1)) == hipSuccess ? 0 : -1;
-}
-#else
-#define CP_TL_INIT() do { } while (0)
-#define CP_TL_VAL(i, v) do { } while (0)
-#define CP_TL(i) do { } while (0)
-#define CP_TL_DRAIN() do { } while (0)
-#endif
 // FUSE (128x128 tiles only): fused prediction head.  The main MFMAs run with swapped operands, so a wave's accumulators
 // hold hidden^T -- rows = 32 hidden channels of a fragment spread over (register, lane half), columns = 32 pixels over
 // the lanes.  That is exactly the B-operand shape of a second MFMA whose k runs over hidden channels: 8 consecutive
@@ -439,11 +396,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
     // reads and writes is pinned by hand below, no alias analysis needed)
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * BUF];
 
-#if CP_EXP & 256
-    const unsigned long long clk0 = clock64(), wclk0 = wall_clock64();
-#endif
-    CP_TL_INIT();
-    CP_TL(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = tid >> 6;
@@ -474,8 +426,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
     int kt0, kt1;
     splitk_range(p, nk, &kt0, &kt1);
     const int n = kt1 - kt0;
-    if ((CP_EXP & 32) && blockIdx.x >= 256 && blockIdx.x < 512)
-        for (int i = 0; i < n / 4; ++i) __builtin_amdgcn_s_sleep(127);
     int u_tap = 0, u_kh = 0, u_kw = 0, u_c0 = 0, u_src = 0, u_cs = 0;
     if (kt0 > 0) {
         const int k0 = kt0 * BK16;
@@ -638,7 +588,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
     };
     auto mfma_slot = [&](int s, const h8(&ah)[MT], const h8(&al)[MT], const h8(&bh)[NT], const h8(&bl)[NT]) {
         const int term = s / (MT * NT), idx = s % (MT * NT), i = idx / NT, j = idx % NT;
-        if (CP_EXP & 8) return;
         if (FUSE) {  // transposed product: rows = output channels, columns = pixels
             if (term == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
             else if (term == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
@@ -672,22 +621,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
                 // the k-step-1 fragment reads and the A conversion / store pieces alternate, the B stores come last
                 constexpr int NI = 2 * NR;  // interleaved prefix: read, piece, read, piece, ...
                 if (q < NI && (q & 1) == 0) read_frag(cur, 1, q / 2, f1ah, f1al, f1bh, f1bl);
-                else if (!(CP_EXP & 2)) {
+                else {
                     const int z = q < NI ? q / 2 : q - NR;  // index into the store pieces
-                    if (z < 4 * A_SLOTS) {
-                        store_a_piece(cur ^ 1, ga, z / 4, z % 4);
-                        if ((CP_EXP & 64) && z % 4 == 3) issue_a(ga, z / 4);
-                    } else {
-                        const int zb = z - 4 * A_SLOTS;
-                        store_b_piece(cur ^ 1, gbh, gbl, zb / 2, zb % 2);
-                        if ((CP_EXP & 64) && zb % 2 == 1) issue_b(gbh, gbl, zb / 2);
-                    }
+                    if (z < 4 * A_SLOTS) store_a_piece(cur ^ 1, ga, z / 4, z % 4);
+                    else store_b_piece(cur ^ 1, gbh, gbl, (z - 4 * A_SLOTS) / 2, (z - 4 * A_SLOTS) % 2);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (CP_EXP & 64) advance_k();
-        if (!(CP_EXP & 4)) __syncthreads();
+        __syncthreads();
         // ---------------- phase 2 ----------------
         constexpr int NL = A_SLOTS + B_SLOTS + 1;
         constexpr int P2 = NR + NL;
@@ -702,8 +644,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
                 const int l = q < NI ? q / 2 : q - NR;   // loader piece index when is_load
                 const int r = q < NI ? q / 2 : q - NL;   // read index otherwise
                 if (is_load) {
-                    if (CP_EXP & (1 | 64)) {
-                    } else if (l < A_SLOTS) issue_a(ga, l);
+                    if (l < A_SLOTS) issue_a(ga, l);
                     else if (l < A_SLOTS + B_SLOTS) issue_b(gbh, gbl, l - A_SLOTS);
                     else advance_k();
                 } else read_frag(cur ^ 1, 0, r, f0ah, f0al, f0bh, f0bl);
@@ -713,24 +654,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
     };
 
     // ---- prologue: tile 0 in buffer 0, tile 1 in the register set ----
-    CP_TL_VAL(9, p.Cin); CP_TL_VAL(10, p.Cout); CP_TL_VAL(11, M); CP_TL_VAL(12, p.splitk); CP_TL_VAL(13, n); CP_TL_VAL(14, 1);
-    CP_TL(1);
     issue_tile(ga, gbh, gbl);
-    CP_TL(2);
     if (!GNIN) conv_in_scale_finish(p, amax_raw, &afwd, &ainv);
-    CP_TL(3);
-    CP_TL_DRAIN();
-    CP_TL(4);
     store_all(0, ga, gbh, gbl, 2);
     issue_tile(ga, gbh, gbl);
     __syncthreads();
-    CP_TL(5);
 #pragma unroll
     for (int r = 0; r < NR; ++r) read_frag(0, 0, r, f0ah, f0al, f0bh, f0bl);
 
     for (int t = 0; t < n; ++t) iteration(t & 1);
-    CP_TL(6);
-    if ((CP_EXP & 16) && acc[0][0][0] != 12345.f) return;
     if constexpr (FUSE) {
         const int g = lane >> 5;
         // 1x1 weight fragments of this wave's 64 hidden channels: [tn][wn][j][s][lane] x 8 halfs
@@ -880,16 +812,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm16p_kernel(const ConvPar
     }
     if (p.splitk > 1) igemm_store_partial<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane, blockIdx.y);
     else igemm_epilogue<32, MT, NT, WM, WN>(p, acc, tm, tn, wm, wn, lane, ainv);
-    CP_TL(7);
-    CP_TL_DRAIN();
-    CP_TL(8);
-    CP_TL_VAL(15, clock64() - tl_c0);
-#if CP_EXP & 256
-    if (blockIdx.x == 4000 && threadIdx.x == 0) {
-        g_cp_clk[0] = clock64() - clk0;
-        g_cp_clk[1] = wall_clock64() - wclk0;
-    }
-#endif
 }
 
 template <int MT, int NT, int WM, int WN, bool DCN, bool MULTISRC>
@@ -1193,11 +1115,6 @@ int cp_launch_head_reduce_grouped(const float* slabs, const HeadReduceGroup& g, 
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 
-#if CP_EXP & 256
-extern "C" int cp_debug_read_clk(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cp_clk), sizeof(unsigned long long) * 2) == hipSuccess ? 0 : -1;
-}
-#endif
 
 // hidden-side ConvGRU convolution (64 -> [r|z|n] x 64, 3x3) with the gate arithmetic fused (ConvParams::gru_x3)
 int cp_launch_conv16_gru(const ConvParams& p, hipStream_t stream) {

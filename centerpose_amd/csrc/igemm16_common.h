@@ -43,14 +43,6 @@ __device__ __forceinline__ uint32_t pk(float a, float b) {
 // zero; CP_SPLIT4 keeps that form for A/B builds.)  The split is most of the loaders' and of the DCN blend's VALU work.
 __device__ __forceinline__ Split2 split2(float a, float b) {
     Split2 s;
-#if defined(CP_DCN_EXP) && (CP_DCN_EXP & 256)
-    {   // tuning build: the same split without inline assembly
-        fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-        s.hi = *reinterpret_cast<uint32_t*>(&h);
-        s.lo = pk(a - (float)h.x, b - (float)h.y);
-        return s;
-    }
-#endif
     fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
     s.hi = *reinterpret_cast<uint32_t*>(&h);
 #ifdef CP_SPLIT4

@@ -881,16 +881,21 @@ __device__ bool epnp(const Problem& q, const Valid& v, double param[6], double* 
 // lane per detection, eight detections of different branches sharing a wavefront: 8 ms for 650 of them).  Lane 0 runs the
 // branch's initialisation (EPnP: the whole solve; planar: homography -> pose) out of the workgroup's LDS work space; the
 // Levenberg-Marquardt refinement of the planar branch then runs on all 16 lanes like pnp_kernel's (lane = image point).
-__global__ __launch_bounds__(16) void pnp_rare_kernel(const float* __restrict__ pts, const float* __restrict__ scale,
+constexpr int RARE_LANES = 16;  // workgroup size of pnp_rare_kernel: the launcher below and the kernel's guard use this one constant
+__global__ __launch_bounds__(RARE_LANES) void pnp_rare_kernel(const float* __restrict__ pts, const float* __restrict__ scale,
                                                       const double* __restrict__ camp, int N, int npts,
                                                       double* __restrict__ out, const int* __restrict__ rare) {
     __shared__ double w[RARE_WS];
     // INVARIANT: the 16 lanes of this workgroup are one (partial) wavefront and run collect / epnp / planar_init in lock-step on
     // the ONE shared work space w[] -- every lane computes the same values and stores them to the same words (including the
     // read-modify-write accumulations), which is only sound inside a single wavefront.  Launch it with 16 threads, never more
-    // than 64 (__launch_bounds__(16) above; a larger block is refused here rather than computing garbage).
-    if (blockDim.x != 16) return;
+    // than 64 (__launch_bounds__ above; any other block size is refused here rather than computing garbage, and LOUDLY: the
+    // detections of the list get status 0 = "failure" instead of keeping pnp_kernel's internal -2 / -3 marks).
     if ((int)blockIdx.x >= rare[0]) return;
+    if (blockDim.x != RARE_LANES) {
+        if (threadIdx.x == 0) out[(size_t)rare[1 + blockIdx.x] * CP_PNP_STRIDE] = 0;
+        return;
+    }
     const int i = rare[1 + blockIdx.x], sub = threadIdx.x;
     double* o = out + (size_t)i * CP_PNP_STRIDE;
     const int status = (int)o[0];  // -2 (4-5 valid points) / -3 (planar model), written by pnp_kernel
@@ -948,6 +953,6 @@ int cp_launch_pnp(hipStream_t s, const float* pts, const float* scale, const dou
         hipLaunchKernelGGL(pnp_kernel, dim3((N * 16 + 63) / 64), dim3(64), 0, s, pts, scale, cam, N, npts, out, (double*)ws);
     // detections the common-case kernel marked -2 (4-5 valid points) / -3 (planar model) and appended to the list at `ws`:
     // one 16-lane workgroup per list entry (the grid covers the worst case; workgroups past the count leave at once)
-    hipLaunchKernelGGL(pnp_rare_kernel, dim3(N), dim3(16), 0, s, pts, scale, cam, N, npts, out, (const int*)ws);
+    hipLaunchKernelGGL(pnp_rare_kernel, dim3(N), dim3(RARE_LANES), 0, s, pts, scale, cam, N, npts, out, (const int*)ws);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }

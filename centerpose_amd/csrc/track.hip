@@ -52,9 +52,13 @@ __global__ __launch_bounds__(64) void track_prepare_kernel(const TrackParams P, 
     use[i] = ok;
 }
 
+__host__ __device__ inline size_t munkres_bytes(int K, int cap) {  // per video: C [K cap] doubles, marked [K cap] bytes, covers, path
+    return ((size_t)K * cap * 9 + (size_t)(K + cap) * (2 + 8) + 255) / 256 * 256;
+}
+
 __global__ __launch_bounds__(64) void track_associate_kernel(const TrackParams P, const int* __restrict__ count, int B, int K,
                                                              const double* __restrict__ dets, int* __restrict__ use,
-                                                             void* state) {
+                                                             void* state, unsigned char* __restrict__ munkres_ws) {
     __shared__ int plan[3 * 128];
     __shared__ int det_idx[128];
     __shared__ unsigned char taken[128];
@@ -79,7 +83,15 @@ __global__ __launch_bounds__(64) void track_associate_kernel(const TrackParams P
             for (int k = 0; k < nd; ++k) u[k] = 1;  // no box at all: every detection takes part (tracker.py:116-117)
         int idc = h[1], dropped = 0;
         const TrkLsapWork W = {ls_u, ls_v, ls_spc, ls_path, ls_c4r, ls_r4c, ls_rem, ls_sr, ls_sc};
-        const int n = trk_associate(P, d, u, nd, prev, h[0], plan, &idc, det_idx, taken, &dropped, &W, ls_match);
+        // Munkres work space of this video (global memory: the reduced cost matrix does not fit LDS)
+        unsigned char* mw = munkres_ws + (size_t)b * munkres_bytes(K, P.cap);
+        TrkMunkresWork MW;
+        MW.C = (double*)mw;
+        MW.path = (int*)(mw + (size_t)K * P.cap * 8);
+        MW.marked = mw + (size_t)K * P.cap * 8 + (size_t)(K + P.cap) * 8;
+        MW.row_unc = MW.marked + (size_t)K * P.cap;
+        MW.col_unc = MW.row_unc + (K + P.cap);
+        const int n = trk_associate(P, d, u, nd, prev, h[0], plan, &idc, det_idx, taken, &dropped, &W, ls_match, &MW);
         h[1] = idc;
         h[2] += dropped;  // sticky count of list entries dropped because a frame needed more than `cap` (cp_track_status)
         s_n = n;
@@ -148,7 +160,8 @@ size_t cp_track_state_bytes_impl(int B, int cap) {
 size_t cp_track_ws_bytes_impl(int B, int K, int cap) {
     const size_t n = (size_t)B * cap;
     return align256((size_t)B * K * CP_TRACK_STRIDE * 8) + align256((size_t)B * K * 4) + align256(n * 16 * 4) +
-           align256(n * 3 * 4) + align256(n * 4 * 8) + align256(n * 40 * 8) + cp_pnp_ws_bytes((int)n);
+           align256(n * 3 * 4) + align256(n * 4 * 8) + align256(n * 40 * 8) + align256(cp_pnp_ws_bytes((int)n)) +
+           (size_t)B * munkres_bytes(K, cap);
 }
 
 int cp_launch_track_step(hipStream_t s, const TrackParams& P, const double* vmeta, const double* post, const int* count,
@@ -167,9 +180,10 @@ int cp_launch_track_step(hipStream_t s, const TrackParams& P, const double* vmet
     w += align256(n * 4 * 8);
     double* rows = (double*)w;
     w += align256(n * 40 * 8);
+    unsigned char* munkres_ws = (unsigned char*)w + align256(cp_pnp_ws_bytes((int)n));  // behind the PnP work space (at `w`)
     hipLaunchKernelGGL(track_prepare_kernel, dim3((B * K + 63) / 64), dim3(64), 0, s, P, vmeta, post, count, det_pnp, B, K,
                        dets, use);
-    hipLaunchKernelGGL(track_associate_kernel, dim3(B), dim3(64), 0, s, P, count, B, K, dets, use, state);
+    hipLaunchKernelGGL(track_associate_kernel, dim3(B), dim3(64), 0, s, P, count, B, K, dets, use, state, munkres_ws);
     hipLaunchKernelGGL(track_advance_kernel, dim3(((int)n + 63) / 64), dim3(64), 0, s, P, vmeta, B, state, pts, scale, cam);
     const bool pnp = P.use_pnp && (P.kalman || P.scale_pool);
     if (pnp) {

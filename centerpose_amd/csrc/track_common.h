@@ -171,6 +171,138 @@ CP_HD void trk_lsap(const Cost& cost, int nd, int nt, int* match, const TrkLsapW
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The assignment the reference really calls: sklearn.utils.linear_assignment_.linear_assignment of scikit-learn 0.22.2
+// (tracker.py:6,157; requirements.txt:13) -- the Kuhn-Munkres state machine (row reduction and greedy starring, cover the
+// starred columns, prime uncovered zeros, augment along the prime / star path, add the smallest uncovered value to covered
+// rows and subtract it from uncovered columns).  The module is absent from every scikit-learn since 0.23; oracle/munkres.py
+// restates it in numpy and this is the same restatement in scalar form for the device and the host build: the SAME float64
+// operations on the same elements in the same order (row minimum subtracted; in the adjustment step first `+= minval` on
+// covered rows, then `-= minval` on uncovered columns -- two roundings where both apply), zeros are `== 0` exactly, and every
+// search returns the FIRST hit in numpy's order (row-major for the uncovered zero, lowest index for the star / prime of a
+// line), because which optimum comes out of a degenerate problem -- the tracker's matrices are full of 1e18 -- depends on all
+// of that, and new tracking ids are handed out in the order of the left-over detections.
+// cost(i, j): det i x track j; nd x nt; match[i] = track of det i or -1 (min(nd, nt) detections / tracks get a partner).
+// Work space for n = min(nd, nt) rows and m = max(nd, nt) columns: C [n m] doubles, marked [n m] bytes (0 / 1 star / 2 prime),
+// row_unc [n] / col_unc [m] bytes, path [2 (n + m)] ints.  Cost: O(n m) per search and per adjustment, O(n^2 m) .. O(n^3 m)
+// in all on one lane -- microseconds for a frame's ten detections, long for a hundred mutually tied ones; the scipy form
+// above (hungarian = 2) is the fast one.
+struct TrkMunkresWork {
+    double* C; unsigned char* marked; unsigned char* row_unc; unsigned char* col_unc; int* path;
+};
+template <class Cost>
+CP_HD void trk_munkres(const Cost& cost, int nd, int nt, int* match, const TrkMunkresWork& W) {
+    for (int i = 0; i < nd; ++i) match[i] = -1;
+    if (nd == 0 || nt == 0) return;
+    const bool tr = nt < nd;  // more rows (detections) than columns: the transpose is solved, the pairs swapped back
+    const int n = tr ? nt : nd, m = tr ? nd : nt;
+    double* C = W.C;
+    unsigned char* mk = W.marked;
+    // ---- step 1: row reduction; star zeros whose row and column hold no star yet (row-major scan) ----
+    for (int i = 0; i < n; ++i) {
+        double lo = tr ? cost(0, i) : cost(i, 0);
+        for (int j = 0; j < m; ++j) {
+            const double c = tr ? cost(j, i) : cost(i, j);
+            C[i * m + j] = c;
+            if (c < lo) lo = c;
+        }
+        for (int j = 0; j < m; ++j) C[i * m + j] -= lo;
+    }
+    for (int i = 0; i < n; ++i) W.row_unc[i] = 1;
+    for (int j = 0; j < m; ++j) W.col_unc[j] = 1;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < m; ++j) {
+            mk[i * m + j] = 0;
+            if (C[i * m + j] == 0.0 && W.col_unc[j] && W.row_unc[i]) {
+                mk[i * m + j] = 1;
+                W.col_unc[j] = 0;
+                W.row_unc[i] = 0;
+            }
+        }
+    for (;;) {
+        // ---- step 3: covers cleared, starred columns covered; n stars = a complete assignment ----
+        for (int i = 0; i < n; ++i) W.row_unc[i] = 1;
+        for (int j = 0; j < m; ++j) W.col_unc[j] = 1;
+        int stars = 0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < m; ++j)
+                if (mk[i * m + j] == 1) { W.col_unc[j] = 0; ++stars; }
+        if (stars >= n) break;
+        int zr = -1, zc = -1;
+        for (;;) {
+            // ---- step 4: prime the first uncovered zero (row-major) until one has no star in its row ----
+            for (;;) {
+                int row = -1, col = -1;
+                for (int i = 0; i < n && row < 0; ++i) {
+                    if (!W.row_unc[i]) continue;
+                    for (int j = 0; j < m; ++j)
+                        if (W.col_unc[j] && C[i * m + j] == 0.0) { row = i; col = j; break; }
+                }
+                if (row < 0) break;  // none left: adjust the matrix
+                mk[row * m + col] = 2;
+                int star = -1;
+                for (int j = 0; j < m; ++j)
+                    if (mk[row * m + j] == 1) { star = j; break; }
+                if (star < 0) { zr = row; zc = col; break; }
+                W.row_unc[row] = 0;
+                W.col_unc[star] = 1;
+            }
+            if (zr >= 0) break;
+            // ---- step 6: smallest uncovered value: + on covered rows, then - on uncovered columns ----
+            bool any_r = false, any_c = false;
+            for (int i = 0; i < n; ++i) any_r = any_r || W.row_unc[i];
+            for (int j = 0; j < m; ++j) any_c = any_c || W.col_unc[j];
+            if (any_r && any_c) {
+                double minval = 0.0;
+                bool have = false;
+                for (int i = 0; i < n; ++i) {
+                    if (!W.row_unc[i]) continue;
+                    for (int j = 0; j < m; ++j)
+                        if (W.col_unc[j] && (!have || C[i * m + j] < minval)) { minval = C[i * m + j]; have = true; }
+                }
+                for (int i = 0; i < n; ++i)
+                    if (!W.row_unc[i])
+                        for (int j = 0; j < m; ++j) C[i * m + j] += minval;
+                for (int j = 0; j < m; ++j)
+                    if (W.col_unc[j])
+                        for (int i = 0; i < n; ++i) C[i * m + j] -= minval;
+            }
+        }
+        // ---- step 5: alternating path from the primed zero; stars on it go, its primes become stars; primes erased ----
+        int count = 0;
+        W.path[0] = zr;
+        W.path[1] = zc;
+        for (;;) {
+            const int pc = W.path[2 * count + 1];
+            int row = -1;
+            for (int i = 0; i < n; ++i)
+                if (mk[i * m + pc] == 1) { row = i; break; }
+            if (row < 0) break;
+            ++count;
+            W.path[2 * count] = row;
+            W.path[2 * count + 1] = pc;
+            int pcol = -1;
+            for (int j = 0; j < m; ++j)
+                if (mk[row * m + j] == 2) { pcol = j; break; }
+            ++count;
+            W.path[2 * count] = row;
+            W.path[2 * count + 1] = pcol;  // (a star on the path always has a prime in its row)
+        }
+        for (int k = 0; k <= count; ++k) {
+            unsigned char& e = mk[W.path[2 * k] * m + W.path[2 * k + 1]];
+            e = e == 1 ? 0 : 1;
+        }
+        for (int i = 0; i < n * m; ++i)
+            if (mk[i] == 2) mk[i] = 0;
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < m; ++j)
+            if (mk[i * m + j] == 1) {
+                if (tr) match[j] = i;  // row = track, column = detection
+                else match[i] = j;
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Gaussian fusion (base_detector.py:503-536), hps_uncertainty branch and the fixed-variance branch.  The reference's standard
 // deviations are float32 numpy scalars and its means float64 ones, so `std ** -2`, their sum and `** -0.5` are float32
 // operations (numpy keeps float32 ** python-int / python-float in float32) and only the products with the means promote to
@@ -642,7 +774,8 @@ CP_HD void trk_render_records(const TrackParams& P, const double* vm, const doub
 // is given to a dropped detection; a dropped coasting track is simply retired early) and the caller can surface the event.
 CP_HD int trk_associate(const TrackParams& P, const double* dets, const int* use, int nd_all, const double* prev, int np,
                         int* plan, int* id_count, int* det_idx /* scratch [K] */, unsigned char* taken /* scratch [cap] */,
-                        int* dropped, const TrkLsapWork* lsap = nullptr, int* lsap_match /* scratch [K] */ = nullptr) {
+                        int* dropped, const TrkLsapWork* lsap = nullptr, int* lsap_match /* scratch [K] */ = nullptr,
+                        const TrkMunkresWork* munkres = nullptr) {
     *dropped = 0;
     int nd = 0;
     for (int k = 0; k < nd_all; ++k)
@@ -685,7 +818,10 @@ CP_HD int trk_associate(const TrackParams& P, const double* dets, const int* use
             const double c = (double)c32 + (bad ? 1e18 : 0.0);
             return c > 1e18 ? 1e18 : c;  // dist[dist > 1e18] = 1e18
         };
-        trk_lsap(cost, nd, np, lsap_match, *lsap);
+        // hungarian = 1: the reference's dependency (sklearn 0.22.2's Munkres); 2: scipy's rectangular LSAP -- the same optimum
+        // value, possibly another optimum among tied / forbidden pairs (include/centerpose_hip.h: cp_track_params)
+        if (P.hungarian == 2 || !munkres) trk_lsap(cost, nd, np, lsap_match, *lsap);
+        else trk_munkres(cost, nd, np, lsap_match, *munkres);
         for (int i = 0; i < nd; ++i) {
             const int match = lsap_match[i];
             if (match >= 0 && cost(i, match) > 1e16) {

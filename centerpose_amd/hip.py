@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CENTERPOSE_HIP_LIB") or os.path.join(_HERE, "libcenterpose_hip.so")
 
 _lib = None
-ABI_VERSION = 5  # CP_ABI_VERSION of include/centerpose_hip.h this binding was written against
+ABI_VERSION = 6  # CP_ABI_VERSION of include/centerpose_hip.h this binding was written against
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -107,15 +107,28 @@ def lib():
     _sig(L.cp_track_status, c_int, c_void_p, c_void_p, c_int, ctypes.POINTER(c_int))
     _sig(L.cp_track_step, c_int, c_void_p, ctypes.POINTER(TrackParams), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
          c_void_p, c_void_p, c_size_t)
-    if L.cp_abi_version() != ABI_VERSION:
-        raise RuntimeError("centerpose_amd: %s has ABI version %d, this binding was written for %d (rebuild the library)"
-                           % (LIB_PATH, L.cp_abi_version(), ABI_VERSION))
+    _sig(L.cp_linear_assignment, c_int, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int))
     _lib = L
     return L
 
 
+def linear_assignment(cost, solver=1):
+    """The tracker's optimal assignment on the host (cp_linear_assignment; no device involved): ``cost`` [n, m] float64 ->
+    int64 array [min(n, m), 2] of (row, column) pairs sorted by row, the return value of scikit-learn 0.22's
+    ``linear_assignment`` (tracker.py:157).  solver 1 = that module's Munkres, 2 = scipy's rectangular LSAP."""
+    import numpy as np
+
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
+    if cost.ndim != 2:
+        raise ValueError("linear_assignment: a 2-D cost matrix is expected")
+    n, m = cost.shape
+    match = (c_int * max(n, 1))()
+    _check(lib().cp_linear_assignment(cost.ctypes.data_as(c_void_p), n, m, int(solver), match), "cp_linear_assignment")
+    return np.array([(i, match[i]) for i in range(n) if match[i] >= 0], dtype=np.int64).reshape(-1, 2)
+
+
 def exported_symbols():
-    """Names every declaration in include/centerpose_hip.h must resolve to (used by CPU tests)."""
+    """Names every declaration in include/centerpose_hip.h (+ the test hook of centerpose_hip_testing.h) must resolve to (used by CPU tests)."""
     return ["cp_version", "cp_last_error", "cp_dcnv2_workspace_bytes", "cp_dcnv2_forward", "cp_model_create",
             "cp_model_set_param", "cp_model_finalize", "cp_model_destroy", "cp_model_workspace_bytes",
             "cp_model_forward", "cp_model_forward_tap", "cp_conv2d_workspace_bytes", "cp_conv2d_nhwc",
@@ -123,7 +136,7 @@ def exported_symbols():
             "cp_kernel_variant_name", "cp_set_default_precision", "cp_model_set_precision", "cp_model_detect_workspace_bytes", "cp_model_detect", "cp_set_debug", "cp_preprocess", "cp_preprocess_batch", "cp_postprocess_workspace_bytes", "cp_postprocess", "cp_render_gaussians",
             "cp_model_profile_roles", "cp_role_name", "cp_pnp_from_post_workspace_bytes", "cp_pnp_from_post", "cp_resize_u8",
             "cp_abi_version", "cp_num_kernel_variants", "cp_num_roles", "cp_track_state_bytes", "cp_track_workspace_bytes",
-            "cp_track_reset", "cp_track_step", "cp_track_status"]
+            "cp_track_reset", "cp_track_step", "cp_track_status", "cp_linear_assignment"]
 
 
 def _check(rc, what):
@@ -470,7 +483,8 @@ def track_params_from_opt(opt, K=100, cap=TRACK_CAP):
                        use_pnp=int(bool(opt.use_pnp)), hps_uncertainty=int(bool(opt.hps_uncertainty)),
                        show_axes=int(bool(opt.show_axes)), cat_rule=cat[opt.c], render_hm_mode=int(opt.render_hm_mode),
                        render_hmhp_mode=int(opt.render_hmhp_mode), pre_hm=int(bool(opt.pre_hm)),
-                       pre_hm_hp=int(bool(opt.pre_hm_hp)), K=int(K), cap=int(cap), hungarian=int(bool(getattr(opt, "hungarian", False))),
+                       pre_hm_hp=int(bool(opt.pre_hm_hp)), K=int(K), cap=int(cap),
+                       hungarian=(2 if getattr(opt, "hungarian_solver", "munkres") == "scipy" else 1) if getattr(opt, "hungarian", False) else 0,
                        baseline=int(baseline))
 
 
@@ -520,7 +534,10 @@ class DeviceTracker(object):
         self.recs[..., 0] = -1.0  # nothing to draw before the first frame
         self.recs[..., 1:] = 0.0
 
-    def step(self, post, count, det_pnp=None):
+    def step(self, post, count, det_pnp=None, check=True):
+        """One frame of every video.  Raises BEFORE the device state has moved if the arguments or the launch are refused;
+        with ``check`` (default) the periodic look at the overflow counters follows and may raise AFTER it has moved -- a caller
+        that keeps per-frame state of its own passes ``check=False``, updates that state, then calls ``check_due()``."""
         if not (post.is_cuda and post.dtype == torch.float64 and post.is_contiguous() and tuple(post.shape) ==
                 (self.B, self.K, POST_STRIDE) and count.is_cuda and count.dtype == torch.int32):
             raise RuntimeError("DeviceTracker.step: post [B,K,120] float64 / count [B] int32 device tensors expected")
@@ -530,6 +547,11 @@ class DeviceTracker(object):
         _check(lib().cp_track_step(_stream(), ctypes.byref(self.P), _ptr(self.vmeta), _ptr(post), _ptr(count), _ptr(det_pnp),
                                    self.B, _ptr(self.state), _ptr(self.recs), _ptr(self.ws), self.ws.numel()), "cp_track_step")
         self.frames += 1
+        if check:
+            self.check_due()
+
+    def check_due(self):
+        """The periodic overflow check of ``step`` (every STATUS_EVERY frames; synchronises when it runs)."""
         if self.STATUS_EVERY and self.frames % self.STATUS_EVERY == 0:  # the device-resident loop never calls read(): surface overflows here
             self.check()
 

@@ -93,13 +93,13 @@ class BatchedTracking(object):
         finally:
             det._skip_host_dets = False
         rec, cnt, poses = det.post_pnp_device(metas)
-        try:
-            self.dev.step(rec, cnt, poses)
-        finally:
-            # (DeviceTracker.step's periodic overflow check may raise AFTER the device has advanced: keep the host's view of
-            # the loop -- previous frame, frame count -- in step with the device before the exception travels on)
-            self.pre_images = images
-            self.frames += 1
+        # a refused cp_track_step raises here, BEFORE the device state has moved: the host's view (previous frame, frame count)
+        # must not move either.  The periodic overflow check raises AFTER the device has advanced, so it runs once the host's
+        # view has followed.
+        self.dev.step(rec, cnt, poses, check=False)
+        self.pre_images = images
+        self.frames += 1
+        self.dev.check_due()
         outs = None
         if read:
             outs = []

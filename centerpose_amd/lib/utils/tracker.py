@@ -33,13 +33,15 @@ def _greedy(cost):
     return np.array(pairs, np.int32).reshape(-1, 2)
 
 
-def _hungarian(cost):
-    """``sklearn.utils.linear_assignment_.linear_assignment`` (scikit-learn 0.22) = rows/cols of the optimal
-    assignment as an [n, 2] array; scipy's solver returns the same pairs."""
-    from scipy.optimize import linear_sum_assignment
+def _hungarian(cost, solver=1):
+    """``sklearn.utils.linear_assignment_.linear_assignment`` (the reference's import, tracker.py:6,157; scikit-learn 0.22.2,
+    a module that no longer exists in scikit-learn >= 0.23): the (row, column) pairs of the optimal assignment as an [n, 2]
+    array sorted by row.  Solved by the library's restatement of that module's Munkres state machine (``solver`` 1,
+    cp_linear_assignment -- the routine the device tracker runs) or of scipy's rectangular LSAP (``solver`` 2): the same
+    optimum value, possibly different pairs among tied / forbidden entries (include/centerpose_hip.h: cp_track_params)."""
+    from centerpose_amd import hip
 
-    r, c = linear_sum_assignment(cost)
-    return np.stack([r, c], 1).astype(np.int64).reshape(-1, 2)
+    return hip.linear_assignment(np.asarray(cost, np.float64), solver)
 
 
 def _area(box):
@@ -148,7 +150,8 @@ class Tracker(object):
         cost = cost + bad * _FORBIDDEN
         if self.opt.hungarian:
             cost[cost > _FORBIDDEN] = _FORBIDDEN
-            pairs = _hungarian(cost)
+            # opt.hungarian is the reference's flag (opts.py); `hungarian_solver` = 'scipy' selects the other optimum finder
+            pairs = _hungarian(cost, 2 if getattr(self.opt, 'hungarian_solver', 'munkres') == 'scipy' else 1)
         else:
             pairs = _greedy(cost)
         free_d = [d for d in range(n) if d not in pairs[:, 0]]

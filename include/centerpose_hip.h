@@ -11,7 +11,8 @@
  * Threading: stateless entry points (cp_dcnv2_forward, cp_conv2d_nhwc, cp_decode, cp_postprocess, cp_pnp_solve,
  * cp_preprocess, cp_render_gaussians) may be called concurrently on different streams.  A cp_model is not re-entrant:
  * one forward / detect at a time per model (its workspace, profile records and hipGraph cache are per model).
- * cp_last_error(), cp_set_default_precision() and cp_set_debug() are process-global.
+ * cp_last_error() is per calling thread (the message of that thread's last failing call); cp_set_default_precision() is
+ * process-global.  The kernel-selection hooks the test-suite uses are NOT part of this header: centerpose_hip_testing.h.
  */
 #ifndef CENTERPOSE_HIP_H
 #define CENTERPOSE_HIP_H
@@ -37,8 +38,9 @@ typedef struct cp_model cp_model;
  * with, so a caller compiled against another revision can refuse to run instead of passing arguments with a stale
  * meaning.  History: 1 = round-1 header; 2 = cp_preprocess takes the FORWARD 2x3 affine as double[6] and inverts it
  * itself (round 1: the inverse as float[6]); 3 = cp_dcnv2_forward accepts every shape of the reference op (generic
- * kernel), cp_num_kernel_variants() / cp_num_roles() size the profile buffers; 4 = cp_track_* added; 5 = cp_track_status, list truncation instead of reset on overflow. */
-#define CP_ABI_VERSION 5
+ * kernel), cp_num_kernel_variants() / cp_num_roles() size the profile buffers; 4 = cp_track_* added; 5 = cp_track_status, list truncation instead of reset on overflow;
+ * 6 = cp_preprocess_batch, CP_NUM_KERNEL_VARIANTS 39, cp_set_debug moved out of this header (centerpose_hip_testing.h). */
+#define CP_ABI_VERSION 6
 const char* cp_version(void);
 int cp_abi_version(void);
 const char* cp_last_error(void);
@@ -127,8 +129,6 @@ int cp_model_forward_tap(cp_model* m, cp_stream_t stream, int B, int H, int W, c
 #define CP_PREC_F32 0
 #define CP_PREC_F16X3 1
 int cp_set_default_precision(int precision);
-/* Kernel-tuning ablation switches for cp_conv2d_nhwc (tools/conv_bench.py --dbg); results are wrong when non-zero. */
-int cp_set_debug(int flags);
 int cp_model_set_precision(cp_model* m, int precision);
 
 /* Per-launch timing of the implicit-GEMM kernels with HIP events recorded on the launch stream
@@ -337,11 +337,16 @@ typedef struct cp_track_params {
     double new_thresh, pre_thresh, R, conf_lo, conf_hi;
     int max_age, kalman, scale_pool, use_pnp, hps_uncertainty, show_axes, cat_rule, render_hm_mode, render_hmhp_mode, pre_hm,
         pre_hm_hp, K, cap;
-    int hungarian; /* 1: optimal assignment (tracker.py:154-170) instead of the greedy walk.  Restates scipy's rectangular LSAP
-                    * (shortest augmenting path) operation for operation; the reference calls sklearn 0.22's linear_assignment
-                    * (Munkres, tracker.py:157).  Both are optimal, but with many 1e18 "forbidden" entries the optimum is
-                    * degenerate and the two can undo different forbidden pairs: same matching cost, possibly another order of
-                    * the left-over detections and hence of new tracking ids / coasting tracks.  The goldens are scipy's. */
+    int hungarian; /* != 0: optimal assignment (tracker.py:154-170) instead of the greedy walk.
+                    *   1 = the solver the reference calls (tracker.py:6,157): sklearn.utils.linear_assignment_ of the pinned
+                    *       scikit-learn 0.22.2, i.e. the Kuhn-Munkres state machine, restated operation for operation
+                    *       (csrc/track_common.h: trk_munkres; the module no longer exists in scikit-learn >= 0.23);
+                    *   2 = scipy.optimize.linear_sum_assignment's rectangular shortest-augmenting-path solver, restated
+                    *       operation for operation (trk_lsap) -- what a host with a current scipy / scikit-learn would run, and
+                    *       the faster of the two (O(n^2 m) against the state machine's O(n^3 m) worst case on one lane).
+                    * Both are optimal; with many 1e18 "forbidden" entries the optimum is degenerate and the two can undo
+                    * different forbidden pairs: same matching cost, possibly another order of the left-over detections and
+                    * hence of new tracking ids / coasting tracks.  Goldens exist for both (tests/golden/tracker_ref.json). */
     int baseline;  /* 1: Tracker_baseline (--refined_Kalman, utils/tracker_baseline.py:14-310): only (x, y) of a vertex observed,
                       plain scale average, association on raw centres against velocity-advanced track centres */
 } cp_track_params;
@@ -352,6 +357,13 @@ int cp_track_step(cp_stream_t stream, const cp_track_params* params, const doubl
                   const double* det_pnp, int B, void* state, double* render_recs, void* workspace, size_t workspace_bytes);
 /* dropped_out: HOST int32 [B], the sticky overflow counters above.  Copies 16 + 16 B bytes and synchronises `stream`. */
 int cp_track_status(cp_stream_t stream, const void* state, int B, int* dropped_out);
+
+/* The tracker's assignment on the HOST (no device work, no stream): replaces `linear_assignment(dist)` of tracker.py:157 for the
+ * host tracker (centerpose_amd/lib/utils/tracker.py) with the very routine the device tracker runs.
+ *   cost       HOST float64 [n_rows, n_cols] row-major (detections x tracks)
+ *   solver     1 = scikit-learn 0.22.2's Munkres, 2 = scipy's rectangular LSAP (cp_track_params.hungarian)
+ *   match_out  HOST int32 [n_rows]: column of each row, -1 for rows left out (min(n_rows, n_cols) rows get one) */
+int cp_linear_assignment(const double* cost, int n_rows, int n_cols, int solver, int* match_out);
 
 #ifdef __cplusplus
 }

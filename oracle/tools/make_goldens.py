@@ -228,6 +228,46 @@ def tracker_frames(seed=9, n_frames=5, n_obj=6):
     return frames
 
 
+def tracker_frames_ties(seed=21, n_frames=8, n_obj=14):
+    """A video built to make the optimal assignment DEGENERATE (what separates sklearn 0.22's Munkres from scipy's solver): small
+    objects of two classes that jump by about their own size, so that most (detection, track) pairs are 1e18-forbidden (area
+    gate or class mismatch, tracker.py:148-151) and many detections / tracks have no admissible partner at all; frames 2 and 5
+    drop half of the objects (more tracks than detections), frames 3 and 6 bring them back together with new ones (more
+    detections than tracks).  The forbidden pairs of the optimum are undone and appended to the unmatched lists
+    (tracker.py:167-174): which ones, and hence the order new ids are handed out and tracks coast, is the solver's choice."""
+    rng = np.random.RandomState(seed)
+    base = rng.uniform(80, 430, (n_obj, 2))
+    vel = rng.uniform(-4, 4, (n_obj, 2))
+    size = rng.uniform(9, 22, n_obj)
+    cls = rng.randint(0, 2, n_obj)
+    frames = []
+    for f in range(n_frames):
+        dets = []
+        order = rng.permutation(n_obj)
+        for o in order:
+            if f in (2, 5) and o % 2 == 0:
+                continue
+            if f < 3 and o >= n_obj - 3:
+                continue
+            jump = rng.randn(2) * (size[o] * (0.2 if rng.rand() < 0.5 else 1.1))
+            ct = base[o] + vel[o] * f + jump
+            kps = ct[None, :] + rng.uniform(-0.5, 0.5, (8, 2)) * size[o]
+            dets.append({
+                "score": float(rng.uniform(0.35, 0.99)), "cls": int(cls[o]),
+                "bbox": [ct[0] - size[o] / 2, ct[1] - size[o] / 2, ct[0] + size[o] / 2, ct[1] + size[o] / 2],
+                "ct": [float(ct[0]), float(ct[1])],
+                "tracking": (-vel[o] + rng.randn(2) * 0.3).astype(np.float32),
+                "tracking_hp": (np.tile(-vel[o], 8) + rng.randn(16) * 0.3).astype(np.float32),
+                "kps": kps.reshape(-1).astype(np.float32),
+                "kps_fusion_mean": kps.reshape(-1) + rng.randn(16) * 0.2,
+                "kps_fusion_std": rng.uniform(0.5, 3.0, 16),
+                "obj_scale": rng.uniform(0.5, 1.5, 3).astype(np.float32),
+                "obj_scale_uncertainty": rng.uniform(0.05, 0.3, 3).astype(np.float32),
+            })
+        frames.append(dets)
+    return frames
+
+
 def tracker_summary(tracks):
     out = []
     for t in tracks:
@@ -240,27 +280,57 @@ def tracker_summary(tracks):
     return out
 
 
-def run_tracker(cls, hungarian):
+def run_tracker(cls, hungarian, frames=None, solver="munkres"):
+    """solver: what stands behind the reference's `linear_assignment` import (ref_harness.setup): "munkres" = the restatement of
+    scikit-learn 0.22.2's module (oracle/munkres.py), "scipy" = scipy.optimize.linear_sum_assignment."""
     import copy
 
-    tr = cls(TrackOpt(hungarian))
-    tr.init_track({"id": 0})
-    res = []
-    for dets in tracker_frames():
-        tracks, _ = tr.step(copy.deepcopy(dets))
-        res.append(tracker_summary(tracks))
+    os.environ["CP_REF_LSAP"] = solver
+    try:
+        opt = TrackOpt(hungarian)
+        opt.hungarian_solver = solver   # read by this repo's host mirror (lib/utils/tracker.py); the reference class ignores it
+        tr = cls(opt)
+        tr.init_track({"id": 0})
+        res = []
+        for dets in (tracker_frames() if frames is None else frames):
+            tracks, _ = tr.step(copy.deepcopy(dets))
+            res.append(tracker_summary(tracks))
+    finally:
+        os.environ.pop("CP_REF_LSAP", None)
     return res
+
+
+TRACKER_MODES = ["greedy", "hungarian", "hungarian_scipy", "baseline", "baseline_hungarian", "baseline_hungarian_scipy",
+                 "ties_greedy", "ties_hungarian", "ties_hungarian_scipy", "ties_baseline_hungarian"]
+
+
+def tracker_mode(mode):
+    """key of tracker_ref.json -> (frames, cp_track_params.hungarian: 0 greedy / 1 Munkres / 2 scipy LSAP, baseline, solver)"""
+    frames = tracker_frames_ties() if mode.startswith("ties_") else tracker_frames()
+    solver = "scipy" if mode.endswith("_scipy") else "munkres"
+    hung = 0 if "hungarian" not in mode else (2 if solver == "scipy" else 1)
+    return frames, hung, "baseline" in mode, solver
 
 
 def tracker_goldens():
     """Reference Tracker.step (utils/tracker.py:112-302) and Tracker_baseline.step (utils/tracker_baseline.py) on the seeded
     video, greedy and Hungarian -> tracker_ref.json."""
     ref = rh.reference_tracker()
-    out = {"greedy": run_tracker(ref, False), "hungarian": run_tracker(ref, True)}
+    out = {"greedy": run_tracker(ref, False), "hungarian": run_tracker(ref, True),
+           "hungarian_scipy": run_tracker(ref, True, solver="scipy")}
     # the position-only Kalman baseline (utils/tracker_baseline.py, --refined_Kalman), both association modes
     base = rh.reference_tracker_baseline()
     out["baseline"] = run_tracker(base, False)
     out["baseline_hungarian"] = run_tracker(base, True)
+    out["baseline_hungarian_scipy"] = run_tracker(base, True, solver="scipy")
+    # the degenerate video: greedy, and the optimal assignment behind both solvers (they differ here)
+    ties = tracker_frames_ties()
+    out["ties_greedy"] = run_tracker(ref, False, ties)
+    out["ties_hungarian"] = run_tracker(ref, True, ties)
+    out["ties_hungarian_scipy"] = run_tracker(ref, True, ties, solver="scipy")
+    out["ties_baseline_hungarian"] = run_tracker(base, True, ties)
+    same = sum(a == b for a, b in zip(out["ties_hungarian"], out["ties_hungarian_scipy"]))
+    print("ties video: frames on which Munkres and scipy give the same track list: %d of %d" % (same, len(ties)))
     with open(os.path.join(GOLD, "tracker_ref.json"), "w") as f:
         json.dump(out, f)
     print("tracker_ref.json: tracks per frame", [len(x) for x in out["greedy"]])

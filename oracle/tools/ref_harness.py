@@ -136,11 +136,18 @@ def install_host_shims():
     fake("numba", jit=lambda *a, **k: (lambda f: f))
     import sklearn.utils  # noqa: F401
 
-    def linear_assignment(cost):  # scikit-learn 0.22.2's API (removed in 0.23): [n, 2] array of (row, col) pairs
-        from scipy.optimize import linear_sum_assignment
+    # scikit-learn 0.22.2's sklearn.utils.linear_assignment_ (requirements.txt:13; removed in 0.23, absent here): the reference
+    # tracker runs on oracle/munkres.py's operation-for-operation restatement of that module's Munkres state machine, or -- for
+    # the "*_scipy" goldens, what a host with a current scipy would compute -- on scipy's rectangular LSAP ($CP_REF_LSAP=scipy)
+    def linear_assignment(cost):
+        if os.environ.get("CP_REF_LSAP") == "scipy":
+            from scipy.optimize import linear_sum_assignment
 
-        r, c = linear_sum_assignment(cost)
-        return np.stack([r, c], 1)
+            r, c = linear_sum_assignment(cost)
+            return np.stack([r, c], 1)
+        from oracle.munkres import linear_assignment as munkres
+
+        return munkres(cost)
 
     fake("sklearn.utils.linear_assignment_", linear_assignment=linear_assignment)
 

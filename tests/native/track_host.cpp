@@ -34,8 +34,12 @@ int cp_track_host_update(const TrackParams* P, const double* vm, const double* p
     std::vector<int> wp(LS), wc(LS), wr(LS), wrem(LS), lm(LS);
     std::vector<unsigned char> wsr(LS), wsc(LS);
     const TrkLsapWork W = {wu.data(), wv.data(), ws.data(), wp.data(), wc.data(), wr.data(), wrem.data(), wsr.data(), wsc.data()};
+    std::vector<double> mC((size_t)LS * LS);
+    std::vector<unsigned char> mM((size_t)LS * LS), mR(LS), mCu(LS);
+    std::vector<int> mP(4 * (size_t)LS);
+    const TrkMunkresWork MW = {mC.data(), mM.data(), mR.data(), mCu.data(), mP.data()};
     const int n = trk_associate(*P, dets.data(), use.data(), count, prev, np, plan.data(), id_count, idx.data(), taken.data(), &dropped,
-                                &W, lm.data());
+                                &W, lm.data(), &MW);
     g_last_dropped = dropped;
     for (int t = 0; t < n; ++t)
         trk_materialise(plan.data() + 3 * t, dets.data(), prev, next + (size_t)t * CP_TRACK_STRIDE, 0, CP_TRACK_STRIDE);
@@ -52,6 +56,16 @@ void cp_track_host_lsap(const double* cost, int nd, int nt, int* match) {
     std::vector<unsigned char> wsr(LS), wsc(LS);
     const TrkLsapWork W = {wu.data(), wv.data(), ws.data(), wp.data(), wc.data(), wr.data(), wrem.data(), wsr.data(), wsc.data()};
     trk_lsap([&](int i, int j) { return cost[(size_t)i * nt + j]; }, nd, nt, match, W);
+}
+
+// sklearn 0.22.2's Munkres on an explicit nd x nt cost matrix (tests: against oracle/munkres.py)
+void cp_track_host_munkres(const double* cost, int nd, int nt, int* match) {
+    const size_t LS = (size_t)(nd > nt ? nd : nt) + 1;
+    std::vector<double> mC((size_t)nd * nt + 1);
+    std::vector<unsigned char> mM((size_t)nd * nt + 1), mR(LS), mCu(LS);
+    std::vector<int> mP(4 * LS);
+    const TrkMunkresWork MW = {mC.data(), mM.data(), mR.data(), mCu.data(), mP.data()};
+    trk_munkres([&](int i, int j) { return cost[(size_t)i * nt + j]; }, nd, nt, match, MW);
 }
 
 // stage 5: tracks [n][STRIDE] (in place), pnp_rows [n][40] or null, recs [n][9][5]

@@ -50,6 +50,36 @@ def test_bench_eight_ranks_dress_rehearsal():
     assert d["dry_run_devices"] == list(range(8))   # rank r would bind device LOCAL_RANK = r (one GPU per rank)
     assert isinstance(d["cpu_baseline"], dict) and "skipped" in d["cpu_baseline"]
     assert "roofline" in d and "legs" in d
+    # the eight shards (distributed.shard_range of the global batch; frames are seeded by global image index) tile [0, 512)
+    # exactly and arrive in rank order -- bench.py itself refuses to print a line otherwise; the line shows first / last / count
+    assert d["dry_run_global_images"] == [0, 511, 512]
+    # the collective's own time next to the step (here: gloo, host clock; on the GPU box: HIP events on the launch stream)
+    ag = d["allgather"]
+    assert ag["ms_per_step_max_over_ranks"] >= ag["ms_per_step_rank0"] > 0
+    assert ag["bytes_received_per_rank"] == 512 * 100 * 118 * 4 and ag["gbps_per_rank"] > 0
+
+
+def test_bench_eight_ranks_tracking_workload_gathers_in_rank_image_slot_order():
+    """BASELINE configs[4]'s collective (`--workload track`: every rank's tracker needs every image's detections) rehearsed dry:
+    bench.py checks the gathered records' (rank, image, slot) tags and exits non-zero if the order is anything else."""
+    d = _run(["--gpus", "8", "--dry-run", "--workload", "track", "--steps", "2", "--warmup", "1"])
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["config"]["global_batch"] == 8 * 16
+    assert d["dry_run_global_images"] == [0, 127, 128] and d["dry_run_devices"] == list(range(8))
+    assert d["allgather"]["bytes_received_per_rank"] == 128 * 100 * 118 * 4
+
+
+def test_shards_tile_the_global_batch_for_every_world_size():
+    """distributed.shard_range (what bench.py seeds and indexes by): contiguous, disjoint, in rank order, covering [0, n) for
+    every world size of the scaling series, divisible or not (opts.py:358-367's chunk sizes without the master-GPU case)."""
+    from centerpose_amd.distributed import shard_range
+
+    for world in (1, 2, 4, 8):
+        for n in (512, 64 * world, 500, 7):
+            edges = [shard_range(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            sizes = [e - s for s, e in edges]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
 
 
 @pytest.mark.parametrize("record", ["r03_bench_default.json", "r04_bench_detail.json", "r05_bench_detail.json"])

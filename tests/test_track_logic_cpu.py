@@ -90,23 +90,27 @@ def _post_from_dict(d, fusion_as_displacement=False):
     return r
 
 
-@pytest.mark.parametrize("mode", ["greedy", "baseline", "baseline_hungarian"])
+@pytest.mark.parametrize("mode", mg.TRACKER_MODES)
 def test_tracker_logic_matches_reference_golden(host, mode):
     """The device tracker's logic (host build of track_common.h) against the REFERENCE's own runs on the seeded video:
-    Tracker.step (greedy; the Hungarian run has its own test below) and Tracker_baseline.step (--refined_Kalman:
-    utils/tracker_baseline.py -- position-only filter with its broadcast initial covariance, plain scale average, raw centres
-    against velocity-advanced track centres, the P[2v] read-out), greedy and Hungarian."""
+    Tracker.step and Tracker_baseline.step (--refined_Kalman: utils/tracker_baseline.py -- position-only filter with its
+    broadcast initial covariance, plain scale average, raw centres against velocity-advanced track centres, the P[2v]
+    read-out); greedy, and the optimal assignment of tracker.py:154-174 behind either solver: "*hungarian" = scikit-learn
+    0.22.2's Munkres, the reference's pinned dependency (cp_track_params.hungarian = 1, trk_munkres), "*_scipy" = scipy's
+    rectangular LSAP (2, trk_lsap); "ties_*" = the degenerate video on which the two optima hand out coasting slots and ids in
+    different orders (make_goldens.tracker_frames_ties)."""
     with open(os.path.join(GOLD, "tracker_ref.json")) as f:
         gold = json.load(f)[mode]
-    o = mg.TrackOpt(mode.endswith("hungarian"))
+    frames, hung, baseline, _ = mg.tracker_mode(mode)
+    o = mg.TrackOpt(bool(hung))
     P = Params(new_thresh=o.new_thresh, pre_thresh=0.3, R=o.R, conf_lo=3, conf_hi=9, max_age=o.max_age, kalman=1,
                scale_pool=1, use_pnp=0, hps_uncertainty=1, show_axes=0, cat_rule=0, render_hm_mode=1, render_hmhp_mode=2,
-               pre_hm=1, pre_hm_hp=1, K=100, hungarian=int(mode.endswith("hungarian")), baseline=int(mode.startswith("baseline")))
+               pre_hm=1, pre_hm_hp=1, K=100, hungarian=hung, baseline=int(baseline))
     vm = np.zeros(16)
     vm[[0, 4]] = 1.0
     vm[6:10] = 512
     ht = HostTracker(host, P, vm)
-    for f, dets in enumerate(mg.tracker_frames()):
+    for f, dets in enumerate(frames):
         post = np.stack([_post_from_dict(d, True) for d in dets])
         tracks, _ = ht.step(post)
         assert len(tracks) == len(gold[f]), f
@@ -215,7 +219,7 @@ def test_tracker_logic_matches_python_loop_with_pnp(host, monkeypatch):
 
 @pytest.mark.parametrize("hungarian,baseline", [(False, False), (True, False), (False, True), (True, True)])
 def test_tracker_logic_random_scenarios_vs_python_tracker(host, hungarian, baseline):
-    """(greedy, and the Hungarian association of tracker.py:154-174 whose Python side solves with scipy.)  Crowded random videos (objects crossing, leaving, re-entering, weak detections, same-frame births and deaths) through
+    """(greedy, and the Hungarian association of tracker.py:154-174: both sides on scikit-learn 0.22.2's Munkres, restated.)  Crowded random videos (objects crossing, leaving, re-entering, weak detections, same-frame births and deaths) through
     the harness and through the reference-pinned Python ``Tracker`` (greedy, Kalman + scale pool, no PnP): identical ids,
     ages, activity and filter read-outs in every frame -- association order, coasting up to max_age, the new-track
     threshold and the float32 cost arithmetic included."""
@@ -350,24 +354,52 @@ def test_assignment_equals_scipy_linear_sum_assignment(host):
     assert n_cases == 1500
 
 
-def test_tracker_logic_hungarian_matches_reference_golden(host):
-    """The Hungarian mode of Tracker.step (tracker.py:154-174) against the reference's own run (tracker_ref.json["hungarian"],
-    generated by the reference class with scipy's solver behind its linear_assignment import)."""
-    with open(os.path.join(GOLD, "tracker_ref.json")) as f:
-        gold = json.load(f)["hungarian"]
-    o = mg.TrackOpt(True)
-    P = Params(new_thresh=o.new_thresh, pre_thresh=0.3, R=o.R, conf_lo=3, conf_hi=9, max_age=o.max_age, kalman=1,
-               scale_pool=1, use_pnp=0, hps_uncertainty=1, show_axes=0, cat_rule=0, render_hm_mode=1, render_hmhp_mode=2,
-               pre_hm=1, pre_hm_hp=1, K=100, hungarian=1)
-    vm = np.zeros(16)
-    vm[[0, 4]] = 1.0
-    vm[6:10] = 512
-    ht = HostTracker(host, P, vm)
-    for f, dets in enumerate(mg.tracker_frames()):
-        post = np.stack([_post_from_dict(d, True) for d in dets])
-        tracks, _ = ht.step(post)
-        assert len(tracks) == len(gold[f]), f
-        for t, g in zip(tracks, gold[f]):
-            assert (int(t[0]), int(t[1]), int(t[2])) == (g["tracking_id"], g["age"], g["active"]), f
-            np.testing.assert_allclose(t[4 + 28:4 + 30], g["ct"], rtol=1e-12)
-            np.testing.assert_allclose(t[TR["MEAN_KF"]:TR["MEAN_KF"] + 16], g["kps_mean_kf"], rtol=1e-9, atol=1e-9)
+def test_munkres_equals_the_restatement_of_sklearn_022_and_is_optimal(host):
+    """trk_munkres (track_common.h, host build; cp_track_params.hungarian = 1) against oracle/munkres.py -- the numpy restatement
+    of scikit-learn 0.22.2's `linear_assignment` (the reference's pinned, no longer installable dependency: PARITY UNPINNED
+    against the real module).  Same PAIRS on every matrix (continuous, tie-heavy, constant, the tracker's 1e18 pattern, all
+    forbidden; tall, wide, square, empty sides), through both entry points (the test harness and the product's
+    cp_linear_assignment); and the structural facts that hold for the real module whatever its tie-breaking: every row of the
+    shorter side is assigned once, no column twice, and the total cost is scipy's optimum."""
+    from scipy.optimize import linear_sum_assignment
+
+    from centerpose_amd import hip as _hip
+    from oracle.munkres import linear_assignment as munkres_ref
+
+    host.cp_track_host_munkres.restype = None
+    rng = np.random.RandomState(5)
+    differs_from_scipy = 0
+    for trial in range(2000):
+        nd, nt = int(rng.randint(1, 15)), int(rng.randint(1, 15))
+        kind = trial % 6
+        if kind == 0:
+            c = rng.rand(nd, nt) * 100.0
+        elif kind == 1:
+            c = rng.randint(0, 4, (nd, nt)).astype(np.float64)
+        elif kind == 2:
+            c = np.full((nd, nt), float(rng.randint(0, 3)))
+        elif kind == 5:
+            c = np.full((nd, nt), 1e18)
+        else:
+            d32 = (rng.rand(nd, nt) * (2000.0 if kind == 3 else 90.0)).astype(np.float32)
+            c = d32 + (rng.rand(nd, nt) < (0.6 if kind == 3 else 0.9)) * 1e18
+            c[c > 1e18] = 1e18
+        c = np.ascontiguousarray(c, np.float64)
+        want = munkres_ref(c)
+        got = np.zeros(nd, np.int32)
+        host.cp_track_host_munkres(_ptr(c), nd, nt, _ptr(got))
+        pairs = [[i, int(got[i])] for i in range(nd) if got[i] >= 0]
+        assert pairs == want.tolist(), (trial, kind, nd, nt)
+        assert _hip.linear_assignment(c, 1).tolist() == pairs
+        assert len(pairs) == min(nd, nt) and len({p[1] for p in pairs}) == len(pairs)
+        r, col = linear_sum_assignment(c)
+        assert np.isclose(sum(c[i, j] for i, j in pairs), c[r, col].sum(), rtol=1e-12, atol=1e-9)
+        differs_from_scipy += int(sorted(map(tuple, pairs)) != sorted(zip(r.tolist(), col.tolist())))
+    assert differs_from_scipy > 50   # the two optima really are different objects: that is why both are restated
+    for nd, nt in ((100, 128), (128, 100), (0, 5), (5, 0)):   # the device's upper sizes (seconds, not minutes), empty sides
+        d32 = (rng.rand(nd, nt) * 5000.0).astype(np.float32)
+        c = np.ascontiguousarray(d32 + (rng.rand(nd, nt) < 0.9) * 1e18)
+        c[c > 1e18] = 1e18
+        assert _hip.linear_assignment(c, 1).tolist() == munkres_ref(c).tolist(), (nd, nt)
+    with pytest.raises(RuntimeError):
+        _hip.linear_assignment(np.zeros((2, 2)), 3)

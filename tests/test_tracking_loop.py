@@ -236,27 +236,30 @@ def test_batched_tracking_matches_reference_per_video(device, monkeypatch, devic
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["greedy", "hungarian", "baseline", "baseline_hungarian"])
+@pytest.mark.parametrize("mode", ["greedy", "hungarian", "hungarian_scipy", "baseline", "baseline_hungarian", "ties_greedy",
+                                  "ties_hungarian", "ties_hungarian_scipy", "ties_baseline_hungarian"])
 def test_device_tracker_matches_reference_tracker_golden(device, mode):
     """cp_track_step alone (no PnP) on the seeded detections of tests/golden/tracker_ref.json -- the REFERENCE's own
     Tracker.step: ids, ages, coasting, Kalman read-out and scale pool, for three videos that start one frame apart; greedy
-    association and (round 4) the Hungarian mode, whose device solver restates scipy's rectangular assignment; "baseline*" = the
-    reference's Tracker_baseline.step (--refined_Kalman) on the same detections."""
+    association and the Hungarian mode behind either solver ("*hungarian": scikit-learn 0.22.2's Munkres, the reference's pinned
+    dependency, restated as trk_munkres; "*_scipy": scipy's rectangular assignment, trk_lsap); "baseline*" = the reference's
+    Tracker_baseline.step (--refined_Kalman) on the same detections; "ties_*" = the degenerate video on which the two optima
+    order coasting tracks and new ids differently (make_goldens.tracker_frames_ties: up to 21 tracks, two classes)."""
     from oracle.tools import make_goldens as mg
 
     with open(os.path.join(os.path.dirname(GOLD), "tracker_ref.json")) as fh:
         gold = json.load(fh)[mode]
-    o = mg.TrackOpt(mode.endswith("hungarian"))
+    frames, hung, baseline, _ = mg.tracker_mode(mode)
+    o = mg.TrackOpt(bool(hung))
     B, K = 3, 100
     P = hip.TrackParams(new_thresh=o.new_thresh, pre_thresh=0.3, R=o.R, conf_lo=3, conf_hi=9, max_age=o.max_age, kalman=1,
                         scale_pool=1, use_pnp=0, hps_uncertainty=1, show_axes=0, cat_rule=0, render_hm_mode=1,
-                        render_hmhp_mode=2, pre_hm=1, pre_hm_hp=1, K=K, cap=hip.TRACK_CAP, hungarian=int(mode.endswith("hungarian")),
-                        baseline=int(mode.startswith("baseline")))
+                        render_hmhp_mode=2, pre_hm=1, pre_hm_hp=1, K=K, cap=hip.TRACK_CAP, hungarian=hung,
+                        baseline=int(baseline))
     vm = np.zeros((B, 16))
     vm[:, [0, 4]] = 1.0
     vm[:, 6:10] = 512
     dt = hip.DeviceTracker(B, P, vm, device, 512, 512)
-    frames = mg.tracker_frames()
 
     def post_of(dets):
         post = np.zeros((K, hip.POST_STRIDE))

@@ -7,19 +7,38 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-# optional: a rocprofv3 --kernel-trace --stats CSV of the same command -> shader clock = per-XCD GUI cycles / average duration
-dur = {}
+# Shader clock of a kernel = per-XCD GRBM_GUI_ACTIVE cycles / the dispatch's duration IN THE SAME PASS (Start / End timestamps of
+# the very counter_collection rows that carry GRBM_GUI_ACTIVE).  Round 5 divided the PMC pass's cycles by the durations of a
+# separate --kernel-trace run: counter collection lengthens the dispatches, so that quotient read 2.5 - 2.96 GHz on a 2.4 GHz
+# part.  (A second argument -- a kernel-trace stats CSV -- is still accepted and only printed as the un-instrumented duration.)
+trace_dur = {}
 if len(sys.argv) > 2:
     for r in csv.DictReader(open(sys.argv[2])):
         k = re.sub(r"\(anonymous namespace\)::", "", r["Name"])
         k = re.sub(r"\(.*$", "", k).replace("void ", "").strip()
-        dur[k] = float(r["AverageNs"])
+        trace_dur[k] = float(r["AverageNs"])
 acc = defaultdict(list)
+clk = defaultdict(list)   # kernel -> [(per-XCD GUI cycles, ns)] per dispatch, both from one row
+import os
+
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    # the same pass's kernel trace (rocprofv3 --kernel-trace --pmc ...: one run, one set of dispatches), joined by dispatch id
+    span = {}
+    for t in glob.glob(os.path.dirname(f) + "/*kernel_trace.csv"):
+        for r in csv.DictReader(open(t)):
+            span[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     for r in csv.DictReader(open(f)):
         k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
         k = re.sub(r"\(.*$", "", k).replace("void ", "").strip()
         acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            ns = 0.0
+            if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                ns = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            elif r.get("Dispatch_Id") in span:
+                ns = span[r["Dispatch_Id"]]
+            if ns > 0:
+                clk[k].append((float(r["Counter_Value"]) / 8, ns))
 by_k = defaultdict(dict)
 calls = {}
 for (k, c), v in acc.items():
@@ -50,6 +69,15 @@ for k in sorted(by_k, key=lambda k: -by_k[k].get("GRBM_GUI_ACTIVE", 0) * calls[k
     if xcd and "SQ_INSTS_VALU_MFMA_MOPS_F16" in d:
         # 1 MOP = 512 f16 FLOPs; the 2.5 PFLOP/s peak at 2.4 GHz is 1.0417e6 FLOP per clock
         print("  %-34s %15.1f%% of the f16 matrix peak per kernel clock" % ("MFMA MOPS", 100 * d["SQ_INSTS_VALU_MFMA_MOPS_F16"] * 512 / (xcd * 1.0417e6)))
-    if xcd and k in dur:
-        print("  %-34s %15.0f MHz (per-XCD GUI clocks / %.1f us average launch of the kernel-trace run)" % ("shader clock", xcd / dur[k] * 1e3, dur[k] / 1e3))
+    if clk.get(k):
+        cyc, ns = sum(c for c, _ in clk[k]), sum(n for _, n in clk[k])
+        mhz = cyc / ns * 1e3
+        note = "" if mhz <= 2450 else "  (!) above the part's 2.4 GHz: timestamps and counters disagree"
+        print("  %-34s %15.0f MHz (per-XCD GUI clocks / the same dispatches' own %.1f us in this counter pass%s)" % (
+            "shader clock", mhz, ns / len(clk[k]) / 1e3, note))
+        if k in trace_dur:
+            print("  %-34s %15.1f us (kernel-trace run, no counters; the counter pass stretches a dispatch by x%.2f)" % (
+                "un-instrumented launch", trace_dur[k] / 1e3, ns / len(clk[k]) / trace_dur[k]))
+    elif xcd:
+        print("  %-34s %15s (no timestamps for these dispatches in this counter pass: run it with --kernel-trace)" % ("shader clock", "n/a"))
     print()

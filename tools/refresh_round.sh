@@ -18,7 +18,7 @@ if [ "${1:-}" != "quick" ]; then
   i=0
   grep "^pmc:" $R/tools/pmc_sq.txt | while read -r _ ctrs; do
     i=$((i+1))
-    timeout 400 rocprofv3 --pmc $ctrs --output-format csv -d $O/sq$i -- python $R/bench.py --steps 3 --warmup 1 $B > $O/sq$i.log 2>&1
+    timeout 400 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/sq$i -- python $R/bench.py --steps 3 --warmup 1 $B > $O/sq$i.log 2>&1
   done
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -- python $R/bench.py --steps 3 --warmup 1 $B > $O/kt2.log 2>&1
   python $R/tools/pmc_kernels.py $O $(find $O/kt2 -name "*kernel_stats.csv" | head -1) > $O/pmc_sq_counters.txt 2>&1
