@@ -200,7 +200,7 @@ int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream);
 // K steps (of 16 for the f32 kernels, 32 for f16x3) and output tiles of the launch cp_launch_conv[16] would make
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 39
+#define CP_NUM_CONV_VARIANTS 40
 #define CP_VARIANT_GRU 26
 // split-f16 ("f16x3") implicit GEMM (igemm16.hip)
 bool cp_conv16_supported(const ConvParams& p);
@@ -232,6 +232,10 @@ bool cp_dcn16s_supported(const ConvParams& p);
 int cp_dcn16s_items(const ConvParams& p);
 int cp_launch_dcn16s(const ConvParams& p, hipStream_t stream);
 int cp_launch_frag16_repack(const void* w16, void* w16f, int CoutPad, int Kpad16, hipStream_t s);
+// dcn16t.hip: dcn16p's gather written for three workgroups per CU (16-channel chunks, one gather set, two weight sets)
+#define CP_VARIANT_DCN16T 39
+bool cp_dcn16t_supported(const ConvParams& p);
+int cp_launch_dcn16t(const ConvParams& p, hipStream_t stream);
 #define CP_VARIANT_DCN16P 30
 #define CP_VARIANT_GN_FINAL 31
 #define CP_VARIANT_HALO_HEAD 32

@@ -981,6 +981,17 @@ static bool dcn16s_wanted(const ConvParams& p) {
     return (p.dbg & 2097152) || cp_dcn16s_items(p) >= 4096;
 }
 
+// ... and the layers without whole 128-channel tiles (Cout = 64: no wider tile to share a blend) from the three-workgroups-per-CU
+// form (dcn16t.hip) once the launch has more workgroups than the chip holds at three per CU: B = 64, same box, alternating
+// launches (profiles/r06_dcn16t_ab.txt): 64 -> 64 @128^2 (8192 workgroups) 393 (dcn16s) / 414 (dcn16p) -> 360 us, 128 -> 64 @64^2
+// (2048) 183 -> 169, 256 -> 64 @32^2 (512) 87 -> 91 (stays on dcn16p).
+// cp_set_debug: 33554432 = every eligible launch, 67108864 = never (tests, A/B runs).
+static bool dcn16t_wanted(const ConvParams& p) {
+    if ((p.dbg & 67108864) || !dcn16p_wanted(p) || !cp_dcn16t_supported(p)) return false;
+    if (p.dbg & 33554432) return true;
+    return !cp_dcn16p_wide(p) && cp_dcn16p_blocks(p) >= 1024;
+}
+
 static bool halo16_wanted(const ConvParams& p, int bn) {
     if ((p.dbg & 4096) || p.gn_in_a || !cp_halo16_supported(p)) return false;
     // with the weight fragments coming straight from L2 (no barrier inside a chunk) the halo kernel beats the per-tap
@@ -1027,6 +1038,7 @@ int cp_launch_conv16(const ConvParams& p, hipStream_t stream) {
             return CP_ERR_INVALID;
         // dcn16.hip: the software-pipelined gather kernel; cp_set_debug(1024) keeps the previous un-pipelined loop
         // (igemm16_kernel<DCN>) for A/B runs, 2048 selects the other wave count of the new kernel
+        if (dcn16t_wanted(p)) return cp_launch_dcn16t(p, stream);
         if (dcn16s_wanted(p)) return cp_launch_dcn16s(p, stream);
         if (dcn16p_wanted(p)) return cp_launch_dcn16p(p, stream);
         if (!(p.dbg & 1024)) return cp_launch_dcn16(p, bn, (p.dbg & 2048) ? 1 : 0, stream);
@@ -1049,7 +1061,7 @@ int cp_launch_conv16(const ConvParams& p, hipStream_t stream) {
 // kernel-variant ids continue after the exact-f32 ones (cp_conv_variant): 14.. = split-f16 instantiations
 int cp_conv16_variant(const ConvParams& p) {
     const int bn = conv16_tile_n(p);
-    if (p.offmask) return dcn16s_wanted(p) ? CP_VARIANT_DCN16S : dcn16p_wanted(p) ? (cp_dcn16p_wide(p) ? CP_VARIANT_DCN16PW : CP_VARIANT_DCN16P) : bn == 128 ? 18 : 17;
+    if (p.offmask) return dcn16t_wanted(p) ? CP_VARIANT_DCN16T : dcn16s_wanted(p) ? CP_VARIANT_DCN16S : dcn16p_wanted(p) ? (cp_dcn16p_wide(p) ? CP_VARIANT_DCN16PW : CP_VARIANT_DCN16P) : bn == 128 ? 18 : 17;
     const int t = bn == 32 ? 0 : bn == 64 ? 1 : 2;
     if (bn == 64 && p.tile_m == 64) return CP_VARIANT_M64N64;
     if (halo16_wanted(p, bn)) return 27 + t;

@@ -363,6 +363,48 @@ def test_dcn_streamed_persistent_vs_oracle_and_gather_kernel(device, B, C, Co, H
     assert not torch.equal(out, old)   # two different kernels really ran (summation order differs)
 
 
+@pytest.mark.parametrize("B,C,Co,H,W,std", [
+    (2, 32, 64, 8, 16, 0.0),       # one patch per image, zero offsets: image border = zero fill, two chunks
+    (2, 64, 64, 16, 16, 1.5),      # the bench's offset scale: a few dozen exception samples per block
+    (1, 128, 256, 32, 32, 3.0),    # eight chunks, four N tiles; some blocks over the exception capacity
+    (1, 64, 128, 16, 32, 8.0),     # offsets far beyond the halo and the image
+    (1, 32, 64, 64, 64, 10.0),     # every block over the exception capacity (buffer-load mode)
+    (2, 64, 64, 32, 32, 2.0),      # ~100 exception samples per block
+    (3, 64, 64, 40, 48, 1.0),      # non-power-of-two map
+    (1, 64, 60, 16, 32, 1.5),      # Cout not a multiple of the N tile: padded channels are not stored
+    (1, 64, 64, 128, 128, 1.5),    # the heaviest layer shape of the network (dla_up 64 -> 64 at 128 x 128)
+])
+def test_dcn_three_workgroups_per_cu_vs_oracle_and_other_kernels(device, B, C, Co, H, W, std):
+    """dcn16t.hip (dcn16p's gather on a 168-register / 46 KB budget: three workgroups per CU, 16-channel chunks, transposed product,
+    first chunk requested in the prologue) against the float64 oracle, against dcn16.hip (cp_set_debug 32768: another summation
+    order) and against dcn16s.hip (the same K order (16-channel chunk, tap): bit-identical).  cp_set_debug 65536 | 33554432 selects
+    it for launches of any size."""
+    hip.set_default_precision("f16x3")
+    try:
+        g = torch.Generator().manual_seed(C + H + int(std * 10))
+        x = torch.randn(B, C, H, W, generator=g)
+        w = torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5
+        b = torch.randn(Co, generator=g)
+        off = torch.randn(B, 18, H, W, generator=g) * std
+        mask = torch.rand(B, 9, H, W, generator=g)
+        ref = odcn.dcn_v2_forward_f64(x, w, b, off, mask)
+        args = [t.to(device) for t in (x, w, b, off, mask)] + [3, 3, 1, 1, 1, 1, 1, 1, 1]
+        outs = {}
+        for name, dbg in (("t", 65536 | 33554432), ("t2", 65536 | 33554432), ("gather", 32768), ("s", 65536 | 2097152 | 67108864)):
+            hip.lib().cp_set_debug(dbg)
+            try:
+                outs[name] = hip.dcn_v2_forward(*args).cpu()
+            finally:
+                hip.lib().cp_set_debug(0)
+    finally:
+        hip.set_default_precision("f32")
+    assert torch.equal(outs["t"], outs["t2"])   # deterministic
+    assert float((outs["t"].double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert float((outs["t"] - outs["gather"]).abs().max() / ref.abs().max()) < 2e-6
+    assert not torch.equal(outs["t"], outs["gather"])   # two different kernels really ran
+    assert torch.equal(outs["t"], outs["s"])    # same products in the same order as the streamed kernel
+
+
 @pytest.mark.parametrize("C,Co,HW", [(64, 64, 128), (128, 128, 64)])
 def test_dcn_at_bench_batch_size_independent_properties(device, C, Co, HW):
     """The two heaviest DCNv2 shapes of the benchmark, at the benchmark's batch (B = 64: 8192 / 4096 patches, where no CPU oracle
@@ -420,7 +462,7 @@ def test_dcn_at_bench_batch_size_independent_properties(device, C, Co, HW):
 
 
 @pytest.mark.parametrize("B,C,Co,HW,n", [(16, 64, 64, 128, 300), (64, 256, 256, 32, 500)])
-@pytest.mark.parametrize("kernel,dbg", [("dcn16p", 65536 | 1048576), ("dcn16p on the 64-wide N tile only", 65536 | 1048576 | 524288),
+@pytest.mark.parametrize("kernel,dbg", [("dcn16p", 65536 | 1048576), ("dcn16t", 65536 | 33554432), ("dcn16p on the 64-wide N tile only", 65536 | 1048576 | 524288),
                                         ("dcn16s", 65536 | 2097152)])
 def test_dcn_kernels_are_stable_over_many_launches(device, kernel, dbg, B, C, Co, HW, n):
     """Regression for the wrong set-up values found in round 4 and explained in round 5 (profiles/NOTES.md: a packed-f32 op with a

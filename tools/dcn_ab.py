@@ -10,7 +10,7 @@ import sys
 
 SHAPES = [  # (Cin, Cout, HW, count in the network)
     (64, 64, 128, 5), (128, 64, 64, 4), (128, 128, 64, 2), (256, 128, 32, 2), (256, 256, 32, 1), (256, 64, 32, 1), (512, 256, 16, 1)]
-MODES = [("dcn16p", 1048576 | 524288), ("dcn16pw", 1048576), ("dcn16s", 2097152)]  # (dcn16pw: the 128-wide N tile where Cout % 128 == 0)
+MODES = [("dcn16p", 1048576 | 524288), ("dcn16pw", 1048576), ("dcn16s", 2097152), ("dcn16t", 33554432)]  # (dcn16pw: the 128-wide N tile where Cout % 128 == 0)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--b", type=int, default=64)
@@ -18,7 +18,7 @@ ap.add_argument("--n", type=int, default=5)
 ap.add_argument("--std", type=float, default=1.5)
 ap.add_argument("--parse", default=None)
 ap.add_argument("--nshapes", type=int, default=7)
-ap.add_argument("--only", default=None, help="dcn16p | dcn16pw | dcn16s")
+ap.add_argument("--only", default=None, help="dcn16p | dcn16pw | dcn16s | dcn16t")
 a = ap.parse_args()
 SHAPES = SHAPES[:a.nshapes]
 if a.only:
@@ -26,7 +26,7 @@ if a.only:
 
 if a.parse:
     f = sorted(glob.glob(os.path.join(a.parse, "**", "*kernel_trace.csv"), recursive=True))[0]
-    rows = [r for r in csv.DictReader(open(f)) if "dcn16p_kernel" in r["Kernel_Name"] or "dcn16s_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in ("dcn16p_kernel", "dcn16s_kernel", "dcn16t_kernel"))]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     i = 0
     tot = {m: 0.0 for m, _ in MODES}
@@ -35,7 +35,7 @@ if a.parse:
         for m, _ in MODES:
             grp = rows[i:i + 2 + a.n]
             i += 2 + a.n
-            names = {("dcn16s" if "dcn16s" in r["Kernel_Name"] else "dcn16pw" if "dcn16p_kernel<4" in r["Kernel_Name"] else "dcn16p") for r in grp}
+            names = {("dcn16t" if "dcn16t" in r["Kernel_Name"] else "dcn16s" if "dcn16s" in r["Kernel_Name"] else "dcn16pw" if "dcn16p_kernel<4" in r["Kernel_Name"] else "dcn16p") for r in grp}
             d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in grp[2:]]
             avg = sum(d) / max(1, len(d))
             tot[m] += avg * cnt
@@ -65,5 +65,7 @@ for (ci, co, hw, cnt) in SHAPES:
         torch.cuda.synchronize()
         outs.append(y)
     hip.lib().cp_set_debug(0)
-    err = float((outs[0] - outs[-1]).abs().max() / outs[0].abs().max())
-    print("%d->%d @%d: max |dcn16p - dcn16s| / max = %.2e; 128-wide == 64-wide: %s" % (ci, co, hw, err, bool(torch.equal(outs[0], outs[1])) if len(outs) > 2 else "-"), flush=True)
+    err = float((outs[0] - outs[2]).abs().max() / outs[0].abs().max()) if len(outs) > 2 else -1.0
+    errt = float((outs[0] - outs[-1]).abs().max() / outs[0].abs().max())
+    print("%d->%d @%d: max |dcn16p - dcn16s| / max = %.2e; |dcn16p - dcn16t| / max = %.2e; dcn16t == dcn16s bit for bit: %s; 128-wide == 64-wide: %s" % (
+        ci, co, hw, err, errt, bool(torch.equal(outs[2], outs[-1])) if len(outs) > 3 else "-", bool(torch.equal(outs[0], outs[1])) if len(outs) > 2 else "-"), flush=True)
