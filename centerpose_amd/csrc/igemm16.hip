@@ -989,6 +989,7 @@ static bool dcn16s_wanted(const ConvParams& p) {
 static bool dcn16t_wanted(const ConvParams& p) {
     if ((p.dbg & 67108864) || !dcn16p_wanted(p) || !cp_dcn16t_supported(p)) return false;
     if (p.dbg & 33554432) return true;
+    if (p.dbg & 2097152) return false;  // (dcn16s asked for by name)
     return !cp_dcn16p_wide(p) && cp_dcn16p_blocks(p) >= 1024;
 }
 

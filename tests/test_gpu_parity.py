@@ -409,10 +409,10 @@ def test_dcn_three_workgroups_per_cu_vs_oracle_and_other_kernels(device, B, C, C
 def test_dcn_at_bench_batch_size_independent_properties(device, C, Co, HW):
     """The two heaviest DCNv2 shapes of the benchmark, at the benchmark's batch (B = 64: 8192 / 4096 patches, where no CPU oracle
     finishes in seconds) through properties that do not depend on the size:
-      * the launch really goes to the kernel the dispatcher means -- the persistent dcn16s for 64 -> 64, dcn16p on the 128-wide N
-        tile for 128 -> 128 -- and it agrees with the other patch kernel (cp_set_debug 1048576 resp. 65536 | 2097152) and with the
-        gather kernel dcn16 (32768) to summation-order round-off; the 128-wide tile equals the 64-wide one (524288 | 1048576) bit
-        for bit;
+      * the launch really goes to the kernel the dispatcher means -- dcn16t (three workgroups per CU, round 6) for 64 -> 64, dcn16p on
+        the 128-wide N tile for 128 -> 128 -- and it agrees with another patch kernel (dcn16p: 67108864 | 1048576, resp. dcn16s:
+        65536 | 2097152) and with the gather kernel dcn16 (32768) to summation-order round-off; the 128-wide tile equals the 64-wide
+        one (524288 | 1048576 | 67108864) and dcn16t equals dcn16s (same K order) bit for bit;
       * homogeneity: without a bias f(4 x) == 4 f(x) bit for bit -- every operand is pre-scaled by exact powers of two
         (profiles/NOTES.md 3.1), so a power-of-two input scale must come out as exactly that scale;
       * additivity in the input for fixed offsets / masks: f(x1 + x2) - f(x1) - f(x2) + f(0) == 0 to round-off;
@@ -431,7 +431,7 @@ def test_dcn_at_bench_batch_size_independent_properties(device, C, Co, HW):
         f = lambda x, m=mask: hip.dcn_v2_forward(x, w, b, off, m, *tail)
         y1 = f(x1)
         scale = float(y1.abs().max())
-        for dbg in ((1048576 if Co % 128 else 65536 | 2097152), 32768):
+        for dbg in ((67108864 | 1048576 if Co % 128 else 65536 | 2097152), 32768):
             hip.lib().cp_set_debug(dbg)
             try:
                 other = f(x1)
@@ -439,12 +439,11 @@ def test_dcn_at_bench_batch_size_independent_properties(device, C, Co, HW):
                 hip.lib().cp_set_debug(0)
             assert not torch.equal(other, y1), dbg            # a different kernel ran
             assert float((other - y1).abs().max()) / scale < 2e-6, dbg
-        if Co % 128 == 0:
-            hip.lib().cp_set_debug(524288 | 1048576)
-            try:
-                assert torch.equal(f(x1), y1)
-            finally:
-                hip.lib().cp_set_debug(0)
+        hip.lib().cp_set_debug(524288 | 1048576 | 67108864 if Co % 128 == 0 else 67108864 | 65536 | 2097152)
+        try:
+            assert torch.equal(f(x1), y1)
+        finally:
+            hip.lib().cp_set_debug(0)
         bias = b.view(1, Co, 1, 1)
         # (without a bias the property is exact: the products, their sums and the epilogue's power-of-two scales carry the factor 4
         # through unchanged; with one, fl(4 X + b) - b and 4 (fl(X + b) - b) differ by the roundings of the additions: a few ulp)
@@ -462,7 +461,7 @@ def test_dcn_at_bench_batch_size_independent_properties(device, C, Co, HW):
 
 
 @pytest.mark.parametrize("B,C,Co,HW,n", [(16, 64, 64, 128, 300), (64, 256, 256, 32, 500)])
-@pytest.mark.parametrize("kernel,dbg", [("dcn16p", 65536 | 1048576), ("dcn16t", 65536 | 33554432), ("dcn16p on the 64-wide N tile only", 65536 | 1048576 | 524288),
+@pytest.mark.parametrize("kernel,dbg", [("dcn16p", 65536 | 1048576 | 67108864), ("dcn16t", 65536 | 33554432), ("dcn16p on the 64-wide N tile only", 65536 | 1048576 | 524288 | 67108864),
                                         ("dcn16s", 65536 | 2097152)])
 def test_dcn_kernels_are_stable_over_many_launches(device, kernel, dbg, B, C, Co, HW, n):
     """Regression for the wrong set-up values found in round 4 and explained in round 5 (profiles/NOTES.md: a packed-f32 op with a
@@ -624,7 +623,7 @@ def test_backbone_at_bench_batch_spot_parity(device, arch, B, pick):
 
 # kernel names (cp_kernel_variant_name) every bench-size forward must have launched: the hot path of SURVEY 8(a) M2-M7
 _HOT_VARIANTS = ("halo16_head_f16x3", "halo16_f16x3_m128n128", "halo16_f16x3_m128n64", "halo16_f16x3_m128n32", "pw16_f16x3",
-                 "lowc_stem7x7", "lowc_3x3_c16", "lowc_3x3s2", "igemm16_f16x3", "dcn16s_f16x3", "dcn16p_f16x3")
+                 "lowc_stem7x7", "lowc_3x3_c16", "lowc_3x3s2", "igemm16_f16x3", "dcn16t_f16x3", "dcn16p_f16x3")
 
 
 @pytest.mark.parametrize("arch,B,reps", [("dla_34", 64, 60), ("dlav1_34", 32, 60)])
@@ -672,10 +671,11 @@ def test_backbone_at_bench_batch_every_image_every_launch(device, arch, B, reps)
 # size (other kernels than at the 128^2 goldens: dcn16s from 4096 patches, the 128-wide DCN tile, the walk over all twelve heads)
 _LEG_VARIANTS = {
     "hourglass": ("halo16_head_f16x3", "halo16_f16x3_m128n128", "igemm16_f16x3", "pw16_f16x3"),
-    # (B = 16: 2048 patches of 8 x 16 -- below dcn16s's 4096-item threshold, so both N tiles of dcn16p carry the DCN layers, and
-    # exactly the count from which a workgroup of the head launch walks every head of its patch)
-    "track": tuple(v for v in _HOT_VARIANTS if v != "dcn16s_f16x3") + ("dcn16p_f16x3_p128n64", "dcn16p_f16x3_p128n128"),
-    "track_gru": tuple(v for v in _HOT_VARIANTS if v not in ("dcn16s_f16x3", "halo16_head_f16x3")) +
+    # (B = 16: 2048 patches of 8 x 16 -- the 64 -> 64 @128^2 layers are over dcn16t's 1024-workgroup threshold, the deeper Cout = 64
+    # ones under it (dcn16p), the others on the 128-wide tile; and exactly the count from which a workgroup of the head launch
+    # walks every head of its patch)
+    "track": _HOT_VARIANTS + ("dcn16p_f16x3_p128n64", "dcn16p_f16x3_p128n128"),
+    "track_gru": tuple(v for v in _HOT_VARIANTS if v != "halo16_head_f16x3") +
                  ("dcn16p_f16x3_p128n64", "dcn16p_f16x3_p128n128", "halo16_gru_f16x3", "gn_final"),
 }
 

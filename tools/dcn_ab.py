@@ -10,7 +10,7 @@ import sys
 
 SHAPES = [  # (Cin, Cout, HW, count in the network)
     (64, 64, 128, 5), (128, 64, 64, 4), (128, 128, 64, 2), (256, 128, 32, 2), (256, 256, 32, 1), (256, 64, 32, 1), (512, 256, 16, 1)]
-MODES = [("dcn16p", 1048576 | 524288), ("dcn16pw", 1048576), ("dcn16s", 2097152), ("dcn16t", 33554432)]  # (dcn16pw: the 128-wide N tile where Cout % 128 == 0)
+MODES = [("dcn16p", 1048576 | 524288 | 67108864), ("dcn16pw", 1048576 | 67108864), ("dcn16s", 2097152), ("dcn16t", 33554432)]  # (dcn16pw: the 128-wide N tile where Cout % 128 == 0)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--b", type=int, default=64)
