@@ -399,6 +399,31 @@ def pnp_from_post(post, count, cam, rep_mode=1, out=None, ws=None):
     return out
 
 
+_masked_streams = []   # (handle, torch stream): kept alive for the life of the process
+
+
+def masked_stream(device, n_cus):
+    """A HIP stream whose kernels may only run on the first ``n_cus`` compute units (hipExtStreamCreateWithCUMask; bits are spread
+    over the XCDs by the runtime), wrapped as a torch stream.  For latency-bound side work that must not take registers away from
+    the kernels of the main stream everywhere on the chip: the batched PnP solve holds 286 - 330 vector registers per wavefront
+    -- one such wave takes more than half of a SIMD's register file for the ~0.5 ms of its Levenberg-Marquardt walk, and a few
+    hundred of them spread over all 1024 SIMDs cost the network kernels they overlap ~0.3 ms per step (profiles/NOTES.md round 6)."""
+    rt = ctypes.CDLL("libamdhip64.so")
+    words = (int(n_cus) + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for i in range(int(n_cus)):
+        mask[i // 32] |= 1 << (i % 32)
+    h = ctypes.c_void_p()
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        rc = rt.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
+    if rc != 0 or not h.value:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed with code %d" % rc)
+    st = torch.cuda.ExternalStream(h.value, device=dev)
+    _masked_streams.append((h, st))
+    return st
+
+
 class PoseStage(object):
     """Post-process + soft-NMS + batched PnP of decoded batches (base_detector.py:547-654 for a whole batch), with the
     PnP on a side stream.  The solve is at most B*K independent float64 problems of ~1e5 operations each: a few dozen
@@ -412,10 +437,24 @@ class PoseStage(object):
     Caller-owned inputs (``det``, ``meta``, ``cam``) are read on the side stream as well: the stage tells the caching
     allocator (``record_stream``), so the caller may drop them right after ``submit``."""
 
-    def __init__(self, B, K, device, depth=2):
+    def __init__(self, B, K, device, depth=2, cus=None):
+        """``cus``: run the solve on a stream restricted to that many compute units (``masked_stream``); None = $CP_PNP_CUS or,
+        unset, 32 (B = 64, 1650 mostly ill-posed detections per batch, profiles/r06_pnp_cu_mask_ab.txt: the first layers of the
+        next batch, which the solve overlaps, 1.60 -> 1.45 ms, step 18.74 -> 18.63 ms with the longer solve's tail included; 8 / 16
+        CUs stretch the solve to 5.4 / 3.4 ms and lose); 0 = an ordinary stream (the solve's waves land on every CU)."""
         L = lib()
         self.B, self.K, self.depth, self.i = int(B), int(K), int(depth), 0
-        self.side = torch.cuda.Stream(device=device)
+        if cus is None:
+            cus = int(os.environ.get("CP_PNP_CUS", "32"))
+        self.cus = int(cus)
+        self.side = None
+        if self.cus > 0:
+            try:
+                self.side = masked_stream(device, self.cus)
+            except (RuntimeError, OSError, AttributeError):   # runtime without the extension: an ordinary stream does the same work
+                self.cus = 0
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=device)
         n_post, n_pnp = L.cp_postprocess_workspace_bytes(B, K), L.cp_pnp_from_post_workspace_bytes(B, K)
         self.sets = []
         for _ in range(self.depth):
