@@ -399,7 +399,9 @@ def pnp_from_post(post, count, cam, rep_mode=1, out=None, ws=None):
     return out
 
 
-_masked_streams = []   # (handle, torch stream): kept alive for the life of the process
+_masked_streams = {}   # (device index, n_cus) -> (handle, torch stream): ONE stream per mask for the life of the process (every
+                       # hipExtStreamCreateWithCUMask is a hardware queue of its own; a process that kept creating them would
+                       # push its other streams onto shared queues)
 
 
 def masked_stream(device, n_cus):
@@ -408,19 +410,22 @@ def masked_stream(device, n_cus):
     the kernels of the main stream everywhere on the chip: the batched PnP solve holds 286 - 330 vector registers per wavefront
     -- one such wave takes more than half of a SIMD's register file for the ~0.5 ms of its Levenberg-Marquardt walk, and a few
     hundred of them spread over all 1024 SIMDs cost the network kernels they overlap ~0.3 ms per step (profiles/NOTES.md round 6)."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(n_cus))
+    if key in _masked_streams:
+        return _masked_streams[key][1]
     rt = ctypes.CDLL("libamdhip64.so")
     words = (int(n_cus) + 31) // 32
     mask = (ctypes.c_uint32 * words)()
     for i in range(int(n_cus)):
         mask[i // 32] |= 1 << (i % 32)
     h = ctypes.c_void_p()
-    dev = torch.device(device)
     with torch.cuda.device(dev):
         rc = rt.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
     if rc != 0 or not h.value:
         raise RuntimeError("hipExtStreamCreateWithCUMask failed with code %d" % rc)
     st = torch.cuda.ExternalStream(h.value, device=dev)
-    _masked_streams.append((h, st))
+    _masked_streams[key] = (h, st)
     return st
 
 

@@ -72,9 +72,22 @@ for k in sorted(by_k, key=lambda k: -by_k[k].get("GRBM_GUI_ACTIVE", 0) * calls[k
     if clk.get(k):
         cyc, ns = sum(c for c, _ in clk[k]), sum(n for _, n in clk[k])
         mhz = cyc / ns * 1e3
-        note = "" if mhz <= 2450 else "  (!) above the part's 2.4 GHz: timestamps and counters disagree"
-        print("  %-34s %15.0f MHz (per-XCD GUI clocks / the same dispatches' own %.1f us in this counter pass%s)" % (
-            "shader clock", mhz, ns / len(clk[k]) / 1e3, note))
+        # GRBM_GUI_ACTIVE of a dispatch also counts a fixed stretch around the kernel (dispatch set-up, counter read-out, cache
+        # write-back): for a kernel that is launched at several sizes the SLOPE of cycles over duration is the clock and the
+        # intercept that stretch; the plain quotient of a short kernel reads high by intercept / duration
+        durs = sorted(n for _, n in clk[k])
+        fit = ""
+        if len(durs) >= 6 and durs[-1] > 1.5 * durs[0]:
+            n_ = len(clk[k])
+            mx, my = ns / n_, cyc / n_
+            sxx = sum((n - mx) ** 2 for _, n in clk[k])
+            sxy = sum((n - mx) * (c - my) for c, n in clk[k])
+            slope = sxy / sxx
+            fit = "; fit over %d launches of %.0f .. %.0f us: %.0f MHz + %.0f k cycles per launch" % (
+                n_, durs[0] / 1e3, durs[-1] / 1e3, slope * 1e3, (my - slope * mx) / 1e3)
+        note = "" if mhz <= 2450 else "  (!) above the part's 2.4 GHz: see the fit / the fixed stretch per launch"
+        print("  %-34s %15.0f MHz (per-XCD GUI clocks / the same dispatches' own %.1f us in this counter pass%s%s)" % (
+            "shader clock", mhz, ns / len(clk[k]) / 1e3, fit, note))
         if k in trace_dur:
             print("  %-34s %15.1f us (kernel-trace run, no counters; the counter pass stretches a dispatch by x%.2f)" % (
                 "un-instrumented launch", trace_dur[k] / 1e3, ns / len(clk[k]) / trace_dur[k]))
