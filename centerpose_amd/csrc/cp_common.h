@@ -200,7 +200,7 @@ int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream);
 // K steps (of 16 for the f32 kernels, 32 for f16x3) and output tiles of the launch cp_launch_conv[16] would make
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 40
+#define CP_NUM_CONV_VARIANTS 41
 #define CP_VARIANT_GRU 26
 // split-f16 ("f16x3") implicit GEMM (igemm16.hip)
 bool cp_conv16_supported(const ConvParams& p);
@@ -280,6 +280,11 @@ int cp_launch_lowc(int kind, const float* in, float* out, const void* w_hi, cons
                    const float* shift, const unsigned* in_amax, unsigned* out_amax, int B, int H, int W, int planes,
                    hipStream_t s);
 #define CP_VARIANT_LOWC0 23
+// stem + level0 in one launch (lowc.hip: lowc2_kernel): the 16-channel full-resolution tensor between them is never stored
+#define CP_VARIANT_LOWC01 40
+int cp_launch_lowc_fused(const float* in, float* out, const void* w0_hi, const void* w0_lo, const float* scale0, const float* shift0,
+                         const void* w1_hi, const void* w1_lo, const float* scale1, const float* shift1, float bound_l, float bound_s,
+                         const unsigned* in_amax, unsigned* out_amax, int B, int H, int W, int planes, hipStream_t s);
 #define CP_PREC_F32 0
 #define CP_PREC_F16X3 1
 

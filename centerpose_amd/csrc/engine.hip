@@ -134,7 +134,7 @@ int g_default_precision = CP_PREC_F32;
 // split-K policy: launches with fewer output tiles than kSplitTiles (and >= 8 K steps) are cut into K slices until
 // about kSplitTarget workgroups exist
 constexpr int kSplitTiles = 128, kSplitTarget = 384;  // (384 / 512 measured: B=32 equal, hourglass B=1 latency +7 %)
-int g_dbg = 0;  // cp_set_debug (include/centerpose_hip_testing.h: kernel SELECTION switches for the parity tests and A/B runs; every choice computes the layer correctly): 8 split-K epilogue element-wise (not the quad form), 1 grouped heads write slabs + reduction launch, 2 grouped heads one workgroup per head (not per patch), 16 small launches on 128-row tiles, 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel, 256 unfused ConvGRU step, 512 no activation |max| tracking / pre-scale, 1024 previous DCN loop, 2048 alternative DCN wave counts, 4096 / 8192 halo kernel never / everywhere, 16384 LDS-staged weights in the N=32 halo kernel, 32768 / 65536 patch-resident DCN never / everywhere, 524288 patch-resident DCN never on the 128-wide N tile, 1048576 / 2097152 streamed DCN (dcn16s) never / everywhere, 33554432 / 67108864 three-workgroup DCN (dcn16t) everywhere / never, 131072 GroupNorm'd heads' 1x1 on the matrix cores, 4194304 1x1 layers on the LDS-staged loop instead of pw16.hip, 8388608 cp_dcnv2_forward always on the generic kernel, 16777216 fused heads one launch per head instead of one grouped launch
+int g_dbg = 0;  // cp_set_debug (include/centerpose_hip_testing.h: kernel SELECTION switches for the parity tests and A/B runs; every choice computes the layer correctly): 8 split-K epilogue element-wise (not the quad form), 1 grouped heads write slabs + reduction launch, 2 grouped heads one workgroup per head (not per patch), 16 small launches on 128-row tiles, 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel, 256 unfused ConvGRU step, 512 no activation |max| tracking / pre-scale, 1024 previous DCN loop, 2048 alternative DCN wave counts, 4096 / 8192 halo kernel never / everywhere, 16384 LDS-staged weights in the N=32 halo kernel, 32768 / 65536 patch-resident DCN never / everywhere, 524288 patch-resident DCN never on the 128-wide N tile, 1048576 / 2097152 streamed DCN (dcn16s) never / everywhere, 33554432 / 67108864 three-workgroup DCN (dcn16t) everywhere / never, 134217728 stem and level0 as two kernels (not the fused one), 131072 GroupNorm'd heads' 1x1 on the matrix cores, 4194304 1x1 layers on the LDS-staged loop instead of pw16.hip, 8388608 cp_dcnv2_forward always on the generic kernel, 16777216 fused heads one launch per head instead of one grouped launch
 
 struct DeformW {
     ConvW offset;  // conv_offset_mask (27 -> 32 padded), shift = bias
@@ -179,6 +179,9 @@ struct cp_model {
         int Cin = 0, hid = 0, Kpad16 = 0;
     } head_group;
     std::map<std::string, LowcW> lowc;  // hi / lo weight fragments of the lowc.hip layers
+    int dry_variant = 0;  // work-space query: 1 = the dry run takes the fused stem + level0 path where the model allows it (the query
+                          // runs both forms and returns the larger peak: switches and taps may select either form later)
+    float stem_bound_l = 0.f, stem_bound_s = 0.f;  // |base_layer out| <= stem_bound_l * max|image| + stem_bound_s (fused stem + level0)
     ConvW gru_x, gru_h;
     void* gru_h16_hi = nullptr;  // hidden-side GRU weights re-ordered [tile][r|z|n][32] for the fused-gate kernel
     void* gru_h16_lo = nullptr;
@@ -504,7 +507,7 @@ struct Packer {
     }
 
     // weight fragments for the direct low-channel kernels (f16x3 mode); the folded BatchNorm comes from the ConvW
-    void lowc(const std::string& name, const std::string& wname, int kind, int cout, int cin, int k) {
+    void lowc(const std::string& name, const std::string& wname, int kind, int cout, int cin, int k, const std::string& affine = "") {
         const auto* w = get(wname + ".weight", (size_t)cout * cin * k * k);
         if (!w) return;
         float* tmp = upload(*w);
@@ -521,7 +524,7 @@ struct Packer {
         int rc = cp_launch_weight_scale(tmp, cout, cin * k * k, fwd, inv, nullptr);
         if (rc == CP_OK) rc = cp_launch_pack_lowc(kind, tmp, hi, lo, fwd, cin, nullptr);
         // the folded BatchNorm of the same layer lives in the ConvW packed under the same name (conv_bn ran first)
-        auto it = m->convs.find(name);
+        auto it = m->convs.find(affine.empty() ? name : affine);
         if (rc == CP_OK) rc = cp_launch_scale16(it != m->convs.end() ? it->second.scale : nullptr, inv, lw.scale16, cout, nullptr);
         hip_ok(hipDeviceSynchronize());
         if (rc != CP_OK) status = rc;
@@ -542,6 +545,23 @@ struct Packer {
         // f16x3 fragments of the same layers (after conv_bn: they take the folded BatchNorm from the ConvW)
         lowc("base.base_layer", "base.base_layer.0", 0, 16, 3, 7);
         lowc("base.level0", "base.level0.0", 1, 16, 16, 3);
+        {   // fused stem + level0 (lowc2_kernel): level0's weights in kernel-row order, and the bound that replaces the measured
+            // |max| of the tensor between the two layers: |relu(bn(conv(x)))_c| <= |s_c| sum|w_c| max|x| + |t_c|
+            lowc("base.level0.rows", "base.level0.0", 4, 16, 16, 3, "base.level0");
+            const auto* w = get("base.base_layer.0.weight", (size_t)16 * 3 * 49);
+            std::vector<float> sc, sh;
+            if (w && bn_fold("base.base_layer.1", 16, nullptr, sc, sh)) {
+                double bl = 0, bs = 0;
+                for (int c = 0; c < 16; ++c) {
+                    double l1 = 0;
+                    for (int i = 0; i < 147; ++i) l1 += std::fabs((double)(*w)[(size_t)c * 147 + i]);
+                    bl = std::max(bl, std::fabs((double)sc[c]) * l1);
+                    bs = std::max(bs, std::fabs((double)sh[c]));
+                }
+                m->stem_bound_l = (float)(bl * 1.0001);
+                m->stem_bound_s = (float)(bs * 1.0001);
+            }
+        }
         lowc("base.level1", "base.level1.0", 2, 32, 16, 3);
         if (has_pre_img) lowc("base.pre_img_layer", "base.pre_img_layer.0", 0, 16, 3, 7);
         if (has_pre_hm) lowc("base.pre_hm_layer", "base.pre_hm_layer.0", 0, 16, 1, 7);
@@ -1209,9 +1229,45 @@ struct Fwd {
              float* const* head_out, int sigmoid_hm) {
         init_slots();
         const bool use_lowc = m->precision == CP_PREC_F16X3 && !(g_dbg & 64) && m->lowc.count("base.base_layer");
-        Tensor x0 = lowc("base.base_layer", 0, images, H, W, 3,
+        // stem + level0 in one launch when nothing is added to the stem's output (no previous-frame stems) and nobody asks for it
+        // (cp_set_debug 134217728: the two kernels, A/B runs and tests)
+        const bool no_pre = m->dry ? m->dry_variant == 1 : (!pre_img && !pre_hm && !pre_hm_hp);
+        const bool fuse01 = use_lowc && no_pre && m->lowc.count("base.level0.rows") && m->stem_bound_l > 0.f &&
+                            !(g_dbg & 134217728) && !(m->tap_name && std::strcmp(m->tap_name, "base.base_layer") == 0) &&
+                            !m->convs.count("base.pre_img_layer") && !m->convs.count("base.pre_hm_layer") && !m->convs.count("base.pre_hm_hp_layer");
+        Tensor l0f;
+        if (fuse01) {
+            const unsigned* in_slot = !m->dry ? input_slot(images, (size_t)B * 3 * H * W) : nullptr;
+            l0f = make(16, H, W);
+            if (!m->dry) {
+                const LowcW& a = m->lowc["base.base_layer"];
+                const LowcW& c = m->lowc["base.level0.rows"];
+                auto launch = [&]() {
+                    return cp_launch_lowc_fused(images, l0f.ptr(), a.hi, a.lo, a.scale16, cw("base.base_layer").shift, c.hi, c.lo, c.scale16,
+                                                cw("base.level0").shift, m->stem_bound_l, m->stem_bound_s, in_slot, l0f.amax, B, H, W, 3, s);
+                };
+                if (m->profile) {
+                    cp_model::ProfRec r;
+                    r.variant = CP_VARIANT_LOWC01;
+                    r.role = CP_ROLE_LOWC;
+                    const double M = (double)B * H * W;
+                    r.flops = 2.0 * M * 16 * (147.0 + 144.0);
+                    r.bytes = 4.0 * (M * 3 + M * 16);
+                    r.M = (int)M; r.N = 16; r.K = 147 + 144; r.kh = 7; r.stride = 1;
+                    r.e0 = m->get_event();
+                    r.e1 = m->get_event();
+                    (void)hipEventRecord(r.e0, s);
+                    chk(launch());
+                    (void)hipEventRecord(r.e1, s);
+                    m->prof.push_back(r);
+                } else {
+                    chk(launch());
+                }
+            }
+        }
+        Tensor x0 = fuse01 ? Tensor() : lowc("base.base_layer", 0, images, H, W, 3,
                          use_lowc && !m->dry ? input_slot(images, (size_t)B * 3 * H * W) : nullptr);
-        if (!x0.valid()) {
+        if (!x0.valid() && !fuse01) {
             Tensor in = to_nhwc(images, 3, 4, H, W);
             x0 = conv(cw("base.base_layer"), {&in}, 1, 3, CP_ACT_RELU);
         }
@@ -1263,8 +1319,9 @@ struct Fwd {
                                            (size_t)B * H * W * 16, sum.amax, s));
             x0 = sum;
         }
-        tap("base.base_layer", x0);
-        Tensor l0 = lowc("base.level0", 1, x0.ptr(), H, W, 16, x0.amax);
+        if (!fuse01) tap("base.base_layer", x0);
+        Tensor l0 = fuse01 ? l0f : lowc("base.level0", 1, x0.ptr(), H, W, 16, x0.amax);
+        l0f = Tensor();  // (one owner: the block returns to the arena when l0 is dropped below)
         if (!l0.valid()) l0 = conv(cw("base.level0"), {&x0}, 1, 1, CP_ACT_RELU);
         tap("base.level0", l0);
         x0 = Tensor();
@@ -1488,7 +1545,9 @@ int forward_impl(cp_model* m, hipStream_t stream, int B, int H, int W, const flo
     Fwd f{m, B, stream};
     if (m->hourglass) f.run_hourglass(H, W, images, head_out, sigmoid_hm);
     else f.run(H, W, images, pre_img, pre_hm, pre_hm_hp, head_out, sigmoid_hm);
-    if (!dry && m->arena.overflow) return fail(CP_ERR_INVALID, "workspace too small");
+    if (!dry && m->arena.overflow)
+        return fail(CP_ERR_INVALID, "workspace too small: " + std::to_string(ws_bytes) + " bytes given, this launch sequence peaks at " +
+                                        std::to_string(m->arena.peak));
     return m->status;
 }
 
@@ -1649,10 +1708,22 @@ void cp_model_destroy(cp_model* m) {
 }
 
 size_t cp_model_workspace_bytes(cp_model* m, int B, int H, int W) {
-    if (forward_impl(m, nullptr, B, H, W, nullptr, (const float*)1, (const float*)1, (const float*)1, nullptr, 0,
-                     nullptr, 0, true) != CP_OK)
-        return 0;
-    return m->arena.peak;
+    // The launch sequence -- and with it the arena's allocation order -- has variants the caller may select later: the first
+    // layers fused or not (engine: fuse01), and a tap request, which turns the fused heads off.  The query runs the dry pass for
+    // every combination and returns the largest peak.
+    size_t peak = 0;
+    const char* const tap_before = m->tap_name;
+    for (int v = 0; v < 4; ++v) {
+        m->dry_variant = v & 1;
+        m->tap_name = (v & 2) ? "" : nullptr;   // "" matches no tensor name: only the routing changes
+        const int rc = forward_impl(m, nullptr, B, H, W, nullptr, (const float*)1, (const float*)1, (const float*)1, nullptr, 0,
+                                    nullptr, 0, true);
+        m->dry_variant = 0;
+        m->tap_name = tap_before;
+        if (rc != CP_OK) return 0;
+        if (m->arena.peak > peak) peak = m->arena.peak;
+    }
+    return peak;
 }
 
 int cp_model_forward(cp_model* m, cp_stream_t stream, int B, int H, int W, const float* images, const float* pre_img,

@@ -245,6 +245,246 @@ __global__ __launch_bounds__(256) void lowc_kernel(const LowcParams p) {
 
 // PyTorch [COUT][cin][KS][KS] float32 -> hi / lo B fragments in the K layout described at the top of the file
 // ci0: first input channel of this plane group (CIN == 4 only)
+// 3x3 / 16-channel weights in the K order of the fused stem + level0 kernel: K step s = (kernel row s / 2, column group s % 2);
+// group 0 = columns 0, 1 (chunk q -> column q / 2, channels 8 (q % 2) .. + 7), group 1 = column 2 in chunks 0, 1 and zeros in
+// chunks 2, 3 -- every K step reads ONE row of the source image, so a wave can multiply a staged row into the three output
+// rows it belongs to.  6 x 32 instead of 5 x 32 deep.
+__global__ void pack_lowc_rows_weights(const float* __restrict__ w, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                       const float* __restrict__ fwd, int cout, int cin) {
+    const int nf = cout / 16, total = 6 * nf * 64 * 8;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int j = idx & 7, lane = (idx >> 3) & 63, sf = idx >> 9;
+        const int f = sf % nf, s = sf / nf;
+        const int co = f * 16 + (lane & 15), q = lane >> 4;
+        const int kh = s >> 1, kw = (s & 1) ? ((q >> 1) == 0 ? 2 : -1) : (q >> 1), ci = (q & 1) * 8 + j;
+        float v = 0.f;
+        if (kw >= 0 && ci < cin) v = w[(((size_t)co * cin + ci) * 3 + kh) * 3 + kw];
+        uint32_t h, l;
+        split2(fwd ? v * fwd[co] : v, 0.f, &h, &l);
+        hi[idx] = (uint16_t)(h & 0xffffu);
+        lo[idx] = (uint16_t)(l & 0xffffu);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused stem (7x7, <= 4 planes -> 16) + level0 (3x3, 16 -> 16), both + BatchNorm + ReLU (pose_dla_dcn.py:268-283, :310-322): the
+// 16-channel full-resolution tensor between them (16.8 MB per 512 x 512 image, written once and read once by the two-kernel
+// form: 43 % of the first three layers' traffic) never exists.
+//
+// A WAVE streams down a column strip on its own -- no barrier, no LDS shared between waves, so every wave of the chip is at
+// another row and the loads / stores / MFMAs of different waves overlap by themselves:
+//   * strip = 14 level0 output columns = one 16-pixel fragment of stem outputs (the 3x3 needs one column either side) = 23
+//     input columns; rows [y0, y0 + R) of level0 = stem rows [y0 - 1, y0 + R] = input rows [y0 - 4, y0 + R + 3];
+//   * per input row j: the row (3 planes x 23 floats, requested three rows ahead) is split into hi / lo halves in a wave-private
+//     LDS row, read back ONCE as the MFMA operand (16 pixels x 8 columns x 4 channels) and multiplied into the SEVEN rolling
+//     stem accumulators it belongs to (kernel rows 6 .. 0 of stem rows j - 3 .. j + 3); stem row j - 3 is then complete:
+//     BatchNorm + ReLU, zero outside the picture (level0's zero padding), x 2^e, split, one wave-private LDS row, read back as
+//     the operands of level0's two K steps per kernel row and multiplied into the THREE rolling level0 accumulators; level0
+//     row j - 4 is complete: BatchNorm + ReLU, one 16-byte store per lane (4 consecutive channels of its pixel);
+//   * products are computed transposed (weights as the first operand): a lane's accumulator quad = channels 4 q .. 4 q + 3 of
+//     pixel lane % 16 -- the layout both the re-split and the stores want;
+//   * 39 MFMAs (16 x 16 x 32) per row and wave: 21 for the stem, 18 for level0; LDS traffic 0.5 KB + 3 KB per row.
+// The intermediate's power-of-two pre-scale cannot come from its measured |max| (it is never stored): it comes from the bound
+// |stem out| <= max_c (|bn scale_c| sum |w_c|) max|x| + max_c |shift_c| (bound_l, bound_s: computed once at model finalize) --
+// a few bits looser than the measured maximum, deterministic, and independent of the other images of the batch.
+// Per level0 row the products are summed in the order (kernel row, columns {0, 1}, column 2): another order than
+// lowc_kernel<16, 3, 1> (tap pairs) -- results agree to float32 round-off.
+struct Lowc2Params {
+    const float* in;   // NCHW [B][planes][H][W]
+    float* out;        // NHWC [B][H][W][16]: level0's output
+    const void *w0_hi, *w0_lo;  // stem fragments [7][64][8] (pack_lowc_weights<4, 7>)
+    const void *w1_hi, *w1_lo;  // level0 fragments [6][64][8] (pack_lowc_rows_weights)
+    const float *scale0, *shift0, *scale1, *shift1;  // folded BatchNorm x 2^-e of the fragment rows
+    const unsigned* in_amax;
+    unsigned* out_amax;
+    float bound_l, bound_s;
+    int B, H, W, planes, rows, strips, bands;
+};
+
+constexpr int L2_SW = 14;                       // level0 columns per strip
+constexpr int L2_INW = 24, L2_STW = 18;         // pixels of the wave-private input / stem rows (23 / 18 used)
+constexpr int L2_PF = 3;                        // input rows requested ahead
+
+__global__ __launch_bounds__(256, 2) void lowc2_kernel(const Lowc2Params p) {
+    __shared__ __attribute__((aligned(16))) _Float16 rows_s[4][2 * (L2_INW * 4 + L2_STW * 16)];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int pl = lane & 15, q = lane >> 4;
+    int t = blockIdx.x;
+    const int sg = t % ((p.strips + 3) / 4);
+    t /= (p.strips + 3) / 4;
+    const int band = t % p.bands, b = t / p.bands;
+    const int sx = sg * 4 + wid, x0 = sx * L2_SW, y0 = band * p.rows;
+    float amax = 0.f;
+    if (x0 < p.W && y0 < p.H) {
+        _Float16* in_hi = rows_s[wid];
+        _Float16* in_lo = in_hi + L2_INW * 4;
+        _Float16* st_hi = in_lo + L2_INW * 4;
+        _Float16* st_lo = st_hi + L2_STW * 16;
+        // ---- weights -> registers (first operand: lane = (output channel lane % 16, k chunk lane / 16)) ----
+        h8 w0h[7], w0l[7], w1h[6], w1l[6];
+        {
+            const u32x4* g0h = reinterpret_cast<const u32x4*>(p.w0_hi) + lane;
+            const u32x4* g0l = reinterpret_cast<const u32x4*>(p.w0_lo) + lane;
+            const u32x4* g1h = reinterpret_cast<const u32x4*>(p.w1_hi) + lane;
+            const u32x4* g1l = reinterpret_cast<const u32x4*>(p.w1_lo) + lane;
+#pragma unroll
+            for (int s = 0; s < 7; ++s) {
+                const u32x4 a = g0h[s * 64], c = g0l[s * 64];
+                w0h[s] = *reinterpret_cast<const h8*>(&a);
+                w0l[s] = *reinterpret_cast<const h8*>(&c);
+            }
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const u32x4 a = g1h[s * 64], c = g1l[s * 64];
+                w1h[s] = *reinterpret_cast<const h8*>(&a);
+                w1l[s] = *reinterpret_cast<const h8*>(&c);
+            }
+        }
+        float afwd = 1.f, ainv = 1.f, hfwd = 1.f, hinv = 1.f;
+        if (p.in_amax) {
+            const unsigned am = cp_amax_read(p.in_amax);
+            cp_amax_to_scale(am, &afwd, &ainv);
+            cp_amax_to_scale(__float_as_uint(p.bound_l * __uint_as_float(am) + p.bound_s), &hfwd, &hinv);
+        }
+        float4 sc0 = p.scale0 ? *reinterpret_cast<const float4*>(p.scale0 + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 sh0 = p.shift0 ? *reinterpret_cast<const float4*>(p.shift0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 sc1 = p.scale1 ? *reinterpret_cast<const float4*>(p.scale1 + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 sh1 = p.shift1 ? *reinterpret_cast<const float4*>(p.shift1 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sc0.x *= ainv; sc0.y *= ainv; sc0.z *= ainv; sc0.w *= ainv;
+        sc1.x *= hinv; sc1.y *= hinv; sc1.z *= hinv; sc1.w *= hinv;
+        // the two pad pixels of the stem row (read by the invalid output columns 14, 15 and by the zero-weight chunks) stay zero
+        if (lane < 32) {
+            reinterpret_cast<uint32_t*>(st_hi + 16 * 16)[lane & 15] = 0u;
+            reinterpret_cast<uint32_t*>(st_lo + 16 * 16)[lane & 15] = 0u;
+        }
+        // ---- input row requests: lane l < 23 -> column x0 - 4 + l of planes 0 .. 2.  NO branch anywhere in the row loop: rows /
+        //      columns / planes that do not exist are requested beyond the buffer descriptor (-> 0, no traffic) and masked stores go
+        //      there too.  (With `if`s around the loads and the store, the compiler's s_waitcnt pass merged the paths conservatively
+        //      and every row waited with vmcnt(0) for the loads it had just issued for three rows later: 3200 clocks per row.) ----
+        const int icol = x0 - 4 + lane;
+        const bool icol_ok = lane < 23 && (unsigned)icol < (unsigned)p.W;
+        const unsigned plane_b = (unsigned)p.H * (unsigned)p.W * 4u;
+        const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + (size_t)b * p.planes * p.H * p.W), 0,
+                                                                            (int)(plane_b * (unsigned)p.planes), 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * p.H * p.W * 16, 0,
+                                                                             (int)((unsigned)p.H * (unsigned)p.W * 64u), 0x00020000);
+        const int so1 = p.planes > 1 ? (int)plane_b : 0x7ffffff0, so2 = p.planes > 2 ? (int)(2u * plane_b) : 0x7ffffff0;
+        auto request = [&](int j, float (&v)[3]) {
+            const unsigned vo = (icol_ok && (unsigned)j < (unsigned)p.H) ? (unsigned)(j * p.W + icol) * 4u : 0xffffffffu;
+            v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_in, (int)vo, 0, 0));
+            v[1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_in, (int)vo, so1, 0));
+            v[2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_in, (int)vo, so2, 0));
+        };
+        const int j0 = y0 - 4, j1 = min(y0 + p.rows, p.H) + 3;   // input rows j0 .. j1 (inclusive)
+        float pv[L2_PF][3];
+#pragma unroll
+        for (int d = 0; d < L2_PF; ++d) request(j0 + d, pv[d]);
+        f32x4 sacc[7], lacc[3];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) sacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int scol = x0 - 1 + pl;  // this lane's stem pixel (column); its level0 pixel is x0 + pl
+        const bool scol_ok = (unsigned)scol < (unsigned)p.W;
+        const bool ocol_ok = pl < L2_SW && x0 + pl < p.W;
+        const int y_end = min(y0 + p.rows, p.H);
+
+        for (int j = j0; j <= j1; ++j) {
+            // ---- input row j: registers -> hi / lo halves in LDS; request row j + 3 ----
+            {
+                uint32_t h0, l0, h1, l1;
+                split2(pv[0][0] * afwd, pv[0][1] * afwd, &h0, &l0);
+                split2(pv[0][2] * afwd, 0.f, &h1, &l1);
+                if (lane < L2_INW) {
+                    *reinterpret_cast<u32x2*>(in_hi + lane * 4) = u32x2{h0, h1};
+                    *reinterpret_cast<u32x2*>(in_lo + lane * 4) = u32x2{l0, l1};
+                }
+#pragma unroll
+                for (int d = 0; d + 1 < L2_PF; ++d) { pv[d][0] = pv[d + 1][0]; pv[d][1] = pv[d + 1][1]; pv[d][2] = pv[d + 1][2]; }
+                request(j + L2_PF, pv[L2_PF - 1]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            h8 ah, al;
+            {
+                const int off = (pl + 2 * q) * 4;  // 8-byte aligned: columns pl + 2 q, pl + 2 q + 1
+                const u32x2 a0 = *reinterpret_cast<const u32x2*>(in_hi + off), a1 = *reinterpret_cast<const u32x2*>(in_hi + off + 4);
+                const u32x2 c0 = *reinterpret_cast<const u32x2*>(in_lo + off), c1 = *reinterpret_cast<const u32x2*>(in_lo + off + 4);
+                const u32x4 hv = {a0.x, a0.y, a1.x, a1.y}, lv = {c0.x, c0.y, c1.x, c1.y};
+                ah = *reinterpret_cast<const h8*>(&hv);
+                al = *reinterpret_cast<const h8*>(&lv);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- stem: input row j is kernel row 6 - k of the stem row in sacc[k] (rows j - 3 .. j + 3) ----
+            // (term-major: the three products of an accumulator -- lo*hi, hi*lo, hi*hi, in that order -- are seven MFMAs apart, so no
+            // MFMA waits for the one in front of it)
+#pragma unroll
+            for (int k = 0; k < 7; ++k) sacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0h[6 - k], al, sacc[k], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) sacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0l[6 - k], ah, sacc[k], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) sacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0h[6 - k], ah, sacc[k], 0, 0, 0);
+            const int i = j - 3;  // the stem row that is complete now
+            const f32x4 sdone = sacc[0];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sacc[k] = sacc[k + 1];
+            sacc[6] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // (stem rows i < y0 - 1 are incomplete -- their upper kernel rows were never fed -- and only reach level0 rows above the
+            // band, which are not stored)
+            {
+                const bool ok = scol_ok && (unsigned)i < (unsigned)p.H;   // level0 sees zeros outside the picture
+                const float v0 = ok ? fmaxf(sdone[0] * sc0.x + sh0.x, 0.f) * hfwd : 0.f;
+                const float v1 = ok ? fmaxf(sdone[1] * sc0.y + sh0.y, 0.f) * hfwd : 0.f;
+                const float v2 = ok ? fmaxf(sdone[2] * sc0.z + sh0.z, 0.f) * hfwd : 0.f;
+                const float v3 = ok ? fmaxf(sdone[3] * sc0.w + sh0.w, 0.f) * hfwd : 0.f;
+                uint32_t h0, l0, h1, l1;
+                split2(v0, v1, &h0, &l0);
+                split2(v2, v3, &h1, &l1);
+                *reinterpret_cast<u32x2*>(st_hi + pl * 16 + q * 4) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(st_lo + pl * 16 + q * 4) = u32x2{l0, l1};
+            }
+            __builtin_amdgcn_wave_barrier();
+            h8 bh[2], bl[2];
+            {
+                const int o0 = (pl + (q >> 1)) * 16 + (q & 1) * 8;   // columns 0, 1 of the kernel row
+                const int o1 = (pl + 2) * 16 + (q & 1) * 8;          // column 2 (chunks 2, 3 meet zero weights)
+                bh[0] = *reinterpret_cast<const h8*>(st_hi + o0);
+                bl[0] = *reinterpret_cast<const h8*>(st_lo + o0);
+                bh[1] = *reinterpret_cast<const h8*>(st_hi + o1);
+                bl[1] = *reinterpret_cast<const h8*>(st_lo + o1);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- level0: stem row i is kernel row 2 - k of the level0 row in lacc[k] (rows i - 1 .. i + 1) ----
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) lacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[2 * (2 - k) + g], bl[g], lacc[k], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) lacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[2 * (2 - k) + g], bh[g], lacc[k], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) lacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[2 * (2 - k) + g], bh[g], lacc[k], 0, 0, 0);
+            }
+            const int o = i - 1;  // the level0 row that is complete now
+            const f32x4 ldone = lacc[0];
+            lacc[0] = lacc[1];
+            lacc[1] = lacc[2];
+            lacc[2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            {
+                const bool st_ok = o >= y0 && o < y_end && ocol_ok;
+                float4 y;
+                y.x = fmaxf(ldone[0] * sc1.x + sh1.x, 0.f);
+                y.y = fmaxf(ldone[1] * sc1.y + sh1.y, 0.f);
+                y.z = fmaxf(ldone[2] * sc1.z + sh1.z, 0.f);
+                y.w = fmaxf(ldone[3] * sc1.w + sh1.w, 0.f);
+                const float m4 = fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w));
+                amax = fmaxf(amax, st_ok ? m4 : 0.f);
+                const u32x4 pk = {__float_as_uint(y.x), __float_as_uint(y.y), __float_as_uint(y.z), __float_as_uint(y.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(pk, r_out, (int)(st_ok ? (unsigned)((o * p.W + x0 + pl) * 64 + 16 * q) : 0x80000000u), 0, 0);
+            }
+        }
+    }
+    if (p.out_amax) cp_amax_commit(p.out_amax, amax);
+}
+
 template <int CIN, int KS>
 __global__ void pack_lowc_weights(const float* __restrict__ w, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
                                   const float* __restrict__ fwd, int cout, int cin, int ci0) {
@@ -280,8 +520,9 @@ int launch_lowc(const LowcParams& p, hipStream_t s) {
 
 // kind: 0 stem 7x7 (NCHW input with `planes` <= 4 channels, pad 3) -> 16; 1 level0 3x3 16->16; 2 level1 3x3/2 16->32;
 //       3 stem 7x7 with 5..8 input planes (two groups of 4) -> 16
+//       4 level0's weights in the row order of the fused stem + level0 kernel (pack only; launched by cp_launch_lowc_fused)
 size_t cp_lowc_weight_halfs(int kind) {
-    return kind == 0 ? (size_t)7 * 1 * 512 : kind == 1 ? (size_t)5 * 1 * 512 : kind == 2 ? (size_t)5 * 2 * 512 : (size_t)14 * 512;
+    return kind == 0 ? (size_t)7 * 1 * 512 : kind == 1 ? (size_t)5 * 1 * 512 : kind == 2 ? (size_t)5 * 2 * 512 : kind == 4 ? (size_t)6 * 512 : (size_t)14 * 512;
 }
 
 int cp_launch_pack_lowc(int kind, const float* w, void* hi, void* lo, const float* fwd, int cin, hipStream_t s) {
@@ -292,7 +533,34 @@ int cp_launch_pack_lowc(int kind, const float* w, void* hi, void* lo, const floa
         hipLaunchKernelGGL((pack_lowc_weights<4, 7>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, fwd, 16, cin, 0);
         hipLaunchKernelGGL((pack_lowc_weights<4, 7>), dim3(16), dim3(256), 0, s, w, (uint16_t*)hi + 7 * 512, (uint16_t*)lo + 7 * 512,
                            fwd, 16, cin, 4);
+    } else if (kind == 4) {
+        hipLaunchKernelGGL(pack_lowc_rows_weights, dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, fwd, 16, cin);
     } else return CP_ERR_INVALID;
+    return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
+}
+
+// stem (<= 3 planes, NCHW) + level0 in one launch -> level0's output (NHWC, 16 channels)
+int cp_launch_lowc_fused(const float* in, float* out, const void* w0_hi, const void* w0_lo, const float* scale0, const float* shift0,
+                         const void* w1_hi, const void* w1_lo, const float* scale1, const float* shift1, float bound_l, float bound_s,
+                         const unsigned* in_amax, unsigned* out_amax, int B, int H, int W, int planes, hipStream_t s) {
+    if (planes < 1 || planes > 3 || B < 1 || H < 1 || W < 1) return CP_ERR_INVALID;
+    Lowc2Params p;
+    p.in = in; p.out = out;
+    p.w0_hi = w0_hi; p.w0_lo = w0_lo; p.w1_hi = w1_hi; p.w1_lo = w1_lo;
+    p.scale0 = scale0; p.shift0 = shift0; p.scale1 = scale1; p.shift1 = shift1;
+    p.in_amax = in_amax; p.out_amax = out_amax;
+    p.bound_l = bound_l; p.bound_s = bound_s;
+    p.B = B; p.H = H; p.W = W; p.planes = planes;
+    p.strips = (W + L2_SW - 1) / L2_SW;
+    // rows per job: about 8192 wave jobs per launch (a job's first 5 rows are recomputed halo), at least 8 rows
+    int bands = 8192 / (B * p.strips);
+    if (bands < 1) bands = 1;
+    int rows = (H + bands - 1) / bands;
+    if (rows < 8) rows = 8;
+    p.rows = rows;
+    p.bands = (H + rows - 1) / rows;
+    const int groups = (p.strips + 3) / 4;
+    hipLaunchKernelGGL(lowc2_kernel, dim3(groups * p.bands * B), dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
 

@@ -623,7 +623,9 @@ def test_backbone_at_bench_batch_spot_parity(device, arch, B, pick):
 
 # kernel names (cp_kernel_variant_name) every bench-size forward must have launched: the hot path of SURVEY 8(a) M2-M7
 _HOT_VARIANTS = ("halo16_head_f16x3", "halo16_f16x3_m128n128", "halo16_f16x3_m128n64", "halo16_f16x3_m128n32", "pw16_f16x3",
-                 "lowc_stem7x7", "lowc_3x3_c16", "lowc_3x3s2", "igemm16_f16x3", "dcn16t_f16x3", "dcn16p_f16x3")
+                 "lowc_stem_level0", "lowc_3x3s2", "igemm16_f16x3", "dcn16t_f16x3", "dcn16p_f16x3")
+# (the CenterPoseTrack networks add the previous-frame stems' outputs to the stem's: their first two layers stay two kernels)
+_HOT_VARIANTS_TRACK = tuple(v for v in _HOT_VARIANTS if v != "lowc_stem_level0") + ("lowc_stem7x7", "lowc_3x3_c16")
 
 
 @pytest.mark.parametrize("arch,B,reps", [("dla_34", 64, 60), ("dlav1_34", 32, 60)])
@@ -674,8 +676,8 @@ _LEG_VARIANTS = {
     # (B = 16: 2048 patches of 8 x 16 -- the 64 -> 64 @128^2 layers are over dcn16t's 1024-workgroup threshold, the deeper Cout = 64
     # ones under it (dcn16p), the others on the 128-wide tile; and exactly the count from which a workgroup of the head launch
     # walks every head of its patch)
-    "track": _HOT_VARIANTS + ("dcn16p_f16x3_p128n64", "dcn16p_f16x3_p128n128"),
-    "track_gru": tuple(v for v in _HOT_VARIANTS if v != "halo16_head_f16x3") +
+    "track": _HOT_VARIANTS_TRACK + ("dcn16p_f16x3_p128n64", "dcn16p_f16x3_p128n128"),
+    "track_gru": tuple(v for v in _HOT_VARIANTS_TRACK if v != "halo16_head_f16x3") +
                  ("dcn16p_f16x3_p128n64", "dcn16p_f16x3_p128n128", "halo16_gru_f16x3", "gn_final"),
 }
 
@@ -783,6 +785,46 @@ def test_conv_kernels_are_stable_over_many_launches(device, f16x3, name, B, H, C
         ref = ref.clamp_min(0.0)
         got = first[b:b + 1].permute(0, 3, 1, 2).double().cpu()
         assert float((got - ref).abs().max()) < 3e-5 * max(1.0, float(ref.abs().max())), (name, b)
+
+
+@pytest.mark.parametrize("arch,B,h,w", [("dla_34", 2, 128, 128), ("dla_34", 2, 96, 160), ("dlav1_34", 1, 256, 256), ("dla_34", 3, 512, 512),
+                                        ("dla_34", 1, 32, 32), ("dla_34", 5, 64, 224)])
+def test_fused_stem_level0_vs_two_kernels_and_oracle(device, arch, B, h, w):
+    """lowc2_kernel (stem 7x7 + level0 3x3 in one launch: a wave streams down a 14-column strip, the 16-channel tensor between the
+    two layers never exists; its pre-scale comes from a bound, not from a measured |max|) against the two-kernel form
+    (cp_set_debug 134217728) on level0's output (tap) -- other pre-scale and another summation order: float32 round-off -- and,
+    through the whole network, against the CPU oracle at the north-star gates.  Sizes: strips that end inside the picture (96 x 160:
+    12 strips, the last 6 columns wide; 224: exactly 16), one band and several, a picture smaller than a band, B not a power of
+    two.  The tap of the stem itself still works (the engine falls back to two kernels for it)."""
+    heads = synth.HEADS_POSE
+    sd = synth.make_state_dict(arch, heads)
+    x = synth.frames(B, seed=23, h=h, w=w).to(device)
+    model = hip.HipModel(arch, heads, sd, precision="f16x3")
+    model.profile(True)
+    z1, t1 = model.forward(x, tap="base.level0")
+    ran = model.profile_read()
+    model.profile(False)
+    assert any(n.startswith("lowc_stem_level0") for n in ran) and not any(n.startswith("lowc_stem7x7") for n in ran), sorted(ran)
+    z1 = {k: v.clone() for k, v in z1.items()}
+    t1 = t1.clone()
+    _, t1b = model.forward(x, tap="base.level0")
+    assert torch.equal(t1, t1b)   # deterministic
+    hip.lib().cp_set_debug(134217728)
+    try:
+        model.profile(True)
+        _, t0 = model.forward(x, tap="base.level0")
+        assert any(n.startswith("lowc_stem7x7") for n in model.profile_read())
+        model.profile(False)
+    finally:
+        hip.lib().cp_set_debug(0)
+    assert t1.shape == t0.shape == (B, 16, h, w)
+    assert float((t1 - t0).abs().max()) < 2e-6 * max(1.0, float(t0.abs().max()))
+    _, ts = model.forward(x, tap="base.base_layer")   # asking for the stem's output selects the two-kernel form
+    assert ts.shape == (B, 16, h, w) and float(ts.abs().max()) > 0
+    zo = ob.dlaseg_forward(sd, x[B - 1:].cpu(), heads, arch=arch.split("_")[0])
+    assert float((torch.sigmoid(z1["hm"][B - 1:]).cpu() - torch.sigmoid(zo["hm"])).abs().max()) < 1e-3
+    for k in ("wh", "hps", "reg", "hp_offset", "scale"):
+        assert float((z1[k][B - 1:].cpu() - zo[k]).abs().max()) < 1e-3 * max(1.0, float(zo[k].abs().max())), k
 
 
 def test_first_layers_are_stable_over_many_launches(device):
