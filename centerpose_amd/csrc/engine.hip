@@ -179,6 +179,8 @@ struct cp_model {
         int Cin = 0, hid = 0, Kpad16 = 0;
     } head_group;
     std::map<std::string, LowcW> lowc;  // hi / lo weight fragments of the lowc.hip layers
+    int ws_key[4] = {0, 0, 0, -1};  // (B, H, W, g_dbg) of the cached work-space query below
+    size_t ws_cached = 0;
     int dry_variant = 0;  // work-space query: 1 = the dry run takes the fused stem + level0 path where the model allows it (the query
                           // runs both forms and returns the larger peak: switches and taps may select either form later)
     float stem_bound_l = 0.f, stem_bound_s = 0.f;  // |base_layer out| <= stem_bound_l * max|image| + stem_bound_s (fused stem + level0)
@@ -1637,6 +1639,7 @@ int cp_set_default_precision(int precision) {
 int cp_model_set_precision(cp_model* m, int precision) {
     if (!m || (precision != CP_PREC_F32 && precision != CP_PREC_F16X3)) return fail(CP_ERR_INVALID, "bad argument");
     m->precision = precision;
+    m->ws_cached = 0;  // (the two arithmetic modes run different launch sequences)
     return CP_OK;
 }
 
@@ -1711,6 +1714,8 @@ size_t cp_model_workspace_bytes(cp_model* m, int B, int H, int W) {
     // The launch sequence -- and with it the arena's allocation order -- has variants the caller may select later: the first
     // layers fused or not (engine: fuse01), and a tap request, which turns the fused heads off.  The query runs the dry pass for
     // every combination and returns the largest peak.
+    if (m && m->ws_cached && m->ws_key[0] == B && m->ws_key[1] == H && m->ws_key[2] == W && m->ws_key[3] == g_dbg && m->finalized)
+        return m->ws_cached;   // (cp_model_detect asks on every call: four dry passes per frame would show in the batch-1 latency)
     size_t peak = 0;
     const char* const tap_before = m->tap_name;
     for (int v = 0; v < 4; ++v) {
@@ -1723,6 +1728,8 @@ size_t cp_model_workspace_bytes(cp_model* m, int B, int H, int W) {
         if (rc != CP_OK) return 0;
         if (m->arena.peak > peak) peak = m->arena.peak;
     }
+    m->ws_key[0] = B; m->ws_key[1] = H; m->ws_key[2] = W; m->ws_key[3] = g_dbg;
+    m->ws_cached = peak;
     return peak;
 }
 

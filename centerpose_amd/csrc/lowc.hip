@@ -305,8 +305,20 @@ constexpr int L2_SW = 14;                       // level0 columns per strip
 constexpr int L2_INW = 24, L2_STW = 18;         // pixels of the wave-private input / stem rows (23 / 18 used)
 constexpr int L2_PF = 3;                        // input rows requested ahead
 
-__global__ __launch_bounds__(256, 2) void lowc2_kernel(const Lowc2Params p) {
+__global__ __launch_bounds__(256, 3) void lowc2_kernel(const Lowc2Params p) {
     __shared__ __attribute__((aligned(16))) _Float16 rows_s[4][2 * (L2_INW * 4 + L2_STW * 16)];
+    // level0's 12 weight fragments (hi, lo x 6 K steps) live in LDS, shared by the four waves and read per row (12 KB of the
+    // ~15 KB a wave reads per row: a fifth of the LDS rate) -- in registers they were 48 of 192 and the kernel ran two waves per
+    // SIMD; without them it fits three
+    __shared__ __attribute__((aligned(16))) u32x4 w1_s[2][6][64];
+    {
+        const int t = threadIdx.x;
+        for (int i = t; i < 2 * 6 * 64; i += 256) {
+            const int pl_ = i / (6 * 64), r = i - pl_ * (6 * 64);
+            w1_s[pl_][r / 64][r % 64] = reinterpret_cast<const u32x4*>(pl_ ? p.w1_lo : p.w1_hi)[r];
+        }
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int pl = lane & 15, q = lane >> 4;
     int t = blockIdx.x;
@@ -321,23 +333,15 @@ __global__ __launch_bounds__(256, 2) void lowc2_kernel(const Lowc2Params p) {
         _Float16* st_hi = in_lo + L2_INW * 4;
         _Float16* st_lo = st_hi + L2_STW * 16;
         // ---- weights -> registers (first operand: lane = (output channel lane % 16, k chunk lane / 16)) ----
-        h8 w0h[7], w0l[7], w1h[6], w1l[6];
+        h8 w0h[7], w0l[7];
         {
             const u32x4* g0h = reinterpret_cast<const u32x4*>(p.w0_hi) + lane;
             const u32x4* g0l = reinterpret_cast<const u32x4*>(p.w0_lo) + lane;
-            const u32x4* g1h = reinterpret_cast<const u32x4*>(p.w1_hi) + lane;
-            const u32x4* g1l = reinterpret_cast<const u32x4*>(p.w1_lo) + lane;
 #pragma unroll
             for (int s = 0; s < 7; ++s) {
                 const u32x4 a = g0h[s * 64], c = g0l[s * 64];
                 w0h[s] = *reinterpret_cast<const h8*>(&a);
                 w0l[s] = *reinterpret_cast<const h8*>(&c);
-            }
-#pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                const u32x4 a = g1h[s * 64], c = g1l[s * 64];
-                w1h[s] = *reinterpret_cast<const h8*>(&a);
-                w1l[s] = *reinterpret_cast<const h8*>(&c);
             }
         }
         float afwd = 1.f, ainv = 1.f, hfwd = 1.f, hinv = 1.f;
@@ -456,12 +460,19 @@ __global__ __launch_bounds__(256, 2) void lowc2_kernel(const Lowc2Params p) {
             // ---- level0: stem row i is kernel row 2 - k of the level0 row in lacc[k] (rows i - 1 .. i + 1) ----
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
+                h8 wh[3], wl[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) lacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[2 * (2 - k) + g], bl[g], lacc[k], 0, 0, 0);
+                for (int k = 0; k < 3; ++k) {
+                    const u32x4 a = w1_s[0][2 * (2 - k) + g][lane], c = w1_s[1][2 * (2 - k) + g][lane];
+                    wh[k] = *reinterpret_cast<const h8*>(&a);
+                    wl[k] = *reinterpret_cast<const h8*>(&c);
+                }
 #pragma unroll
-                for (int k = 0; k < 3; ++k) lacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[2 * (2 - k) + g], bh[g], lacc[k], 0, 0, 0);
+                for (int k = 0; k < 3; ++k) lacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[k], bl[g], lacc[k], 0, 0, 0);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) lacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[2 * (2 - k) + g], bh[g], lacc[k], 0, 0, 0);
+                for (int k = 0; k < 3; ++k) lacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[k], bh[g], lacc[k], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) lacc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[k], bh[g], lacc[k], 0, 0, 0);
             }
             const int o = i - 1;  // the level0 row that is complete now
             const f32x4 ldone = lacc[0];
