@@ -56,6 +56,8 @@ from centerpose_amd import distributed as cpd  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, dense f32 matrix
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense f16/bf16 matrix
 PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md, HBM3E
+# the kernels of the DCN layers' offset / mask convolutions (32-wide N tile): patch-resident (halo16.hip) and row-streamed (strm16.hip)
+OFFSET_CONV_KERNELS = ("halo16_f16x3_m128n32", "strm16_f16x3_w32n32")
 DCN_MB_PER_IMG = 95.36  # sum over the 16 DCNv2 layers of (Cin + 27 + Cout) * HW * 4 + weights, 512x512
 DECODE_MB_PER_IMG = 0.66  # one read of hm + hm_hp, gathers, 47 KB of records
 GFLOP_PER_IMG = {"dlav1_34": 106.85, "dla_34": 85.11, "dla_34_track": 109.68,
@@ -359,15 +361,15 @@ def roofline_object(prof, roles, sampled, batch, precision, workload=None):
             roof["traffic"] = t["hbm_bytes_per_launch"]
             roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `%s`)" % meta.get("command", "bench.py")
             if "dcn" in roof:
-                # the DCN pair's counter bytes per step: every DCN main kernel that ran + the offset convolutions (N = 32 halo tile),
+                # the DCN pair's counter bytes per step: every DCN main kernel that ran + the offset convolutions (OFFSET_CONV_KERNELS),
                 # each kernel's PMC bytes per launch x its launches per step in THIS run
                 tot, main, missing = 0.0, 0.0, []
                 for k, v in prof.items():
-                    if k.startswith(("dcn16", "dcn_igemm16")) or k == "halo16_f16x3_m128n32":
+                    if k.startswith(("dcn16", "dcn_igemm16")) or k in OFFSET_CONV_KERNELS:
                         if k in pmc:
                             b = pmc[k]["hbm_bytes_per_launch"] * (v["launches"] / sampled)
                             tot += b
-                            main += b if k != "halo16_f16x3_m128n32" else 0.0
+                            main += b if k not in OFFSET_CONV_KERNELS else 0.0
                         else:
                             missing.append(k)
                 if tot > 0 and not missing:

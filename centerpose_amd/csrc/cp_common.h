@@ -200,7 +200,8 @@ int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream);
 // K steps (of 16 for the f32 kernels, 32 for f16x3) and output tiles of the launch cp_launch_conv[16] would make
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 41
+#define CP_NUM_CONV_VARIANTS 42
+#define CP_VARIANT_STRM16 41
 #define CP_VARIANT_GRU 26
 // split-f16 ("f16x3") implicit GEMM (igemm16.hip)
 bool cp_conv16_supported(const ConvParams& p);
@@ -213,6 +214,10 @@ int cp_launch_halo16_fused_head(const ConvParams& p, hipStream_t stream);
 bool cp_halo16_gru_supported(const ConvParams& p);
 int cp_launch_halo16_gru(const ConvParams& p, hipStream_t stream);
 int cp_launch_halo16(const ConvParams& p, int bn, hipStream_t stream);
+// strm16.hip: 64 -> <= 32 channel 3x3 / stride-1 layers (DCN offset / mask convolutions) as wave-private row streams, weights in LDS
+bool cp_strm16_supported(const ConvParams& p);
+int cp_strm16_jobs(const ConvParams& p);
+int cp_launch_strm16(const ConvParams& p, hipStream_t stream);
 // fused DCNv2 gather + contraction (dcn16.hip); bn = N tile (64 / 128), variant = alternative wave count (tuning)
 int cp_launch_dcn16(const ConvParams& p, int bn, int variant, hipStream_t stream);
 // dcn16p.hip: patch-resident DCNv2 (gather from an LDS-staged halo); N tile 64, or 128 where cp_dcn16p_wide says so

@@ -993,6 +993,13 @@ static bool dcn16t_wanted(const ConvParams& p) {
     return !cp_dcn16p_wide(p) && cp_dcn16p_blocks(p) >= 1024;
 }
 
+// 64 -> <= 32 channel 3x3 layers (DCN offset / mask convolutions) with at least one (strip, band) job per wave slot of the chip: the
+// row-streaming kernel of strm16.hip.  cp_set_debug: 268435456 = never, 536870912 = every eligible layer (tests).
+static bool strm16_wanted(const ConvParams& p) {
+    if ((p.dbg & 268435456) || (p.dbg & 4096) || !cp_strm16_supported(p)) return false;
+    return (p.dbg & 536870912) || cp_strm16_jobs(p) >= 1024;
+}
+
 static bool halo16_wanted(const ConvParams& p, int bn) {
     if ((p.dbg & 4096) || p.gn_in_a || !cp_halo16_supported(p)) return false;
     // with the weight fragments coming straight from L2 (no barrier inside a chunk) the halo kernel beats the per-tap
@@ -1052,6 +1059,7 @@ int cp_launch_conv16(const ConvParams& p, hipStream_t stream) {
     // cp_set_debug: 4096 = never, 8192 = every eligible layer (A/B runs).
     // small launches on 64 x 64 tiles (ConvParams::tile_m): the LDS-staged loop, whatever the layer shape
     if (bn == 64 && p.tile_m == 64) return cat ? launch16<1, 1, 2, 2, false, true>(p, stream) : launch16<1, 1, 2, 2, false, false>(p, stream);
+    if (bn == 32 && strm16_wanted(p)) return cp_launch_strm16(p, stream);
     if (halo16_wanted(p, bn)) return cp_launch_halo16(p, bn, stream);
     if (pw16_wanted(p)) return cp_launch_pw16(p, stream);
     if (bn == 128) return cat ? launch16<2, 2, 2, 2, false, true>(p, stream) : launch16<2, 2, 2, 2, false, false>(p, stream);
@@ -1065,6 +1073,7 @@ int cp_conv16_variant(const ConvParams& p) {
     if (p.offmask) return dcn16t_wanted(p) ? CP_VARIANT_DCN16T : dcn16s_wanted(p) ? CP_VARIANT_DCN16S : dcn16p_wanted(p) ? (cp_dcn16p_wide(p) ? CP_VARIANT_DCN16PW : CP_VARIANT_DCN16P) : bn == 128 ? 18 : 17;
     const int t = bn == 32 ? 0 : bn == 64 ? 1 : 2;
     if (bn == 64 && p.tile_m == 64) return CP_VARIANT_M64N64;
+    if (bn == 32 && strm16_wanted(p)) return CP_VARIANT_STRM16;
     if (halo16_wanted(p, bn)) return 27 + t;
     if (pw16_wanted(p)) return CP_VARIANT_PW16 + (p.CoutPad % 128 == 0 ? 1 : 0);
     return (p.nsrc > 1 ? 19 : 14) + t;

@@ -259,6 +259,44 @@ def test_halo_resident_conv3x3_vs_float64_and_previous_kernel(device, f16x3, B, 
     assert not torch.equal(out, old) or Cin == 64   # two different kernels really ran (summation order differs)
 
 
+@pytest.mark.parametrize("B,H,W,act", [
+    (2, 16, 32, 0),     # one strip, one band per image
+    (3, 8, 48, 1),      # a ragged second strip (16 of 32 columns), a band of 8 rows, ReLU
+    (1, 40, 40, 2),     # ragged strip and ragged last band (8 of 16 rows), sigmoid on every channel
+    (2, 33, 100, 0),    # odd height: a band of ONE row (an odd row count runs one more turn of the two-row loop); 4 strips
+    (5, 128, 128, 2),   # the offset convolutions' own map size: more jobs than one workgroup's waves, several jobs per wave
+])
+def test_streamed_conv3x3_c64_n32_vs_float64_and_other_kernels(device, f16x3, B, H, W, act):
+    """strm16.hip (64 -> <= 32 channel 3x3 layers as wave-private row streams, weights in LDS; cp_set_debug 536870912: at any size)
+    against a float64 convolution and against the kernel it replaces (268435456: halo16's 32-wide tile where the map tiles into
+    8 x 16 patches, the per-tap implicit GEMM otherwise -- both sum in the same order); the sigmoid by hardware exp2 / rcp
+    (|error| < 3e-7) instead of expf.  How the profile shows that strm16 ran: test_backbone_at_bench_batch_every_image_every_launch."""
+    g = torch.Generator().manual_seed(B * 100 + H + W)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(32, 64, 3, 3, generator=g) / (64 * 9) ** 0.5
+    scale = 0.5 + torch.rand(32, generator=g)
+    shift = torch.randn(32, generator=g)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    ref = F.relu(ref) if act == 1 else torch.sigmoid(ref) if act == 2 else ref
+    args = (x.permute(0, 2, 3, 1).contiguous().to(device), w.to(device), scale.to(device), shift.to(device), None, 1, 1, act)
+    outs = {}
+    for name, dbg in (("strm16", 536870912), ("other", 268435456)):
+        hip.lib().cp_set_debug(dbg)
+        try:
+            outs[name] = hip.conv2d_nhwc(*args).permute(0, 3, 1, 2).cpu().double()
+            again = hip.conv2d_nhwc(*args).permute(0, 3, 1, 2).cpu().double()
+        finally:
+            hip.lib().cp_set_debug(0)
+        assert torch.equal(outs[name], again), name
+        assert float((outs[name] - ref).abs().max() / ref.abs().max()) < 2e-5, name
+    assert float((outs["strm16"] - outs["other"]).abs().max() / ref.abs().max()) < 2e-6
+    if act != 2:
+        # all three kernels sum a 64-channel layer in the same order (tap, 16-channel group; lo.hi, hi.lo, hi.hi): bit-equal
+        assert torch.equal(outs["strm16"], outs["other"])
+    else:
+        assert not torch.equal(outs["strm16"], outs["other"])   # (the sigmoid forms differ: two different kernels really ran)
+
+
 def test_dcn_both_precisions_vs_oracle(device, precision):
     g = torch.Generator().manual_seed(77)
     x = torch.randn(2, 64, 24, 20, generator=g)
@@ -623,9 +661,10 @@ def test_backbone_at_bench_batch_spot_parity(device, arch, B, pick):
 
 # kernel names (cp_kernel_variant_name) every bench-size forward must have launched: the hot path of SURVEY 8(a) M2-M7
 _HOT_VARIANTS = ("halo16_head_f16x3", "halo16_f16x3_m128n128", "halo16_f16x3_m128n64", "halo16_f16x3_m128n32", "pw16_f16x3",
-                 "lowc_stem_level0", "lowc_3x3s2", "igemm16_f16x3", "dcn16t_f16x3", "dcn16p_f16x3")
+                 "lowc_stem_level0", "lowc_3x3s2", "igemm16_f16x3", "dcn16t_f16x3", "dcn16p_f16x3", "strm16_f16x3")
 # (the CenterPoseTrack networks add the previous-frame stems' outputs to the stem's: their first two layers stay two kernels)
-_HOT_VARIANTS_TRACK = tuple(v for v in _HOT_VARIANTS if v != "lowc_stem_level0") + ("lowc_stem7x7", "lowc_3x3_c16")
+# (and at their B = 16 the 128^2 offset convolutions have too few (strip, band) jobs for the row-streaming kernel)
+_HOT_VARIANTS_TRACK = tuple(v for v in _HOT_VARIANTS if v not in ("lowc_stem_level0", "strm16_f16x3")) + ("lowc_stem7x7", "lowc_3x3_c16")
 
 
 @pytest.mark.parametrize("arch,B,reps", [("dla_34", 64, 60), ("dlav1_34", 32, 60)])
@@ -753,6 +792,8 @@ def _many_launches(f, n):
     ("halo16 N=64 (64->64 @128^2 BasicBlock)", 32, 128, 64, 64, 3, 1, True, 200),
     ("halo16 N=128 (256->256 @32^2)", 64, 32, 256, 256, 3, 1, True, 200),
     ("halo16 N=32 (offset convolution 64->27)", 32, 128, 64, 27, 3, 1, False, 200),
+    ("strm16 (64->32 @128^2, one band of 16 rows per wave slot)", 64, 128, 64, 32, 3, 1, False, 200),
+    ("strm16 (64->32 @128^2, B = 32: bands of 8 rows)", 32, 128, 64, 32, 3, 1, False, 200),
     ("igemm16p stride 2 (64->128 @128^2)", 32, 128, 64, 128, 3, 2, False, 200),
     ("pw16 1x1 (128->128 @64^2)", 64, 64, 128, 128, 1, 1, False, 200),
     ("pw16 1x1 (512->256 @16^2... Root)", 64, 16, 512, 256, 1, 1, True, 200),
