@@ -45,6 +45,8 @@ def variant(kname):
         return "dcn16t_f16x3_p128n64"
     if "strm16_kernel" in kname:
         return "strm16_f16x3_w32n32"
+    if "lowc2_kernel" in kname:
+        return "lowc_stem_level0_f16x3"
     mh = re.search(r"halo16_kernel<(\d+), (\d+), (\d+), (\d+)(?:, (?:true|false)(?:, (\d+))?)?", kname)
     if mh:  # <MT, NT, WM, WN[, BDIRECT[, EPI]]>
         mt, nt, wm, wn = (int(mh.group(i)) for i in range(1, 5))
