@@ -174,3 +174,58 @@ def test_device_code_has_no_packed_op_with_a_set_op_sel_bit(tmp_path):
             n_insts += 0
     assert n_insts > 0          # the disassembly worked (dcn16.hip's broadcast FMAs are packed ops)
     assert not bad, bad[:8]
+
+
+def test_streaming_kernels_keep_their_prefetch_lead_in_the_built_library(tmp_path):
+    """The row loops of the barrier-free streaming kernels (lowc.hip: lowc2_kernel, strm16.hip: strm16_kernel) request input rows
+    two / three rows ahead.  hipcc's wait-count pass silently removes that lead -- `s_waitcnt vmcnt(0)` at the loop head -- as soon
+    as the loop holds a branch around a load or store, a waterfall loop (lane-variant soffset), a register copy between prefetch
+    buffers, or when the scheduler re-orders the prologue's requests (profiles/NOTES.md, round 6: every one of these happened).
+    Nothing fails when it does; the kernel is just 1.4 - 4 x slower.  So: disassemble the built library, find each kernel's loops
+    (backward branches) that hold its MFMAs and its row requests, and fail on any `vmcnt(0)` inside."""
+    import re
+    import shutil
+    import subprocess
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    so = tmp_path / "lib.so"
+    shutil.copy(hip.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
+    want = {"strm16_kernel": (100, 9), "lowc2_kernel": (30, 3)}   # kernel -> (MFMAs, buffer loads) its row loop holds at least
+    found = {}
+    head = re.compile(r"^[0-9a-f]+ <(\S+)>:$")
+    inst = re.compile(r"^\s+(\S+)(.*?)//\s*([0-9A-Fa-f]+):")
+    tgt = re.compile(r"<\S+\+0x([0-9a-fA-F]+)>")
+    for o in sorted(p for p in tmp_path.iterdir() if "amdgcn" in p.name):
+        dis = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(o)], check=True, capture_output=True, text=True).stdout
+        fn, start, body = None, 0, []
+        funcs = {}
+        for line in dis.splitlines():
+            m = head.match(line)
+            if m:
+                fn, body = m.group(1), []
+                funcs[fn] = body
+                start = int(line.split()[0], 16)
+                continue
+            m = inst.match(line)
+            if m and fn:
+                t = tgt.search(line)
+                body.append((int(m.group(3), 16), m.group(1), m.group(2), start + int(t.group(1), 16) if t and m.group(1).startswith(("s_cbranch", "s_branch")) else None))
+        for name, body in funcs.items():
+            key = next((k for k in want if k in name), None)
+            if not key:
+                continue
+            loops = [(t, a) for a, op, _, t in body if t is not None and t <= a]
+            for lo, hi in loops:
+                ins = [(op, rest) for a, op, rest, _ in body if lo <= a <= hi]
+                n_mfma = sum(op.startswith("v_mfma") for op, _ in ins)
+                n_ld = sum(op.startswith("buffer_load") for op, _ in ins)
+                if n_mfma >= want[key][0] and n_ld >= want[key][1]:
+                    drains = [op + rest for op, rest in ins if op == "s_waitcnt" and "vmcnt(0)" in rest]
+                    counted = [rest for op, rest in ins if op == "s_waitcnt" and "vmcnt(" in rest and "vmcnt(0)" not in rest]
+                    found.setdefault(key, []).append((n_mfma, n_ld, len(counted), drains))
+    for key in want:
+        assert key in found, (key, "row loop not found in the disassembly", sorted(found))
+        for n_mfma, n_ld, n_counted, drains in found[key]:
+            assert n_counted >= 1 and not drains, (key, n_mfma, n_ld, n_counted, drains[:4])
