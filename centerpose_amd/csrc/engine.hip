@@ -995,7 +995,9 @@ struct Fwd {
                 cp_conv_geometry(p, use16, &tiles, &nk);
             }
             // (64 x 64 tiles are a quarter of the work each: they are still cut along K below one workgroup per CU)
-            if (tiles > 0 && tiles < (p.tile_m == 64 ? 256 : kSplitTiles) && nk >= 8 && !p.gn_stats) {
+            // (cp_set_debug 536870912 -- tests: the row-streaming kernel at any size -- keeps such a layer whole)
+            const bool force_strm = use16 && (g_dbg & 536870912) && cp_strm16_supported(p);
+            if (tiles > 0 && tiles < (p.tile_m == 64 ? 256 : kSplitTiles) && nk >= 8 && !p.gn_stats && !force_strm) {
                 int want = (kSplitTarget + tiles - 1) / tiles;
                 if (want > nk / 2) want = nk / 2;
                 if (want > 32) want = 32;

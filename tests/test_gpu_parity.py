@@ -949,6 +949,37 @@ def test_backbone_vs_reference_golden(device, arch, tracking, prec):
         np.testing.assert_allclose(torch.sigmoid(z[k]).cpu().numpy(), 1 / (1 + np.exp(-gold[k])), rtol=0, atol=1e-3)
 
 
+@pytest.mark.parametrize("arch,tracking", CONFIGS)
+def test_backbone_with_row_streamed_offset_convolutions_vs_reference_golden(device, arch, tracking):
+    """The reference goldens again with the 64-channel conv_offset_mask layers forced onto strm16.hip at the goldens' small size
+    (cp_set_debug 536870912; by default the kernel only takes them from B = 32 at 128 x 128): 27 of 32 channels, the mask sigmoid
+    from channel 18 (dcn_v2.py:105-125), few jobs per workgroup.  Same gates as test_backbone_vs_reference_golden, and against the
+    default dispatch the heads may differ only by what the sigmoid form (exp2 / rcp, < 3e-7 per mask) propagates."""
+    heads = synth.HEADS_TRACK if tracking else synth.HEADS_POSE
+    gold = np.load(os.path.join(GOLD, "backbone_%s.npz" % synth.config_key(arch, tracking)))
+    sd = synth.make_state_dict(arch, heads, tracking)
+    x, kw = mg.backbone_inputs(tracking)
+    model = hip.HipModel(arch, heads, sd, tracking_task=tracking, precision="f16x3")
+    args = (x.to(device),), {k: v.to(device) for k, v in kw.items()}
+    z0 = {k: v.clone() for k, v in model(*args[0], **args[1]).items()}
+    hip.lib().cp_set_debug(536870912)
+    try:
+        model.profile(True)
+        z = {k: v.clone() for k, v in model(*args[0], **args[1]).items()}
+        torch.cuda.synchronize()
+        ran = model.profile_read()
+        model.profile(False)
+    finally:
+        hip.lib().cp_set_debug(0)
+    assert any(name.startswith("strm16_f16x3") for name in ran), sorted(ran)
+    for k in heads:
+        ref = gold[k]
+        np.testing.assert_allclose(z[k].cpu().numpy(), ref, rtol=0, atol=1e-3 * max(1.0, np.abs(ref).max()), err_msg=k)
+        assert float((z[k] - z0[k]).abs().max()) < 2e-5 * max(1.0, float(z0[k].abs().max())), k
+    for k in ("hm", "hm_hp"):
+        np.testing.assert_allclose(torch.sigmoid(z[k]).cpu().numpy(), 1 / (1 + np.exp(-gold[k])), rtol=0, atol=1e-3)
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("arch", ["dla_34", "dlav1_34"])
 def test_backbone_512_vs_oracle_and_batch_invariance(device, arch, prec):
