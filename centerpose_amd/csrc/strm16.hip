@@ -8,17 +8,21 @@
 //   * a WAVE streams down a 32-pixel-wide column strip on its own: no barrier after the start, no LDS shared between waves
 //     except the read-only weights.  Per input row: 34 pixels x 64 channels (8.7 KB, one coalesced piece, requested two rows
 //     ahead) -> x 2^e, hi / lo halves -> a wave-private LDS row (pixel pitch 144 B: conflict-free fragment reads) -> the 12 A
-//     fragments (3 columns x 4 channel groups) are read ONCE and each is multiplied into the THREE rolling accumulators of the
-//     output rows the input row belongs to (kernel rows 2, 1, 0 of rows j - 1, j, j + 1): 108 MFMAs per input row and wave
-//     against ~90 VALU and 27 stores -- the row is matrix-bound;
+//     fragment pairs (3 columns x 4 channel groups) are read ONCE and each is multiplied into the THREE rolling accumulators of
+//     the output rows the input row belongs to (kernel rows 2, 1, 0 of rows j - 1, j, j + 1): 108 MFMAs per input row and wave
+//     against ~350 VALU (split, epilogue, accumulator rotation), 96 LDS fragment reads and 4 sixteen-byte stores per lane;
 //   * the whole weight tensor (36 K steps x hi / lo x 1 KB = 72 KB in MFMA operand order) sits in LDS, loaded once per
 //     workgroup: a weight fragment is a conflict-free ds_read_b128, not a texture-path load per wave;
-//   * one persistent workgroup of 8 waves per CU (72 KB of weights + 8 x 9.8 KB of row buffers), jobs = (image, strip, band of
-//     16 rows) dealt round-robin; a band re-reads one row above and one below (the MFMAs of rows outside the band are skipped);
+//   * one persistent workgroup of 8 waves per CU (72 KB of weights + 8 x 10.1 KB of row buffers), jobs = (image, strip, band of
+//     16 rows) dealt wave-major; a band re-reads one row above and one below, and the row products that belong to output rows
+//     outside the band are formed and dropped (6 of 54: cheaper than a branch in front of every MFMA);
 //   * products transposed (weights as the first operand): a lane's accumulator quad = four consecutive channels of its pixel ->
 //     16-byte stores, scale / shift read as float4.
-// K order per output row: (kernel row, kernel column, 16-channel group) -- another summation order than halo16 (chunk, tap, half):
-// results agree to float32 round-off.
+// K order per output row: (kernel row, kernel column, 16-channel group; lo.hi, hi.lo, hi.hi) -- for a 64-channel layer the order of
+// halo16.hip (one chunk: tap, 16-channel group) and of the per-tap kernel: linear / ReLU outputs are bit-identical to theirs.  The
+// mask sigmoid is exp2 / rcp here (cp_fast_sigmoid, |error| < 3e-7) where those kernels call expf.
+// The row loop is branch-free on purpose (out-of-range buffer offsets, arithmetic masks, two register buffers used in turn):
+// profiles/NOTES.md round 6 lists what each kind of branch costs; tests/test_host_cpu.py checks the built loop for counted waits.
 #include "igemm16_common.h"
 
 namespace {
@@ -221,17 +225,17 @@ int cp_strm16_jobs(const ConvParams& p) { return p.B * ((p.W + SM_W - 1) / SM_W)
 
 int cp_launch_strm16(const ConvParams& p, hipStream_t stream) {
     if (!cp_strm16_supported(p)) return CP_ERR_INVALID;
-    static int cus = 0;
-    static bool attr_ok = false;
-    if (!cus) {
-        int dev = 0;
+    // per device (a process normally drives one): CU count, and the opt-in to more than 64 KB of dynamic LDS
+    static int cus_of[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return CP_ERR_LAUNCH;
+    if (!cus_of[dev]) {
         hipDeviceProp_t prop;
-        cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
-        attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&strm16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS) == hipSuccess;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&strm16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS) != hipSuccess)
+            return CP_ERR_LAUNCH;
+        cus_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    if (!attr_ok) return CP_ERR_LAUNCH;
+    const int cus = cus_of[dev];
     // bands of 16 rows (2 of 18 input rows re-read, 6 of 54 row products unused); of 8 when that is what fills the chip's wave slots
     const int strips = (p.W + SM_W - 1) / SM_W;
     const int rows = p.B * strips * ((p.H + 15) / 16) >= cus * SM_WAVES * 3 / 4 ? 16 : 8;
