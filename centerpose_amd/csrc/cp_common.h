@@ -200,8 +200,9 @@ int cp_launch_splitk_epilogue(const ConvParams& p, hipStream_t stream);
 // K steps (of 16 for the f32 kernels, 32 for f16x3) and output tiles of the launch cp_launch_conv[16] would make
 void cp_conv_geometry(const ConvParams& p, bool f16x3, int* tiles, int* nk);
 const char* cp_conv_variant_name(int v);
-#define CP_NUM_CONV_VARIANTS 42
+#define CP_NUM_CONV_VARIANTS 43
 #define CP_VARIANT_STRM16 41
+#define CP_VARIANT_LOWC1S 42
 #define CP_VARIANT_GRU 26
 // split-f16 ("f16x3") implicit GEMM (igemm16.hip)
 bool cp_conv16_supported(const ConvParams& p);

@@ -134,7 +134,7 @@ int g_default_precision = CP_PREC_F32;
 // split-K policy: launches with fewer output tiles than kSplitTiles (and >= 8 K steps) are cut into K slices until
 // about kSplitTarget workgroups exist
 constexpr int kSplitTiles = 128, kSplitTarget = 384;  // (384 / 512 measured: B=32 equal, hourglass B=1 latency +7 %)
-int g_dbg = 0;  // cp_set_debug (include/centerpose_hip_testing.h: kernel SELECTION switches for the parity tests and A/B runs; every choice computes the layer correctly): 8 split-K epilogue element-wise (not the quad form), 1 grouped heads write slabs + reduction launch, 2 grouped heads one workgroup per head (not per patch), 16 small launches on 128-row tiles, 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel, 256 unfused ConvGRU step, 512 no activation |max| tracking / pre-scale, 1024 previous DCN loop, 2048 alternative DCN wave counts, 4096 / 8192 halo kernel never / everywhere, 16384 LDS-staged weights in the N=32 halo kernel, 32768 / 65536 patch-resident DCN never / everywhere, 524288 patch-resident DCN never on the 128-wide N tile, 1048576 / 2097152 streamed DCN (dcn16s) never / everywhere, 33554432 / 67108864 three-workgroup DCN (dcn16t) everywhere / never, 134217728 stem and level0 as two kernels (not the fused one), 268435456 / 536870912 row-streamed 64 -> <= 32 channel 3x3 layers (strm16) never / at any size, 131072 GroupNorm'd heads' 1x1 on the matrix cores, 4194304 1x1 layers on the LDS-staged loop instead of pw16.hip, 8388608 cp_dcnv2_forward always on the generic kernel, 16777216 fused heads one launch per head instead of one grouped launch
+int g_dbg = 0;  // cp_set_debug (include/centerpose_hip_testing.h: kernel SELECTION switches for the parity tests and A/B runs; every choice computes the layer correctly): 8 split-K epilogue element-wise (not the quad form), 1 grouped heads write slabs + reduction launch, 2 grouped heads one workgroup per head (not per patch), 16 small launches on 128-row tiles, 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel, 256 unfused ConvGRU step, 512 no activation |max| tracking / pre-scale, 1024 previous DCN loop, 2048 alternative DCN wave counts, 4096 / 8192 halo kernel never / everywhere, 16384 LDS-staged weights in the N=32 halo kernel, 32768 / 65536 patch-resident DCN never / everywhere, 524288 patch-resident DCN never on the 128-wide N tile, 1048576 / 2097152 streamed DCN (dcn16s) never / everywhere, 33554432 / 67108864 three-workgroup DCN (dcn16t) everywhere / never, 134217728 stem and level0 as two kernels (not the fused one), 262144 / 1073741824 level1 never / always on the row-streaming kernel, 268435456 / 536870912 row-streamed 64 -> <= 32 channel 3x3 layers (strm16) never / at any size, 131072 GroupNorm'd heads' 1x1 on the matrix cores, 4194304 1x1 layers on the LDS-staged loop instead of pw16.hip, 8388608 cp_dcnv2_forward always on the generic kernel, 16777216 fused heads one launch per head instead of one grouped launch
 
 struct DeformW {
     ConvW offset;  // conv_offset_mask (27 -> 32 padded), shift = bias
@@ -565,6 +565,7 @@ struct Packer {
             }
         }
         lowc("base.level1", "base.level1.0", 2, 32, 16, 3);
+        lowc("base.level1.rows", "base.level1.0", 5, 32, 16, 3, "base.level1");   // the row-streaming level1 kernel's fragments
         if (has_pre_img) lowc("base.pre_img_layer", "base.pre_img_layer.0", 0, 16, 3, 7);
         if (has_pre_hm) lowc("base.pre_hm_layer", "base.pre_hm_layer.0", 0, 16, 1, 7);
         if (has_pre_hm_hp) lowc("base.pre_hm_hp_layer", "base.pre_hm_hp_layer.0", 3, 16, 8, 7);
@@ -1128,12 +1129,19 @@ struct Fwd {
 
     // the network's first layers through lowc.hip (f16x3 mode only); returns an invalid Tensor when not applicable
     Tensor lowc(const std::string& name, int kind, const float* in, int H, int W, int planes, const unsigned* in_amax) {
-        auto it = m->lowc.find(name);
-        if (m->precision != CP_PREC_F16X3 || it == m->lowc.end() || (g_dbg & 64)) return Tensor();
-        const ConvW& w = cw(name);
+        if (m->precision != CP_PREC_F16X3 || (g_dbg & 64)) return Tensor();
         const int Ho = kind == 2 ? (H - 1) / 2 + 1 : H, Wo = kind == 2 ? (W - 1) / 2 + 1 : W;
+        // level1: the row-streaming kernel (lowc1s_kernel, kind 5) from the batch at which bands of >= 8 output rows give every wave
+        // slot of the chip a strip (cp_set_debug 262144: never, 1073741824: at any size -- tests)
+        if (kind == 2 && m->lowc.count(name + ".rows") && !(g_dbg & 262144) &&
+            ((g_dbg & 1073741824) || (long)B * ((Wo + 31) / 32) * ((Ho + 7) / 8) >= 2048))
+            kind = 5;
+        auto it = m->lowc.find(kind == 5 ? name + ".rows" : name);
+        if (it == m->lowc.end()) return Tensor();
+        const ConvW& w = cw(name);
         const bool stem = kind == 0 || kind == 3;  // 3: the 8-plane stem (two groups of 4 planes)
-        const int cout = kind == 2 ? 32 : 16, cin = stem ? planes : 16, k = stem ? 7 : 3;
+        const bool l1 = kind == 2 || kind == 5;
+        const int cout = l1 ? 32 : 16, cin = stem ? planes : 16, k = stem ? 7 : 3;
         Tensor out = make(cout, Ho, Wo);
         if (m->dry) return out;
         auto launch = [&]() {
@@ -1142,12 +1150,12 @@ struct Fwd {
         };
         if (m->profile) {
             cp_model::ProfRec r;
-            r.variant = CP_VARIANT_LOWC0 + (kind == 3 ? 0 : kind);
+            r.variant = kind == 5 ? CP_VARIANT_LOWC1S : CP_VARIANT_LOWC0 + (kind == 3 ? 0 : kind);
             r.role = CP_ROLE_LOWC;
             const double M = (double)B * Ho * Wo;
             r.flops = 2.0 * M * cout * (double)(k * k * cin);
             r.bytes = 4.0 * ((double)B * H * W * cin + M * cout + (double)k * k * cin * cout);
-            r.M = (int)M; r.N = cout; r.K = k * k * cin; r.kh = k; r.stride = kind == 2 ? 2 : 1;
+            r.M = (int)M; r.N = cout; r.K = k * k * cin; r.kh = k; r.stride = l1 ? 2 : 1;
             r.e0 = m->get_event();
             r.e1 = m->get_event();
             (void)hipEventRecord(r.e0, s);

@@ -385,7 +385,7 @@ const char* cp_conv_variant_name(int v) {
         "lowc_stem7x7_f16x3", "lowc_3x3_c16_f16x3", "lowc_3x3s2_c16_f16x3", "igemm16_gru_f16x3_m128n96",
         "halo16_f16x3_m128n32", "halo16_f16x3_m128n64", "halo16_f16x3_m128n128", "dcn16p_f16x3_p128n64", "gn_final_f32_valu", "halo16_head_f16x3_m128n128",
         "halo16_gru_f16x3_m128n96", "pw16_f16x3_m128n64", "pw16_f16x3_m128n128", "dcn16s_f16x3_p128n64", "igemm16_f16x3_m64n64", "dcn16p_f16x3_p128n128",
-        "dcn16t_f16x3_p128n64", "lowc_stem_level0_f16x3", "strm16_f16x3_w32n32"};
+        "dcn16t_f16x3_p128n64", "lowc_stem_level0_f16x3", "strm16_f16x3_w32n32", "lowc_3x3s2_c16_rows_f16x3"};
     return (v >= 0 && v < CP_NUM_CONV_VARIANTS) ? names[v] : "?";
 }
 

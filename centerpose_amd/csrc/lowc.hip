@@ -23,6 +23,7 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
@@ -520,6 +521,217 @@ __global__ void pack_lowc_weights(const float* __restrict__ w, uint16_t* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// level1 (3x3 / stride 2, 16 -> 32, + BatchNorm + ReLU; pose_dla_dcn.py:310-322 `_make_conv_level(16, 32, 1, stride=2)`) as a row
+// stream: 25.2 MB per 512 x 512 image against 0.3 GFLOP -- nothing but memory traffic, which the tile kernel above moves at
+// 3.75 TB/s behind its barriers.  The structure of strm16.hip: a wave owns a strip of 32 output columns (65 input columns) and a band
+// of output rows; an input row (65 px x 16 ch x 4 B = 4.1 KB, requested four rows ahead, branch-free) is split into hi / lo halves
+// in a wave-private LDS row -- even and odd columns in separate planes, so the stride-2 fragment of a kernel column is a
+// conflict-free ds_read_b128 at pitch 48 B -- and multiplied into the rolling accumulators of the output rows it belongs to: an even
+// row 2y is kernel row 1 of output row y, an odd row 2y + 1 kernel row 2 of y (which is then complete) and kernel row 0 of y + 1.
+// The nine weight fragments (one per tap: 32 output channels x 16 input channels, hi / lo, 18 KB) sit in LDS; products transposed
+// (weights first), so a lane holds four consecutive channels of its pixel per accumulator quad: 16-byte stores.
+constexpr int L1_W = 32;                    // output columns per strip
+constexpr int L1_PIECES = (2 * L1_W + 1) * 4;   // float4 pieces of an input row (65 pixels x 4)
+constexpr int L1_NLD = (L1_PIECES + 63) / 64;   // loads per lane and row (5; the last round's spare lanes land in spare slots)
+constexpr int L1_PITCH = 48;                // bytes per pixel and plane (16 halfs + 16 B)
+constexpr int L1_PLANE = 40 * L1_PITCH;     // even or odd columns of a row: 33 / 32 used + the spare slots of pieces 260 .. 319
+constexpr int L1_ROWB = 4 * L1_PLANE;       // hi even, hi odd, lo even, lo odd
+constexpr int L1_WAVES = 8;
+constexpr int L1_WB = 9 * 2 * 1024;         // weight fragments [tap][hi, lo][64 lanes][16 B]
+constexpr int L1_TPITCH = 144;              // bytes per pixel of the epilogue's transposition rows (32 channels x 4 B + 16)
+constexpr int L1_TRB = 32 * L1_TPITCH;
+constexpr int L1_LDS = L1_WB + L1_WAVES * (L1_ROWB + L1_TRB);   // 114 KB: one workgroup per CU
+constexpr int L1_PF = 4;                    // input rows requested ahead = register buffers used in turn (odd, even, odd, even)
+static_assert(L1_LDS > 80 * 1024 && L1_LDS <= 160 * 1024, "one workgroup per CU");
+
+struct Lowc1Params {
+    const float* in;   // NHWC [B][H][W][16]
+    float* out;        // NHWC [B][Ho][Wo][32]
+    const void *w_hi, *w_lo;   // fragments [9 taps][64 lanes][8 halfs] (pack kind 5)
+    const float *scale, *shift;
+    const unsigned* in_amax;
+    unsigned* out_amax;
+    int B, H, W, Ho, Wo, rows, strips, bands, njobs;
+};
+
+__global__ __launch_bounds__(64 * L1_WAVES, 1) void lowc1s_kernel(const Lowc1Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char l1_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const u32x4* gh = reinterpret_cast<const u32x4*>(p.w_hi);
+        const u32x4* gl = reinterpret_cast<const u32x4*>(p.w_lo);
+        u32x4* ws = reinterpret_cast<u32x4*>(l1_smem);
+        for (int i = tid; i < 9 * 64; i += 64 * L1_WAVES) {
+            const int t = i >> 6, l = i & 63;
+            ws[(2 * t) * 64 + l] = gh[i];
+            ws[(2 * t + 1) * 64 + l] = gl[i];
+        }
+    }
+    __syncthreads();
+    float afwd = 1.f, ainv = 1.f;
+    if (p.in_amax) cp_amax_to_scale(cp_amax_read(p.in_amax), &afwd, &ainv);
+    afwd = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(afwd)));
+    ainv = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ainv)));
+    unsigned char* row_b = l1_smem + L1_WB + wid * (L1_ROWB + L1_TRB);   // [hi even | hi odd | lo even | lo odd]
+    unsigned char* tr_b = row_b + L1_ROWB;
+    const unsigned char* w_b = l1_smem + lane * 16;
+    const int px = lane & 31, kg = lane >> 5;
+    float4 sc[4], sh[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const int n0 = 8 * g4 + 4 * kg;
+        sc[g4] = p.scale ? *reinterpret_cast<const float4*>(p.scale + n0) : make_float4(1.f, 1.f, 1.f, 1.f);
+        sh[g4] = p.shift ? *reinterpret_cast<const float4*>(p.shift + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sc[g4].x *= ainv; sc[g4].y *= ainv; sc[g4].z *= ainv; sc[g4].w *= ainv;
+    }
+    float amax = 0.f;
+    // LDS slot of this lane's pieces: piece i = lane + 64 k = pixel i / 4 (input column 2 x0 - 1 + i / 4), channel quad i % 4
+    int wo[L1_NLD];
+#pragma unroll
+    for (int k = 0; k < L1_NLD; ++k) {
+        const int i = lane + 64 * k, pp = i >> 2;
+        wo[k] = (pp & 1) * L1_PLANE + (pp >> 1) * L1_PITCH + (i & 3) * 8;
+    }
+
+    // (block-major: the eight waves of a workgroup take neighbouring strips of one band -- whole rows of the picture per workgroup)
+    for (int job = (int)blockIdx.x * L1_WAVES + wid; job < p.njobs; job += (int)gridDim.x * L1_WAVES) {
+        int t = job;
+        const int sx = t % p.strips;
+        t /= p.strips;
+        const int band = t % p.bands, b = t / p.bands;
+        const int x0 = sx * L1_W;
+        const int y0 = band * p.rows, y1 = min(y0 + p.rows, p.Ho);
+        const int jlast = 2 * y1 - 1;   // the last input row of the band
+        const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + (size_t)b * p.H * p.W * 16), 0,
+                                                                            (int)((unsigned)p.H * (unsigned)p.W * 64u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * p.Ho * p.Wo * 32, 0,
+                                                                             (int)((unsigned)p.Ho * (unsigned)p.Wo * 128u), 0x00020000);
+        unsigned cvo[L1_NLD];
+#pragma unroll
+        for (int k = 0; k < L1_NLD; ++k) {
+            const int i = lane + 64 * k, c = 2 * x0 - 1 + (i >> 2);
+            cvo[k] = (i < L1_PIECES && (unsigned)c < (unsigned)p.W) ? (unsigned)(c * 64 + (i & 3) * 16) : 0xffffffffu;
+        }
+        const float col_okf = x0 + px < p.Wo ? 1.f : 0.f;
+        float4 pf[L1_PF][L1_NLD];
+        auto request = [&](int j, float4 (&v)[L1_NLD]) {
+            const bool row_ok = (unsigned)j < (unsigned)p.H && j <= jlast;   // (rows behind the band: nothing is fetched)
+            const int so = row_ok ? j * p.W * 64 : 0;
+#pragma unroll
+            for (int k = 0; k < L1_NLD; ++k) {
+                const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r_in, (int)(row_ok ? cvo[k] : 0xffffffffu), so, 0);
+                v[k] = make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < L1_PF; ++d) {
+            request(2 * y0 - 1 + d, pf[d]);
+            __builtin_amdgcn_sched_barrier(0);   // requests stay in row order (strm16.hip: what the other order costs)
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+        // registers -> hi / lo halves in the wave's LDS row; the buffer then takes the request four rows on
+        auto stage = [&](const int j, float4 (&buf)[L1_NLD]) {
+#pragma unroll
+            for (int k = 0; k < L1_NLD; ++k) {
+                const float4 v = buf[k];
+                uint32_t h0, l0, h1, l1;
+                split2(v.x * afwd, v.y * afwd, &h0, &l0);
+                split2(v.z * afwd, v.w * afwd, &h1, &l1);
+                *reinterpret_cast<u32x2*>(row_b + wo[k]) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(row_b + 2 * L1_PLANE + wo[k]) = u32x2{l0, l1};
+            }
+            request(j + L1_PF, buf);
+            __builtin_amdgcn_wave_barrier();
+        };
+        // acc += kernel row kh x the staged row: three taps, kernel column kw reads pixel 2 x + kw = even[x], odd[x], even[x + 1]
+        auto mac = [&](const int kh, f32x16& a) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ao = (kw == 1 ? L1_PLANE : 0) + (px + (kw == 2 ? 1 : 0)) * L1_PITCH + kg * 16;
+                const h8 xh = *reinterpret_cast<const h8*>(row_b + ao), xl = *reinterpret_cast<const h8*>(row_b + 2 * L1_PLANE + ao);
+                const int tp = kh * 3 + kw;
+                const h8 wh = *reinterpret_cast<const h8*>(w_b + (2 * tp) * 1024), wl = *reinterpret_cast<const h8*>(w_b + (2 * tp + 1) * 1024);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, a, 0, 0, 0);
+            }
+        };
+        // odd input row j = 2 y + 1: closes output row y (kernel row 2), stores it, and opens row y + 1 (kernel row 0)
+        auto odd_row = [&](const int j, float4 (&buf)[L1_NLD]) {
+            stage(j, buf);
+            mac(2, acc);
+            f32x16 nxt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nxt[r] = 0.f;
+            mac(0, nxt);
+            __builtin_amdgcn_wave_barrier();
+            const int o = (j - 1) >> 1;   // (j = 2 y0 - 1: o = y0 - 1, masked)
+            const unsigned okm = ~(unsigned)((o - y0) >> 31) & (unsigned)((o - y1) >> 31);
+            const float okf = __uint_as_float(okm & __float_as_uint(col_okf));
+            // BatchNorm + ReLU where a lane knows its channels (quad g4 = channels 8 g4 + 4 kg .. + 3 of pixel px), then through the
+            // wave's transposition rows: stored straight from this layout a 16-byte store would touch 64 different 128-byte lines
+            // (lane = pixel); after the exchange lane l holds quad l % 8 of pixel l / 8 + 8 i and a store writes 8 whole lines
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 y;
+                y.x = fmaxf(acc[4 * g4] * sc[g4].x + sh[g4].x, 0.f);
+                y.y = fmaxf(acc[4 * g4 + 1] * sc[g4].y + sh[g4].y, 0.f);
+                y.z = fmaxf(acc[4 * g4 + 2] * sc[g4].z + sh[g4].z, 0.f);
+                y.w = fmaxf(acc[4 * g4 + 3] * sc[g4].w + sh[g4].w, 0.f);
+                amax = fmaxf(amax, fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w)) * okf);
+                *reinterpret_cast<float4*>(tr_b + px * L1_TPITCH + (2 * g4 + kg) * 16) = y;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // (the two "no store" marks are OR-ed in AFTER the sum: added, a masked row and a masked column would wrap into range)
+            const unsigned row_out = (unsigned)(o * p.Wo) * 128u, row_no = ~okm & 0x80000000u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pxo = (lane >> 3) + 8 * i;
+                const u32x4 pk = *reinterpret_cast<const u32x4*>(tr_b + pxo * L1_TPITCH + (lane & 7) * 16);
+                const unsigned col_no = x0 + pxo < p.Wo ? 0u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(pk, r_out, (int)((row_out + (unsigned)((x0 + pxo) * 128 + (lane & 7) * 16)) | row_no | col_no), 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+            acc = nxt;
+        };
+        auto even_row = [&](const int j, float4 (&buf)[L1_NLD]) {
+            stage(j, buf);
+            mac(1, acc);
+            __builtin_amdgcn_wave_barrier();
+        };
+        // rows 2 y0 - 1 .. 2 y1 - 1, four per turn; what a turn runs past the band is neither fetched nor stored
+        for (int j = 2 * y0 - 1; j <= jlast; j += 4) {
+            odd_row(j, pf[0]);
+            even_row(j + 1, pf[1]);
+            odd_row(j + 2, pf[2]);
+            even_row(j + 3, pf[3]);
+        }
+    }
+    if (p.out_amax) cp_amax_commit(p.out_amax, amax);
+}
+
+// level1's weights for lowc1s_kernel: one fragment per tap, first-operand order (lane = output channel lane % 32, input channels
+// 8 (lane / 32) .. + 7)
+__global__ void pack_lowc1s_weights(const float* __restrict__ w, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                    const float* __restrict__ fwd, int cin) {
+    const int total = 9 * 64 * 8;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int j = idx & 7, lane = (idx >> 3) & 63, tp = idx >> 9;
+        const int co = lane & 31, ci = (lane >> 5) * 8 + j;
+        float v = 0.f;
+        if (ci < cin) v = w[(((size_t)co * cin + ci) * 3 + tp / 3) * 3 + tp % 3];
+        uint32_t h, l;
+        split2(fwd ? v * fwd[co] : v, 0.f, &h, &l);
+        hi[idx] = (uint16_t)(h & 0xffffu);
+        lo[idx] = (uint16_t)(l & 0xffffu);
+    }
+}
+
 template <int CIN, int KS, int S, int COUT, int TW, int TH, bool NCHW_IN, int NG = 1>
 int launch_lowc(const LowcParams& p, hipStream_t s) {
     const int tiles = ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH) * p.B;
@@ -532,8 +744,9 @@ int launch_lowc(const LowcParams& p, hipStream_t s) {
 // kind: 0 stem 7x7 (NCHW input with `planes` <= 4 channels, pad 3) -> 16; 1 level0 3x3 16->16; 2 level1 3x3/2 16->32;
 //       3 stem 7x7 with 5..8 input planes (two groups of 4) -> 16
 //       4 level0's weights in the row order of the fused stem + level0 kernel (pack only; launched by cp_launch_lowc_fused)
+//       5 level1's weights, one fragment per tap, for the row-streaming level1 kernel (launched as kind 5)
 size_t cp_lowc_weight_halfs(int kind) {
-    return kind == 0 ? (size_t)7 * 1 * 512 : kind == 1 ? (size_t)5 * 1 * 512 : kind == 2 ? (size_t)5 * 2 * 512 : kind == 4 ? (size_t)6 * 512 : (size_t)14 * 512;
+    return kind == 0 ? (size_t)7 * 1 * 512 : kind == 1 ? (size_t)5 * 1 * 512 : kind == 2 ? (size_t)5 * 2 * 512 : kind == 4 ? (size_t)6 * 512 : kind == 5 ? (size_t)9 * 512 : (size_t)14 * 512;
 }
 
 int cp_launch_pack_lowc(int kind, const float* w, void* hi, void* lo, const float* fwd, int cin, hipStream_t s) {
@@ -546,6 +759,8 @@ int cp_launch_pack_lowc(int kind, const float* w, void* hi, void* lo, const floa
                            fwd, 16, cin, 4);
     } else if (kind == 4) {
         hipLaunchKernelGGL(pack_lowc_rows_weights, dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, fwd, 16, cin);
+    } else if (kind == 5) {
+        hipLaunchKernelGGL(pack_lowc1s_weights, dim3(16), dim3(256), 0, s, w, (uint16_t*)hi, (uint16_t*)lo, fwd, cin);
     } else return CP_ERR_INVALID;
     return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
 }
@@ -609,6 +824,42 @@ int cp_launch_lowc(int kind, const float* in, float* out, const void* w_hi, cons
         if (planes < 5 || planes > 8) return CP_ERR_INVALID;
         p.Ho = H; p.Wo = W; p.pad = 3;
         return launch_lowc<4, 7, 1, 16, 64, 8, true, 2>(p, s);
+    }
+    if (kind == 5) {
+        Lowc1Params q;
+        q.in = in; q.out = out; q.w_hi = w_hi; q.w_lo = w_lo; q.scale = scale; q.shift = shift; q.in_amax = in_amax; q.out_amax = out_amax;
+        q.B = B; q.H = H; q.W = W;
+        q.Ho = (H + 2 - 3) / 2 + 1; q.Wo = (W + 2 - 3) / 2 + 1;
+        if ((size_t)H * W * 64 >= (size_t)0x70000000u || (size_t)q.Ho * q.Wo * 128 >= (size_t)0x70000000u) return CP_ERR_INVALID;
+        static int cus_of[16] = {0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return CP_ERR_LAUNCH;
+        if (!cus_of[dev]) {
+            hipDeviceProp_t prop;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lowc1s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS) != hipSuccess)
+                return CP_ERR_LAUNCH;
+            cus_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        const int cus = cus_of[dev];
+        q.strips = (q.Wo + L1_W - 1) / L1_W;
+        // the tallest band of output rows that still gives every wave slot of the chip a job (B = 16 / 32 at 512 x 512: 16 / 32 rows,
+        // one job per wave: 5.2 / 4.7 TB/s).  At twice that (B = 64: 1.6 GB through the kernel) the chip moves MORE with a quarter of
+        // its CUs idle -- measured 0.43 - 0.44 ms on 256 CUs at every band height against 0.365 on 192 with 32-row bands dealt in three
+        // turns (profiles/r06_level1_rows_ab.txt: it is the number of CUs injecting requests, not the waves per CU, the band
+        // geometry or the image order) -- so large launches run on three quarters of the CUs.
+        int rows = 64;
+        while (rows > 8 && B * q.strips * ((q.Ho + rows - 1) / rows) < cus * L1_WAVES) rows >>= 1;
+        int use_cus = cus;
+        if (B * q.strips * ((q.Ho + 31) / 32) >= 2 * cus * L1_WAVES) {
+            rows = 32;
+            use_cus = cus * 3 / 4;
+        }
+        q.rows = rows;
+        q.bands = (q.Ho + rows - 1) / rows;
+        q.njobs = B * q.strips * q.bands;
+        const int blocks = (q.njobs + L1_WAVES - 1) / L1_WAVES < use_cus ? (q.njobs + L1_WAVES - 1) / L1_WAVES : use_cus;
+        hipLaunchKernelGGL(lowc1s_kernel, dim3(blocks), dim3(64 * L1_WAVES), L1_LDS, s, q);
+        return hipGetLastError() == hipSuccess ? CP_OK : CP_ERR_LAUNCH;
     }
     return CP_ERR_INVALID;
 }

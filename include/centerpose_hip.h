@@ -39,7 +39,7 @@ typedef struct cp_model cp_model;
  * meaning.  History: 1 = round-1 header; 2 = cp_preprocess takes the FORWARD 2x3 affine as double[6] and inverts it
  * itself (round 1: the inverse as float[6]); 3 = cp_dcnv2_forward accepts every shape of the reference op (generic
  * kernel), cp_num_kernel_variants() / cp_num_roles() size the profile buffers; 4 = cp_track_* added; 5 = cp_track_status, list truncation instead of reset on overflow;
- * 6 = cp_preprocess_batch, cp_linear_assignment, CP_NUM_KERNEL_VARIANTS 42, cp_set_debug moved out of this header (centerpose_hip_testing.h). */
+ * 6 = cp_preprocess_batch, cp_linear_assignment, CP_NUM_KERNEL_VARIANTS 43, cp_set_debug moved out of this header (centerpose_hip_testing.h). */
 #define CP_ABI_VERSION 6
 const char* cp_version(void);
 int cp_abi_version(void);
@@ -137,7 +137,7 @@ int cp_model_set_precision(cp_model* m, int precision);
  * pair.  cp_model_profile_read drains them: out[v*4 + 0..3] = {launches, total milliseconds, total
  * algorithmic FLOPs (2*M*Cout*KH*KW*Cin), total algorithmic bytes (input + output + weights
  * [+ offsets/mask] [+ residual], float32)} per kernel variant v in [0, CP_NUM_KERNEL_VARIANTS). */
-#define CP_NUM_KERNEL_VARIANTS 42
+#define CP_NUM_KERNEL_VARIANTS 43
 int cp_num_kernel_variants(void); /* the value the LIBRARY was built with: size cp_model_profile_read's buffer from it */
 int cp_model_profile(cp_model* m, int enable);
 int cp_model_profile_read(cp_model* m, double* out, int num_variants);

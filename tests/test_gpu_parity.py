@@ -868,6 +868,44 @@ def test_fused_stem_level0_vs_two_kernels_and_oracle(device, arch, B, h, w):
         assert float((z1[k][B - 1:].cpu() - zo[k]).abs().max()) < 1e-3 * max(1.0, float(zo[k].abs().max())), k
 
 
+@pytest.mark.parametrize("arch,B,h,w", [("dla_34", 2, 128, 128), ("dla_34", 2, 96, 160), ("dlav1_34", 1, 256, 256), ("dla_34", 3, 512, 512),
+                                        ("dla_34", 1, 32, 32), ("dla_34", 5, 64, 224), ("dla_34", 2, 160, 352)])
+def test_row_streamed_level1_vs_tile_kernel_and_float64(device, arch, B, h, w):
+    """lowc1s_kernel (level1, 3x3 / stride 2, 16 -> 32 as a row stream: even / odd input columns in separate LDS planes, two rolling
+    accumulators; cp_set_debug 1073741824: at any size, 262144: never) on level1's output (tap) against the tile kernel -- other
+    MFMA shape, other summation order: float32 round-off -- and against a float64 convolution of level0's output with the folded
+    BatchNorm + ReLU (pose_dla_dcn.py:310-322).  Sizes: strips that end inside the picture (80 / 112 / 176 output columns), one band
+    and several, pictures smaller than a strip, several jobs per wave."""
+    heads = synth.HEADS_POSE
+    sd = synth.make_state_dict(arch, heads)
+    x = synth.frames(B, seed=29, h=h, w=w).to(device)
+    model = hip.HipModel(arch, heads, sd, precision="f16x3")
+    outs = {}
+    for name, dbg, want in (("rows", 1073741824, "lowc_3x3s2_c16_rows"), ("tile", 262144, "lowc_3x3s2_c16_f16x3")):
+        hip.lib().cp_set_debug(dbg)
+        try:
+            model.profile(True)
+            _, t = model.forward(x, tap="base.level1")
+            ran = model.profile_read()
+            model.profile(False)
+            outs[name] = t.clone()
+            _, t2 = model.forward(x, tap="base.level1")
+            assert torch.equal(outs[name], t2), name   # deterministic
+        finally:
+            hip.lib().cp_set_debug(0)
+        assert any(n.startswith(want) for n in ran), (name, sorted(ran))
+    _, l0 = model.forward(x, tap="base.level0")
+    wgt = sd["base.level1.0.weight"].double()
+    bn = {k: sd["base.level1.1." + k].double() for k in ("weight", "bias", "running_mean", "running_var")}
+    ref = F.conv2d(l0.double().cpu(), wgt, None, 2, 1)
+    scale = bn["weight"] / torch.sqrt(bn["running_var"] + 1e-5)
+    ref = F.relu(ref * scale.view(1, -1, 1, 1) + (bn["bias"] - bn["running_mean"] * scale).view(1, -1, 1, 1))
+    assert outs["rows"].shape == outs["tile"].shape == ref.shape == (B, 32, (h - 1) // 2 + 1, (w - 1) // 2 + 1)
+    top = max(1.0, float(ref.abs().max()))
+    assert float((outs["rows"].double().cpu() - ref).abs().max()) < 2e-5 * top
+    assert float((outs["rows"] - outs["tile"]).abs().max()) < 4e-6 * top
+
+
 def test_first_layers_are_stable_over_many_launches(device):
     """lowc.hip (7x7 stem, level0, level1 -- 8 % of the step) at launches larger than the chip: the level1 activation of a batch of
     16 frames (tap), 100 forwards, odd ones with the batch in reversed image order: per image bit-identical to the first forward."""

@@ -47,6 +47,8 @@ def variant(kname):
         return "strm16_f16x3_w32n32"
     if "lowc2_kernel" in kname:
         return "lowc_stem_level0_f16x3"
+    if "lowc1s_kernel" in kname:
+        return "lowc_3x3s2_c16_rows_f16x3"
     mh = re.search(r"halo16_kernel<(\d+), (\d+), (\d+), (\d+)(?:, (?:true|false)(?:, (\d+))?)?", kname)
     if mh:  # <MT, NT, WM, WN[, BDIRECT[, EPI]]>
         mt, nt, wm, wn = (int(mh.group(i)) for i in range(1, 5))
