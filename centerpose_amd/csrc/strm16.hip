@@ -99,8 +99,6 @@ __global__ __launch_bounds__(64 * SM_WAVES, 1) void strm16_kernel(const ConvPara
             const int i = lane + 64 * k, c = x0 - 1 + (i >> 4);
             cvo[k] = (i < SM_Q && (unsigned)c < (unsigned)p.W) ? (unsigned)(c * 256 + (i & 15) * 16) : 0xffffffffu;
         }
-        // output column of this lane: byte offset inside a row, or beyond the range check (then any row offset added stays beyond)
-        const unsigned col_out = x0 + px < p.W ? (unsigned)((x0 + px) * p.ldo) * 4u : 0x80000000u;
         const float col_okf = x0 + px < p.W ? 1.f : 0.f;
         float4 pf[SM_PF][SM_NLD];
         auto request = [&](int j, float4 (&v)[SM_NLD]) {
@@ -171,8 +169,11 @@ __global__ __launch_bounds__(64 * SM_WAVES, 1) void strm16_kernel(const ConvPara
             // all ones when y0 <= o < y1 -- by arithmetic: a selection on the row test became a scalar branch in the row loop, and
             // every branch there costs the counted waits on the row requests (s_waitcnt vmcnt(0) at the loop head)
             const unsigned okm = ~(unsigned)((o - y0) >> 31) & (unsigned)((o - y1) >> 31);
-            const unsigned vout = ((unsigned)(o * p.W * p.ldo) * 4u + col_out) | (~okm & 0x80000000u);
             const float okf = __uint_as_float(okm & __float_as_uint(col_okf));
+            // scale / shift / activation where a lane knows its channels (quad g4 = channels 8 g4 + 4 kg .. + 3 of pixel px), then through
+            // the wave's row buffer (free until the next row is staged; LDS operations of a wave execute in order): stored straight
+            // from this layout, a 16-byte store touches 64 different 128-byte lines (lane = pixel); after the exchange lane l holds
+            // channel quad l % 8 of pixel l / 8 + 8 i and a store writes 8 whole lines (measured on the level1 stream: -16 %)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int n0 = 8 * g4 + 4 * kg;
@@ -191,9 +192,20 @@ __global__ __launch_bounds__(64 * SM_WAVES, 1) void strm16_kernel(const ConvPara
                     v[e] = n0 + e < p.Cout ? v[e] : 0.f;
                     amax = fmaxf(amax, fabsf(v[e]) * okf);
                 }
-                const u32x4 pk = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                __builtin_amdgcn_raw_buffer_store_b128(pk, r_out, (int)(n0 < p.Cout ? vout + (unsigned)n0 * 4u : 0x80000000u), 0, 0);
+                *reinterpret_cast<float4*>(row_hi + px * SM_PITCH + (2 * g4 + kg) * 16) = make_float4(v[0], v[1], v[2], v[3]);
             }
+            __builtin_amdgcn_wave_barrier();
+            // (the "no store" marks are OR-ed in after the sum: added, a masked row and a masked column could wrap into range)
+            const unsigned row_out = (unsigned)(o * p.W * p.ldo) * 4u, row_no = ~okm & 0x80000000u;
+            const unsigned q_no = 4 * (lane & 7) < p.Cout ? 0u : 0x80000000u;   // channel quads beyond Cout are not written
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pxo = (lane >> 3) + 8 * i;
+                const u32x4 pk = *reinterpret_cast<const u32x4*>(row_hi + pxo * SM_PITCH + (lane & 7) * 16);
+                const unsigned col_no = x0 + pxo < p.W ? 0u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(pk, r_out, (int)((row_out + (unsigned)(((x0 + pxo) * p.ldo + (lane & 7) * 4) * 4)) | row_no | col_no | q_no), 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
             racc[0] = racc[1];
             racc[1] = racc[2];
 #pragma unroll
