@@ -134,7 +134,7 @@ int g_default_precision = CP_PREC_F32;
 // split-K policy: launches with fewer output tiles than kSplitTiles (and >= 8 K steps) are cut into K slices until
 // about kSplitTarget workgroups exist
 constexpr int kSplitTiles = 128, kSplitTarget = 384;  // (384 / 512 measured: B=32 equal, hourglass B=1 latency +7 %)
-int g_dbg = 0;  // cp_set_debug (include/centerpose_hip_testing.h: kernel SELECTION switches for the parity tests and A/B runs; every choice computes the layer correctly): 8 split-K epilogue element-wise (not the quad form), 1 grouped heads write slabs + reduction launch, 2 grouped heads one workgroup per head (not per patch), 16 small launches on 128-row tiles, 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel, 256 unfused ConvGRU step, 512 no activation |max| tracking / pre-scale, 1024 previous DCN loop, 2048 alternative DCN wave counts, 4096 / 8192 halo kernel never / everywhere, 16384 LDS-staged weights in the N=32 halo kernel, 32768 / 65536 patch-resident DCN never / everywhere, 524288 patch-resident DCN never on the 128-wide N tile, 1048576 / 2097152 streamed DCN (dcn16s) never / everywhere, 33554432 / 67108864 three-workgroup DCN (dcn16t) everywhere / never, 134217728 stem and level0 as two kernels (not the fused one), 262144 / 1073741824 level1 never / always on the row-streaming kernel, 268435456 / 536870912 row-streamed 64 -> <= 32 channel 3x3 layers (strm16) never / at any size, 131072 GroupNorm'd heads' 1x1 on the matrix cores, 4194304 1x1 layers on the LDS-staged loop instead of pw16.hip, 8388608 cp_dcnv2_forward always on the generic kernel, 16777216 fused heads one launch per head instead of one grouped launch
+int g_dbg = 0;  // cp_set_debug (include/centerpose_hip_testing.h: kernel SELECTION switches for the parity tests and A/B runs; every choice computes the layer correctly): 4 1x1 layers with fragment-shaped A loads (pw16_kernel) instead of whole lines through staging rows (pw16s_kernel), 8 split-K epilogue element-wise (not the quad form), 1 grouped heads write slabs + reduction launch, 2 grouped heads one workgroup per head (not per patch), 16 small launches on 128-row tiles, 32 no head fusion, 64 no lowc kernels, 128 GN heads' 1x1 on the f32 kernel, 256 unfused ConvGRU step, 512 no activation |max| tracking / pre-scale, 1024 previous DCN loop, 2048 alternative DCN wave counts, 4096 / 8192 halo kernel never / everywhere, 16384 LDS-staged weights in the N=32 halo kernel, 32768 / 65536 patch-resident DCN never / everywhere, 524288 patch-resident DCN never on the 128-wide N tile, 1048576 / 2097152 streamed DCN (dcn16s) never / everywhere, 33554432 / 67108864 three-workgroup DCN (dcn16t) everywhere / never, 134217728 stem and level0 as two kernels (not the fused one), 262144 / 1073741824 level1 never / always on the row-streaming kernel, 268435456 / 536870912 row-streamed 64 -> <= 32 channel 3x3 layers (strm16) never / at any size, 131072 GroupNorm'd heads' 1x1 on the matrix cores, 4194304 1x1 layers on the LDS-staged loop instead of pw16.hip, 8388608 cp_dcnv2_forward always on the generic kernel, 16777216 fused heads one launch per head instead of one grouped launch
 
 struct DeformW {
     ConvW offset;  // conv_offset_mask (27 -> 32 padded), shift = bias

@@ -220,9 +220,15 @@ def test_pointwise_stream_kernel_vs_float64_and_lds_loop(device, f16x3, B, H, W,
         old = hip.conv2d_nhwc(*args).permute(0, 3, 1, 2).cpu()
     finally:
         hip.lib().cp_set_debug(0)
+    hip.lib().cp_set_debug(4)   # round 5's form of the stream: fragment-shaped A loads instead of whole lines through staging rows
+    try:
+        frag = hip.conv2d_nhwc(*args).permute(0, 3, 1, 2).cpu()
+    finally:
+        hip.lib().cp_set_debug(0)
     scale = float(ref.abs().max())
     assert float((out.double() - ref).abs().max()) < 2e-5 * scale
     assert float((out - old).abs().max()) < 2e-6 * scale
+    assert torch.equal(out, frag)   # the same products in the same order: only the way the A operand reaches the registers differs
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,res,act", [
