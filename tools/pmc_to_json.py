@@ -49,6 +49,9 @@ def variant(kname):
         return "lowc_stem_level0_f16x3"
     if "lowc1s_kernel" in kname:
         return "lowc_3x3s2_c16_rows_f16x3"
+    mw = re.search(r"pw16s?_kernel<(\d+)>", kname)
+    if mw:  # <NT>: the profile names both forms of the 1x1 stream by their tile
+        return "pw16_f16x3_m128n%d" % (32 * int(mw.group(1)))
     mh = re.search(r"halo16_kernel<(\d+), (\d+), (\d+), (\d+)(?:, (?:true|false)(?:, (\d+))?)?", kname)
     if mh:  # <MT, NT, WM, WN[, BDIRECT[, EPI]]>
         mt, nt, wm, wn = (int(mh.group(i)) for i in range(1, 5))
