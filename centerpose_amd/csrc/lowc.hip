@@ -530,7 +530,9 @@ __global__ void pack_lowc_weights(const float* __restrict__ w, uint16_t* __restr
 // conflict-free ds_read_b128 at pitch 48 B -- and multiplied into the rolling accumulators of the output rows it belongs to: an even
 // row 2y is kernel row 1 of output row y, an odd row 2y + 1 kernel row 2 of y (which is then complete) and kernel row 0 of y + 1.
 // The nine weight fragments (one per tap: 32 output channels x 16 input channels, hi / lo, 18 KB) sit in LDS; products transposed
-// (weights first), so a lane holds four consecutive channels of its pixel per accumulator quad: 16-byte stores.
+// (weights first: a lane holds four consecutive channels of ITS pixel per accumulator quad), and the finished values pass through
+// wave-private transposition rows so that eight lanes hold one pixel's 128 bytes and a 16-byte store instruction writes 8 whole lines
+// (straight from the accumulator layout it would touch 64 lines: measured 0.51 against 0.43 ms).
 constexpr int L1_W = 32;                    // output columns per strip
 constexpr int L1_PIECES = (2 * L1_W + 1) * 4;   // float4 pieces of an input row (65 pixels x 4)
 constexpr int L1_NLD = (L1_PIECES + 63) / 64;   // loads per lane and row (5; the last round's spare lanes land in spare slots)

@@ -177,8 +177,8 @@ def test_device_code_has_no_packed_op_with_a_set_op_sel_bit(tmp_path):
 
 
 def test_streaming_kernels_keep_their_prefetch_lead_in_the_built_library(tmp_path):
-    """The row loops of the barrier-free streaming kernels (lowc.hip: lowc2_kernel, strm16.hip: strm16_kernel) request input rows
-    two / three rows ahead.  hipcc's wait-count pass silently removes that lead -- `s_waitcnt vmcnt(0)` at the loop head -- as soon
+    """The row loops of the barrier-free streaming kernels (lowc.hip: lowc2_kernel, lowc1s_kernel, strm16.hip: strm16_kernel) request
+    input rows two to four rows ahead.  hipcc's wait-count pass silently removes that lead -- `s_waitcnt vmcnt(0)` at the loop head -- as soon
     as the loop holds a branch around a load or store, a waterfall loop (lane-variant soffset), a register copy between prefetch
     buffers, or when the scheduler re-orders the prologue's requests (profiles/NOTES.md, round 6: every one of these happened).
     Nothing fails when it does; the kernel is just 1.4 - 4 x slower.  So: disassemble the built library, find each kernel's loops
@@ -192,7 +192,8 @@ def test_streaming_kernels_keep_their_prefetch_lead_in_the_built_library(tmp_pat
     so = tmp_path / "lib.so"
     shutil.copy(hip.LIB_PATH, so)
     subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
-    want = {"strm16_kernel": (100, 9), "lowc2_kernel": (30, 3)}   # kernel -> (MFMAs, buffer loads) its row loop holds at least
+    # kernel -> (MFMAs, buffer loads) its row loop holds at least
+    want = {"strm16_kernel": (100, 9), "lowc2_kernel": (30, 3), "lowc1s_kernel": (50, 20)}
     found = {}
     head = re.compile(r"^[0-9a-f]+ <(\S+)>:$")
     inst = re.compile(r"^\s+(\S+)(.*?)//\s*([0-9A-Fa-f]+):")
