@@ -44,7 +44,7 @@ calls = {}
 for (k, c), v in acc.items():
     by_k[k][c] = sum(v) / len(v)
     calls[k] = max(calls.get(k, 0), len(v))
-keep = ("halo16", "strm16", "dcn16", "igemm16", "lowc", "gn_final", "upsample", "peaks", "assoc", "gru_gate", "maxpool")
+keep = ("halo16", "strm16", "pw16", "dcn16", "igemm16", "lowc", "gn_final", "upsample", "peaks", "assoc", "gru_gate", "maxpool")
 for k in sorted(by_k, key=lambda k: -by_k[k].get("GRBM_GUI_ACTIVE", 0) * calls[k]):
     if not any(s in k for s in keep):
         continue
