@@ -89,7 +89,10 @@ __global__ void upsample_add_kernel(const float* __restrict__ in, const float* _
                                     const float* __restrict__ add, float* __restrict__ out, int B, int H, int W, int C,
                                     int f, unsigned* __restrict__ out_amax) {
     // per-channel kernels staged once per workgroup as [tap][channel] so a lane's 4 channels are one ds_read_b128
-    extern __shared__ float wt[];
+    // (16-byte aligned and indexed in float4 units below: as a plain float array with a float index the compiler read a lane's four
+    // weights with two ds_read2_b32 -- lanes 16 bytes apart, a 4-way bank conflict on every read: three quarters of the kernel's LDS
+    // cycles, a third of its clocks x CUs, profiles/r06_pmc_sq_counters.txt)
+    extern __shared__ __attribute__((aligned(16))) float wt[];
     const int k = 2 * f, kk = k * k;
     for (int i = threadIdx.x; i < C * kk; i += blockDim.x) {
         const int c = i / kk, t = i - c * kk;
@@ -121,7 +124,7 @@ __global__ void upsample_add_kernel(const float* __restrict__ in, const float* _
                 const int kx = kx0 + bb * f, ix = ix0 - bb;
                 if (ix < 0 || ix >= W) continue;
                 const float4 v = reinterpret_cast<const float4*>(in)[((unsigned)(b * H + iy) * W + ix) * C4 + c4];
-                const float4 wv = *reinterpret_cast<const float4*>(wt + (ky * k + kx) * C + c4 * 4);
+                const float4 wv = reinterpret_cast<const float4*>(wt)[(ky * k + kx) * C4 + (int)c4];   // (float4 index: the alignment is provable)
                 s.x += v.x * wv.x;
                 s.y += v.y * wv.y;
                 s.z += v.z * wv.z;
