@@ -1,6 +1,8 @@
 // HBM-bound data-movement / element-wise kernels of the backbone (float32 NHWC, 16 B per lane).
 #include "cp_common.h"
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 namespace {
 
 constexpr int TPB = 256;
@@ -102,6 +104,7 @@ __global__ void upsample_add_kernel(const float* __restrict__ in, const float* _
     // 32-bit index math throughout (B*Ho*Wo*C/4 < 2^31 for every supported shape)
     const int p = f / 2, Ho = H * f, Wo = W * f, C4 = C >> 2;
     const unsigned total = (unsigned)B * Ho * Wo * C4;
+    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((unsigned)B * H * W * C * 4u), 0x00020000);
     float amax = 0.f;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const unsigned c4 = i % (unsigned)C4;
@@ -110,27 +113,34 @@ __global__ void upsample_add_kernel(const float* __restrict__ in, const float* _
         t /= (unsigned)Wo;
         const int y = (int)(t % (unsigned)Ho);
         const int b = (int)(t / (unsigned)Ho);
-        float4 acc = add ? reinterpret_cast<const float4*>(add)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         // ky ranges over { (y+p) % f, (y+p) % f + f }
         const int ky0 = (y + p) % f, kx0 = (x + p) % f;
         const int iy0 = (y + p - ky0) / f, ix0 = (x + p - kx0) / f;  // source of tap (ky0, kx0); the other tap is one less
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        // all five loads of the output piece are issued before anything is used, without a branch: a tap outside the source is
+        // requested beyond the buffer descriptor and comes back as zeros (s + 0 * w = s: the sum is the one of the taps inside)
+        float4 v[2][2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int ky = ky0 + a * f, iy = iy0 - a;
-            if (iy < 0 || iy >= H) continue;
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
-                const int kx = kx0 + bb * f, ix = ix0 - bb;
-                if (ix < 0 || ix >= W) continue;
-                const float4 v = reinterpret_cast<const float4*>(in)[((unsigned)(b * H + iy) * W + ix) * C4 + c4];
-                const float4 wv = reinterpret_cast<const float4*>(wt)[(ky * k + kx) * C4 + (int)c4];   // (float4 index: the alignment is provable)
-                s.x += v.x * wv.x;
-                s.y += v.y * wv.y;
-                s.z += v.z * wv.z;
-                s.w += v.w * wv.w;
+                const int iy = iy0 - a, ix = ix0 - bb;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r_in, (int)(ok ? (((unsigned)(b * H + iy) * W + ix) * C4 + c4) * 16u : 0xffffffffu), 0, 0);
+                v[a][bb] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
             }
-        }
+        float4 acc = add ? reinterpret_cast<const float4*>(add)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int ky = ky0 + a * f, kx = kx0 + bb * f;
+                const float4 wv = reinterpret_cast<const float4*>(wt)[(ky * k + kx) * C4 + (int)c4];   // (float4 index: the alignment is provable)
+                s.x += v[a][bb].x * wv.x;
+                s.y += v[a][bb].y * wv.y;
+                s.z += v[a][bb].z * wv.z;
+                s.w += v[a][bb].w * wv.w;
+            }
         acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
         amax = fmaxf(amax, fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));
         reinterpret_cast<float4*>(out)[i] = acc;
