@@ -105,45 +105,66 @@ __global__ void upsample_add_kernel(const float* __restrict__ in, const float* _
     const int p = f / 2, Ho = H * f, Wo = W * f, C4 = C >> 2;
     const unsigned total = (unsigned)B * Ho * Wo * C4;
     const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((unsigned)B * H * W * C * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(add ? add : in), 0, add ? (int)(total * 16u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(total * 16u), 0x00020000);
     float amax = 0.f;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    // One output piece = 16 bytes (4 channels of one pixel): `add` + exactly 2 x 2 source taps.  All five loads are issued before
+    // anything is used, without a branch -- a tap outside the source (and a piece beyond the tensor) is requested beyond the buffer
+    // descriptor and comes back as zeros (s + 0 * w = s: the sum is the one of the taps inside) -- and a thread handles TWO pieces per
+    // turn, so ten loads are in flight per lane: the kernel's waves spend three quarters of their cycles waiting for HBM.
+    struct Piece {
+        float4 v[2][2], acc;
+        int wi;   // float4 index of tap (ky0, kx0)'s weights; the other taps are f and f * k further on
+    };
+    auto request = [&](unsigned i, Piece& q) {
         const unsigned c4 = i % (unsigned)C4;
         unsigned t = i / (unsigned)C4;
         const int x = (int)(t % (unsigned)Wo);
         t /= (unsigned)Wo;
         const int y = (int)(t % (unsigned)Ho);
         const int b = (int)(t / (unsigned)Ho);
+        const bool live = i < total;
         // ky ranges over { (y+p) % f, (y+p) % f + f }
         const int ky0 = (y + p) % f, kx0 = (x + p) % f;
         const int iy0 = (y + p - ky0) / f, ix0 = (x + p - kx0) / f;  // source of tap (ky0, kx0); the other tap is one less
-        // all five loads of the output piece are issued before anything is used, without a branch: a tap outside the source is
-        // requested beyond the buffer descriptor and comes back as zeros (s + 0 * w = s: the sum is the one of the taps inside)
-        float4 v[2][2];
+        q.wi = (ky0 * k + kx0) * C4 + (int)c4;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
                 const int iy = iy0 - a, ix = ix0 - bb;
-                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const bool ok = live && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
                 const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r_in, (int)(ok ? (((unsigned)(b * H + iy) * W + ix) * C4 + c4) * 16u : 0xffffffffu), 0, 0);
-                v[a][bb] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
+                q.v[a][bb] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
             }
-        float4 acc = add ? reinterpret_cast<const float4*>(add)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const u32x4 ra = __builtin_amdgcn_raw_buffer_load_b128(r_add, (int)(live ? i * 16u : 0xffffffffu), 0, 0);   // (no `add`: a descriptor of size 0)
+        q.acc = make_float4(__uint_as_float(ra.x), __uint_as_float(ra.y), __uint_as_float(ra.z), __uint_as_float(ra.w));
+    };
+    auto finish = [&](unsigned i, const Piece& q) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
-                const int ky = ky0 + a * f, kx = kx0 + bb * f;
-                const float4 wv = reinterpret_cast<const float4*>(wt)[(ky * k + kx) * C4 + (int)c4];   // (float4 index: the alignment is provable)
-                s.x += v[a][bb].x * wv.x;
-                s.y += v[a][bb].y * wv.y;
-                s.z += v[a][bb].z * wv.z;
-                s.w += v[a][bb].w * wv.w;
+                const float4 wv = reinterpret_cast<const float4*>(wt)[q.wi + (a * k + bb) * f * C4];   // (float4 index: the alignment is provable)
+                s.x += q.v[a][bb].x * wv.x;
+                s.y += q.v[a][bb].y * wv.y;
+                s.z += q.v[a][bb].z * wv.z;
+                s.w += q.v[a][bb].w * wv.w;
             }
+        float4 acc = q.acc;
         acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
-        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));
-        reinterpret_cast<float4*>(out)[i] = acc;
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));   // (a piece beyond the tensor is all zeros)
+        const u32x4 pk = {__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(pk, r_out, (int)(i < total ? i * 16u : 0xffffffffu), 0, 0);
+    };
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += 2 * stride) {
+        Piece q0, q1;
+        request(i, q0);
+        request(i + stride, q1);
+        finish(i, q0);
+        finish(i + stride, q1);
     }
     if (out_amax) cp_amax_commit(out_amax, amax);
 }
