@@ -431,16 +431,20 @@ def masked_stream(device, n_cus):
 
 class PoseStage(object):
     """Post-process + soft-NMS + batched PnP of decoded batches (base_detector.py:547-654 for a whole batch), with the
-    PnP on a side stream.  The solve is at most B*K independent float64 problems of ~1e5 operations each: a few dozen
+    PnP -- and, from 8 images per batch, the post-process -- on a side stream.  The solve is at most B*K independent float64 problems of ~1e5 operations each: a few dozen
     wavefronts whose run time is the slowest lane's Levenberg-Marquardt walk (0.5 - 2.5 ms), during which the rest of
-    the chip would idle.  ``submit`` therefore queues post-process on the caller's stream and the solve on the stage's
-    own stream, so that the solve of batch i runs under the network of batch i+1; ``depth`` sets of result buffers
+    the chip would idle.  ``submit`` therefore queues the solve (and the post-process of a batch of 8 or more, behind a copy of the
+    decoded records) on the stage's own stream, so that the solve of batch i runs under the network of batch i+1; ``depth`` sets of result buffers
     rotate, and the caller's stream waits for the solve that last used a set before post-process overwrites it.
 
     submit() -> (post [B,K,120], count [B], poses [B,K,40], done): the tensors are valid once ``done`` (a
     torch.cuda.Event) has completed -- ``done.synchronize()`` on the host or ``stream.wait_event(done)``.
     Caller-owned inputs (``det``, ``meta``, ``cam``) are read on the side stream as well: the stage tells the caching
     allocator (``record_stream``), so the caller may drop them right after ``submit``."""
+
+    # batches of at least this many images post-process on the side stream too (below: on the caller's, one hop less per frame);
+    # $CP_POST_SIDE_FROM overrides (A/B runs)
+    SIDE_POST_FROM = int(os.environ.get("CP_POST_SIDE_FROM", "8"))
 
     def __init__(self, B, K, device, depth=2, cus=None):
         """``cus``: run the solve on a stream restricted to that many compute units (``masked_stream``); None = $CP_PNP_CUS or,
@@ -467,6 +471,8 @@ class PoseStage(object):
                 post=torch.empty(B, K, POST_STRIDE, dtype=torch.float64, device=device),
                 cnt=torch.empty(B, dtype=torch.int32, device=device),
                 poses=torch.empty(B, K, PNP_STRIDE, dtype=torch.float64, device=device),
+                det=torch.empty(B, K, DET_STRIDE, dtype=torch.float32, device=device),
+                meta=torch.empty(B, 8, dtype=torch.float64, device=device),
                 ws_post=torch.empty(n_post, dtype=torch.uint8, device=device),
                 ws_pnp=torch.empty(n_pnp, dtype=torch.uint8, device=device),
                 ready=torch.cuda.Event(), done=torch.cuda.Event(enable_timing=True),
@@ -479,14 +485,25 @@ class PoseStage(object):
         self.i += 1
         main = torch.cuda.current_stream()
         if not first_use:
-            main.wait_event(s["done"])  # the solve that read this set `depth` batches ago
-        postprocess(det, meta, vis_thresh, nms=nms, out=s["post"], cnt=s["cnt"], ws=s["ws_post"])
+            main.wait_event(s["done"])  # the post-process / solve that read this set `depth` batches ago
+        B = int(det.shape[0])
+        side_post = B >= self.SIDE_POST_FROM
+        if side_post:
+            # the post-process (one latency-bound launch of ~0.15 ms at B = 64: a serial soft-NMS walk per image) joins the solve on the
+            # side stream; the caller's stream only copies the decoded records (3 MB) and the per-image affine into the set, so the
+            # caller may overwrite `det` / `meta` with the next batch at once
+            s["det"][:B].copy_(det, non_blocking=True)
+            s["meta"][:B].copy_(torch.as_tensor(meta, dtype=torch.float64).reshape(B, 8).to(det.device), non_blocking=True)
+        else:
+            postprocess(det, meta, vis_thresh, nms=nms, out=s["post"], cnt=s["cnt"], ws=s["ws_post"])
         s["ready"].record(main)
         if torch.is_tensor(cam) and cam.is_cuda:
             cam.record_stream(self.side)  # read by the solve after this call returns
         with torch.cuda.stream(self.side):
             self.side.wait_event(s["ready"])
             s["begin"].record(self.side)
+            if side_post:
+                postprocess(s["det"][:B], s["meta"][:B], vis_thresh, nms=nms, out=s["post"], cnt=s["cnt"], ws=s["ws_post"])
             pnp_from_post(s["post"], s["cnt"], cam, rep_mode=rep_mode, out=s["poses"], ws=s["ws_pnp"])
             s["done"].record(self.side)
         self._timed = [(s["begin"], s["done"])]

@@ -223,10 +223,13 @@ def test_device_gaussian_render_matches_reference_golden(device):
     assert float(hip.render_gaussians(np.zeros((0, 5)), 1, 8, 8, device).abs().sum()) == 0.0
 
 
-def test_pose_stage_side_stream_matches_serial_path(device):
-    """hip.PoseStage (post-process on the caller's stream, PnP on a side stream, two rotating buffer sets) must return,
+@pytest.mark.parametrize("side_post_from", [8, 1])
+def test_pose_stage_side_stream_matches_serial_path(device, side_post_from, monkeypatch):
+    """hip.PoseStage (post-process on the caller's stream -- or, from PoseStage.SIDE_POST_FROM images per batch, behind a copy of
+    the decoded records on the side stream: both forms here --, PnP on a side stream, two rotating buffer sets) must return,
     for every batch of a stream of different batches, exactly what the serial postprocess -> pnp_from_post path
     returns -- including when a buffer set is reused while the previous solve that read it is still in flight."""
+    monkeypatch.setattr(hip.PoseStage, "SIDE_POST_FROM", side_post_from)
     B, K = 4, 100
     meta = np.zeros((B, 8))
     from centerpose_amd.lib.utils.image import get_affine_transform
@@ -252,7 +255,10 @@ def test_pose_stage_side_stream_matches_serial_path(device):
     with torch.cuda.stream(side):
         stage = hip.PoseStage(B, K, device, depth=2)
         for d in dets:
-            post, cnt, poses, done = stage.submit(d, meta_d, cam, 0.3, nms=True, rep_mode=1)
+            dd = d.clone()
+            post, cnt, poses, done = stage.submit(dd, meta_d, cam, 0.3, nms=True, rep_mode=1)
+            if side_post_from == 1:
+                dd.zero_()   # the stage works on its own copy of the decoded records: the caller's tensor is free at once
             if len(got) % 2 == 0:
                 done.synchronize()  # odd batches are read only after later submits were queued behind them
                 got.append((post.cpu().clone(), cnt.cpu().clone(), poses.cpu().clone()))
